@@ -1,0 +1,110 @@
+/*
+ * mi_unet.h -- C-ABI of the MI355X-native UNet segmentation engine (libmiunet.so).
+ *
+ * This is the drop-in seam for the reference's TensorRT call: everything between the normalised 8-bit tile and the
+ * u8 label map in MedicalSeg::execute_inference (/root/reference/src/process.cpp:123-175), i.e.
+ *     preprocess_image  u8 -> f32 /255.0f            src/process.cpp:22-42
+ *     H2D + cudaGraphLaunch(engine) + D2H            src/process.cpp:143-155
+ *     3-class first-max-wins argmax                  src/process.cpp:158-170
+ * plus the lifecycle around it (engine load: src/initialize.cpp:26-77; per-thread context with device buffers, stream
+ * and captured graph: src/process.cpp:45-120; teardown: src/cleanup.cpp:10-64).
+ *
+ * Plain pointers and sizes only; no C++/torch types.  Every function returns 0 on success or an MI_UNET_E* code and
+ * leaves a human-readable message retrievable through mi_unet_last_error() (thread local).  There is no CPU fallback:
+ * without a HIP device every entry point that needs one fails with MI_UNET_ENODEVICE.
+ */
+#ifndef MI_UNET_H
+#define MI_UNET_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MI_UNET_OK 0
+#define MI_UNET_EARG 1        /* bad argument / unsupported configuration */
+#define MI_UNET_ENODEVICE 2   /* no usable HIP device */
+#define MI_UNET_EHIP 3        /* a HIP runtime call failed (message carries hipGetErrorString) */
+#define MI_UNET_EFILE 4       /* weight file missing / malformed / topology mismatch */
+#define MI_UNET_ESTATE 5      /* call order violated (e.g. infer before load_weights) */
+
+typedef struct mi_unet mi_unet_t;
+
+typedef struct mi_unet_config {
+    int height;      /* input tile height; the reference fixes 512 (src/process.cpp:70, :126) */
+    int width;       /* input tile width;  512 */
+    int in_ch;       /* 1 (grayscale, src/process.cpp:70) */
+    int base;        /* channels of the first level, 64 */
+    int levels;      /* number of 2x down/up steps, 4 */
+    int classes;     /* 3 (src/process.cpp:162) */
+    int max_batch;   /* images processed per micro-batch; device buffers are sized for this */
+    int device;      /* HIP device ordinal (the reference uses implicit device 0) */
+} mi_unet_config;
+
+/* Fills *cfg with the reference's constants: 512x512x1, base 64, 4 levels, 3 classes, max_batch 16, device 0. */
+void mi_unet_default_config(mi_unet_config *cfg);
+
+/* Replaces createInferRuntime + per-thread context creation (src/initialize.cpp:48, src/process.cpp:45-120):
+ * allocates all device buffers and the stream.  No weights yet. */
+int mi_unet_create(const mi_unet_config *cfg, mi_unet_t **out);
+
+/* Replaces reading + deserialising the .trt engine (src/initialize.cpp:49-60).  File format: miunet/spec.py
+ * ("MIUNETW1").  Folds eval-mode BatchNorm into the conv weights, repacks for the MFMA kernels, uploads. */
+int mi_unet_load_weights(mi_unet_t *h, const char *path);
+int mi_unet_load_weights_from_memory(mi_unet_t *h, const void *blob, size_t len);
+
+/* The hot path = execute_inference (src/process.cpp:123-175) for B images at once, host buffers:
+ *   imgs   u8  [B][H][W][in_ch]              (the 8-bit normalised tile the reference reads back at :217)
+ *   labels u8  [B][H][W]          out        (class index per pixel, as pred_mask at :170)
+ *   logits f32 [B][classes][H][W] out/NULL   (planar, the reference's output binding layout :81-85, :163)
+ * B may exceed max_batch (processed in micro-batches). */
+int mi_unet_infer_u8(mi_unet_t *h, const uint8_t *imgs, int B, uint8_t *labels, float *logits);
+
+/* Same, with all three buffers already resident in device memory (HBM); asynchronous on the engine's stream.
+ * Call mi_unet_sync() before reading results from another stream. */
+int mi_unet_infer_u8_device(mi_unet_t *h, const uint8_t *d_imgs, int B, uint8_t *d_labels, float *d_logits);
+
+/* Use an external hipStream_t (e.g. the caller framework's current stream) instead of the engine's own. NULL restores it. */
+int mi_unet_set_stream(mi_unet_t *h, void *hip_stream);
+int mi_unet_sync(mi_unet_t *h);
+
+/* Time the last `mi_unet_infer_u8_device` calls: brackets with hipEvents on the engine's stream.
+ * mi_unet_timer_begin/end return elapsed milliseconds through *ms at end (end synchronises the stop event). */
+int mi_unet_timer_begin(mi_unet_t *h);
+int mi_unet_timer_end(mi_unet_t *h, float *ms);
+
+/* Per-kernel accounting of the most recent micro-batch, measured with hipEvents when profiling is enabled
+ * (mi_unet_set_profiling(h,1): serialises launches, for bench/roofline use only).
+ * Fills up to `cap` entries; returns the number of kernels launched in *n. */
+typedef struct mi_unet_kernel_stat {
+    char name[48];        /* layer name, e.g. "up4.c1" */
+    char kernel[32];      /* kernel family: conv3x3_mfma, convT2x2_mfma, conv3x3_c1, maxpool2x2, head_argmax */
+    double flops;         /* algorithmic FLOPs of this launch (2*MAC) */
+    double bytes;         /* algorithmic HBM bytes of this launch (inputs + weights + outputs, each once) */
+    float ms;             /* measured duration */
+} mi_unet_kernel_stat;
+int mi_unet_set_profiling(mi_unet_t *h, int on);
+int mi_unet_get_kernel_stats(mi_unet_t *h, mi_unet_kernel_stat *stats, int cap, int *n);
+
+/* Parity hook: run ONE layer kernel on host NHWC fp32 buffers (uploaded, run, downloaded).
+ *   op = "conv3x3"  : in [B][H][W][Cin], w [Cout][Cin][3][3], scale/shift [Cout] (folded BN; NULL = 1/0), relu flag
+ *   op = "convT2x2" : in [B][H][W][Cin], w [Cin][Cout][2][2], shift = bias [Cout]  -> out [B][2H][2W][Cout]
+ *   op = "maxpool"  : in [B][H][W][Cin]                                          -> out [B][H/2][W/2][Cin]
+ * Weights are given in PyTorch layout exactly as in the weight file. */
+int mi_unet_layer_debug(int device, const char *op, const float *in, int B, int H, int W, int Cin, const float *w,
+                        const float *scale, const float *shift, int Cout, int relu, float *out);
+
+void mi_unet_destroy(mi_unet_t *h);
+
+/* Message of the last failing call on this thread ("" if none). */
+const char *mi_unet_last_error(void);
+
+/* Number of visible HIP devices (0 when there is no driver); never fails. */
+int mi_unet_device_count(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MI_UNET_H */

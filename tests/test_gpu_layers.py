@@ -1,0 +1,103 @@
+"""Layer-by-layer parity of the HIP kernels against the oracle, through the C-ABI (mi_unet_layer_debug)."""
+import numpy as np
+import pytest
+
+import oracle_lib as orc
+from miunet import binding
+
+pytestmark = pytest.mark.gpu
+
+
+def _rng(seed):
+    return np.random.default_rng(seed)
+
+
+def _tol(ref):
+    # fp32 sums of K products in a different order: |err| <= ~K * eps * |a||b|; 1e-4 relative to the output scale is ample
+    return 1e-4 * max(1.0, float(np.abs(ref).max()))
+
+
+@pytest.mark.parametrize("B,H,W,Cin,Cout", [
+    (1, 8, 32, 16, 64),        # one exact tile
+    (2, 16, 64, 64, 64),       # several tiles, several chunks
+    (1, 5, 7, 32, 64),         # ragged: partial tile in x and y
+    (1, 12, 40, 48, 128),      # two n-tiles, partial x tile, Cin % 16 == 0
+    (1, 9, 33, 24, 32),        # Cin % 16 != 0 (masked last chunk), Cout < tile (masked columns)
+    (3, 4, 4, 128, 256),       # deep-layer shape
+    (1, 2, 2, 1024, 64),       # bottleneck of a 32x32 input: K = 9216
+])
+def test_conv3x3_mfma(B, H, W, Cin, Cout):
+    r = _rng(B * 1000 + H * 100 + W + Cin + Cout)
+    x = r.standard_normal((B, H, W, Cin), dtype=np.float32)
+    w = (r.standard_normal((Cout, Cin, 3, 3), dtype=np.float32) * np.sqrt(2.0 / (9 * Cin))).astype(np.float32)
+    scale = (1.0 + 0.1 * r.standard_normal(Cout)).astype(np.float32)
+    shift = (0.1 * r.standard_normal(Cout)).astype(np.float32)
+    got = binding.layer_debug("conv3x3", x, w, scale, shift, relu=True)
+    ref = orc.conv3x3(x, w) * scale + shift
+    ref = np.maximum(ref, 0.0)
+    assert not np.isnan(got).any(), "unwritten (NaN-poisoned) outputs"
+    assert np.max(np.abs(got - ref)) < _tol(ref)
+
+
+def test_conv3x3_no_relu_keeps_negatives():
+    r = _rng(5)
+    x = r.standard_normal((1, 8, 32, 16), dtype=np.float32)
+    w = r.standard_normal((64, 16, 3, 3), dtype=np.float32) * 0.1
+    got = binding.layer_debug("conv3x3", x, w, None, None, relu=False)
+    ref = orc.conv3x3(x, w.astype(np.float32))
+    assert (got < 0).any()
+    assert np.max(np.abs(got - ref)) < _tol(ref)
+
+
+def test_conv3x3_exact_integers_and_asymmetric_taps():
+    # small-integer data: every product and partial sum is exact in fp32, so any summation order gives the same bits;
+    # a delta weight on ONE tap/channel checks tap orientation (dy,dx not swapped or mirrored) and channel order.
+    r = _rng(11)
+    B, H, W, Cin, Cout = 1, 10, 36, 32, 64
+    x = r.integers(-4, 5, (B, H, W, Cin)).astype(np.float32)
+    w = r.integers(-3, 4, (Cout, Cin, 3, 3)).astype(np.float32)
+    got = binding.layer_debug("conv3x3", x, w)
+    assert np.array_equal(got, orc.conv3x3(x, w))
+    for (ky, kx, ci, co) in [(0, 2, 5, 7), (2, 0, 31, 63), (1, 1, 0, 0), (0, 0, 17, 33)]:
+        w = np.zeros((Cout, Cin, 3, 3), np.float32)
+        w[co, ci, ky, kx] = 1.0
+        got = binding.layer_debug("conv3x3", x, w)
+        want = np.zeros((B, H, W), np.float32)
+        ys, xs = np.arange(H)[:, None] + ky - 1, np.arange(W)[None, :] + kx - 1
+        ok = (ys >= 0) & (ys < H) & (xs >= 0) & (xs < W)
+        want[0][ok] = x[0, np.clip(ys, 0, H - 1), np.clip(xs, 0, W - 1), ci][ok]
+        assert np.array_equal(got[..., co], want)
+        assert np.count_nonzero(got) == np.count_nonzero(want)
+
+
+@pytest.mark.parametrize("B,H,W,Cin,Cout", [
+    (1, 8, 32, 64, 32),        # N = 128: taps straddle a 64-column tile boundary at Cout = 32
+    (2, 4, 4, 128, 64),
+    (1, 3, 5, 1024, 512),      # ragged, u1.t shape
+    (1, 16, 48, 128, 64),
+])
+def test_convT2x2_mfma(B, H, W, Cin, Cout):
+    r = _rng(H * 7 + W + Cin)
+    x = r.standard_normal((B, H, W, Cin), dtype=np.float32)
+    w = (r.standard_normal((Cin, Cout, 2, 2), dtype=np.float32) / np.sqrt(Cin)).astype(np.float32)
+    bias = (0.1 * r.standard_normal(Cout)).astype(np.float32)
+    got = binding.layer_debug("convT2x2", x, w, None, bias)
+    ref = orc.convT2x2(x, w, bias)
+    assert not np.isnan(got).any()
+    assert np.max(np.abs(got - ref)) < _tol(ref)
+
+
+def test_convT2x2_tap_placement_exact():
+    r = _rng(3)
+    x = r.integers(-4, 5, (1, 4, 6, 16)).astype(np.float32)
+    w = r.integers(-3, 4, (16, 64, 2, 2)).astype(np.float32)
+    bias = r.integers(-2, 3, 64).astype(np.float32)
+    got = binding.layer_debug("convT2x2", x, w, None, bias)
+    assert np.array_equal(got, orc.convT2x2(x, w, bias))
+
+
+@pytest.mark.parametrize("B,H,W,C", [(1, 2, 2, 4), (2, 6, 10, 64), (1, 64, 64, 128)])
+def test_maxpool(B, H, W, C):
+    x = _rng(C).standard_normal((B, H, W, C), dtype=np.float32)
+    got = binding.layer_debug("maxpool", x)
+    assert np.array_equal(got, orc.maxpool2x2(x))

@@ -1,0 +1,101 @@
+"""End-to-end parity of the HIP path (through the C-ABI) against the committed golden vectors and the oracle."""
+import os
+
+import numpy as np
+import pytest
+
+import oracle_lib as orc
+from miunet import binding, synth
+from miunet.spec import UNetSpec, pack_weights
+from test_oracle_unet import load_case
+
+pytestmark = pytest.mark.gpu
+
+LOGIT_TOL = 1e-3          # BASELINE.json north_star: "logits within 1e-3 fp32"
+
+
+def check_parity(labels, logits, ref_logits, ref_labels=None):
+    """north_star bar: logits within 1e-3; label maps identical -- a mismatch is tolerated ONLY where the oracle's
+    top-2 margin is itself below the logit tolerance (fp32 re-association), and is counted."""
+    assert np.max(np.abs(logits - ref_logits)) < LOGIT_TOL
+    # the device argmax follows the device's own logits exactly (first max wins)
+    assert np.array_equal(labels, orc_argmax_batch(logits))
+    if ref_labels is None:
+        ref_labels = orc_argmax_batch(ref_logits)
+    srt = np.sort(ref_logits, axis=1)
+    margin = srt[:, -1] - srt[:, -2]
+    bad = labels != ref_labels
+    assert not (bad & (margin > LOGIT_TOL)).any()
+    return int(bad.sum())
+
+
+def orc_argmax_batch(logits):
+    return np.stack([orc.argmax_planar(l) for l in logits])
+
+
+@pytest.mark.parametrize("name", ["unet_b64_l4_64", "unet_b64_l4_48x80", "unet_b16_l3_40x24", "unet_b32_l5_c3_64"])
+def test_against_golden(golden_dir, name):
+    spec, blob, imgs, want = load_case(os.path.join(golden_dir, name + ".npz"))
+    b, h, w, _ = imgs.shape
+    with binding.Engine(h, w, spec.in_ch, spec.base, spec.levels, spec.classes, max_batch=2) as eng:
+        eng.load_weights(blob)
+        labels, logits = eng.infer(imgs, want_logits=True)
+    flips = check_parity(labels, logits, want)
+    assert flips == 0
+
+
+def test_against_oracle_128_batch_and_microbatching():
+    spec = UNetSpec()
+    blob = pack_weights(spec, synth.make_weights(spec, 4321))
+    imgs = synth.make_images(5, 128, 128, 1, 0xBEEF, "blobs")
+    ref_logits, ref_labels = orc.unet_forward(blob, imgs)
+    with binding.Engine(128, 128, max_batch=2) as eng:      # 5 images through micro-batches of 2,2,1
+        eng.load_weights(blob)
+        labels, logits = eng.infer(imgs, want_logits=True)
+        flips = check_parity(labels, logits, ref_logits, ref_labels)
+        assert flips <= 2
+        # labels-only call gives the same labels; single-image calls give the same bits as the batched call
+        labels2, none = eng.infer(imgs, want_logits=False)
+        assert none is None and np.array_equal(labels, labels2)
+        l1, g1 = eng.infer(imgs[3:4], want_logits=True)
+        assert np.array_equal(l1[0], labels[3]) and np.array_equal(g1[0], logits[3])
+
+
+def test_full_size_512_one_image_vs_oracle_and_batch16_properties():
+    """configs[1] of BASELINE.json: batch 16 at 512x512.  The oracle checks one image in full; the other 15 are
+    covered by size-independent properties: batch independence (bit-identical to the single-image run), and
+    determinism across two runs."""
+    spec = UNetSpec()
+    blob = pack_weights(spec, synth.make_weights(spec, 1234))
+    imgs = synth.make_images(16, 512, 512, 1, 0x5EED, "bytes")
+    with binding.Engine(512, 512, max_batch=16) as eng:
+        eng.load_weights(blob)
+        labels, logits = eng.infer(imgs, want_logits=True)
+        labels_b, logits_b = eng.infer(imgs, want_logits=True)
+        assert np.array_equal(labels, labels_b) and np.array_equal(logits, logits_b)
+        l7, g7 = eng.infer(imgs[7:8], want_logits=True)
+        assert np.array_equal(l7[0], labels[7]) and np.array_equal(g7[0], logits[7])
+    ref_logits, ref_labels = orc.unet_forward(blob, imgs[7:8])
+    flips = check_parity(labels[7:8], logits[7:8], ref_logits, ref_labels)
+    assert flips <= 8
+    assert set(np.unique(labels)) <= {0, 1, 2}
+
+
+def test_error_paths():
+    with binding.Engine(64, 64, max_batch=1) as eng:
+        with pytest.raises(binding.MiUnetError) as ei:
+            eng.infer(np.zeros((1, 64, 64, 1), np.uint8))
+        assert ei.value.code == 5 and "Engine not initialized" in str(ei.value)     # src/process.cpp:195
+        with pytest.raises(binding.MiUnetError) as ei:
+            eng.load_weights(b"not a weight file")
+        assert ei.value.code == 4
+        spec = UNetSpec(1, 32, 4, 3)
+        with pytest.raises(binding.MiUnetError):
+            eng.load_weights(pack_weights(spec, synth.make_weights(spec, 1)))       # topology mismatch
+        with pytest.raises(binding.MiUnetError) as ei:
+            eng.load_weights("/nonexistent/engine.miw")
+        assert "Engine file not found" in str(ei.value)                              # src/initialize.cpp:43
+        with pytest.raises(ValueError):
+            eng.infer(np.zeros((1, 32, 32, 1), np.uint8))                             # src/process.cpp:126-128
+    with pytest.raises(binding.MiUnetError):
+        binding.Engine(100, 64)                                                      # not a multiple of 2^levels

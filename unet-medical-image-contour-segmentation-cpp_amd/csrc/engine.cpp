@@ -1,0 +1,597 @@
+// engine.cpp -- the C-ABI of include/mi_unet.h: handle, weight loading (BN fold + MFMA repack), device buffers,
+// the forward plan and its launches.  Host code only; every device kernel lives in kernels.hip.
+//
+// Replaces, for the reference's hot path, initialize_engine's engine deserialisation (src/initialize.cpp:49-60),
+// initialize_context's buffers/stream (src/process.cpp:45-120) and execute_inference (src/process.cpp:123-175).
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <fstream>
+#include <string>
+#include <vector>
+
+#include "../../include/mi_unet.h"
+#include "kernels.h"
+
+using namespace miunet;
+
+namespace {
+
+thread_local std::string g_err;
+
+int fail(int code, const std::string &msg)
+{
+    g_err = msg;
+    return code;
+}
+
+#define HIP_TRY(expr)                                                                                          \
+    do {                                                                                                       \
+        hipError_t e__ = (expr);                                                                               \
+        if (e__ != hipSuccess)                                                                                 \
+            return fail(MI_UNET_EHIP, std::string(#expr) + ": " + hipGetErrorString(e__));                    \
+    } while (0)
+
+struct Step {
+    enum Kind { FIRST, CONV, CONVT, POOL, HEAD } kind;
+    std::string name;
+    ConvArgs a{};                 // CONV / CONVT
+    // FIRST / POOL / HEAD operands
+    const float *src = nullptr;
+    float *dst = nullptr;
+    const float *w = nullptr, *shift = nullptr;
+    int H = 0, W = 0, C = 0, Cout = 0, ld = 0;
+    double flops_per_img = 0, bytes_per_img = 0, weight_bytes = 0;
+};
+
+}  // namespace
+
+struct mi_unet {
+    mi_unet_config cfg{};
+    int ch[8]{};
+    hipStream_t own_stream = nullptr;
+    hipStream_t stream = nullptr;
+    bool weights_loaded = false;
+    // device memory
+    float *d_weights = nullptr;     // one blob: every packed tensor (single allocation -> one broadcast / one free)
+    size_t weight_floats = 0;
+    float *d_lut = nullptr;         // 256 floats: i / 255.0f
+    float *d_cat[8]{};              // concat buffers [Bm][h_i][w_i][2*ch_i]
+    float *d_s0 = nullptr, *d_s1 = nullptr;
+    uint8_t *d_img = nullptr;       // staging for the host-buffer entry point
+    uint8_t *d_labels = nullptr;
+    float *d_logits = nullptr;
+    // pinned host staging (the reference used pageable std::vector, src/process.cpp:138,152)
+    uint8_t *h_img = nullptr;
+    uint8_t *h_labels = nullptr;
+    std::vector<Step> plan;
+    // profiling
+    bool profiling = false;
+    std::vector<mi_unet_kernel_stat> stats;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr, tev0 = nullptr, tev1 = nullptr;
+};
+
+namespace {
+
+size_t round_up(size_t v, size_t g) { return (v + g - 1) / g * g; }
+
+struct HostWeights {
+    std::vector<float> blob;                    // packed, device layout
+    struct Off { size_t w, shift; };
+    std::vector<Off> conv;                      // per 3x3 conv in file order (first one = FIRST layer layout)
+    std::vector<Off> convT;
+    Off head{};
+};
+
+// parse "MIUNETW1" (miunet/spec.py), fold BN, repack
+int build_host_weights(const mi_unet_config &cfg, const void *blob, size_t len, HostWeights &hw)
+{
+    const unsigned char *p = static_cast<const unsigned char *>(blob);
+    if (len < 36 || memcmp(p, "MIUNETW1", 8) != 0) return fail(MI_UNET_EFILE, "weight blob: bad magic (want MIUNETW1)");
+    uint32_t h[5], n;
+    float eps;
+    memcpy(h, p + 8, 20);
+    memcpy(&eps, p + 28, 4);
+    memcpy(&n, p + 32, 4);
+    if (h[0] != 1) return fail(MI_UNET_EFILE, "weight blob: unsupported version");
+    if ((int)h[1] != cfg.in_ch || (int)h[2] != cfg.base || (int)h[3] != cfg.levels || (int)h[4] != cfg.classes)
+        return fail(MI_UNET_EFILE, "weight blob: topology (in_ch/base/levels/classes) does not match the engine config");
+    if (len < 36 + (size_t)n * 4) return fail(MI_UNET_EFILE, "weight blob: truncated payload");
+    const float *cur = reinterpret_cast<const float *>(p + 36);
+    size_t left = n;
+    auto take = [&](size_t k) -> const float * {
+        if (left < k) return nullptr;
+        const float *r = cur;
+        cur += k; left -= k;
+        return r;
+    };
+    const int L = cfg.levels;
+    int ch[8];
+    for (int i = 0; i <= L; ++i) ch[i] = cfg.base << i;
+    auto &out = hw.blob;
+    auto alloc = [&](size_t k) { size_t o = out.size(); out.resize(o + round_up(k, 4), 0.f); return o; };
+
+    bool first_done = false;
+    auto add_conv = [&](int cin, int cout) -> int {
+        const float *w = take((size_t)cout * cin * 9);
+        const float *g = take(cout), *be = take(cout), *mu = take(cout), *va = take(cout);
+        if (!w || !g || !be || !mu || !va) return fail(MI_UNET_EFILE, "weight blob: payload shorter than the topology needs");
+        std::vector<double> sc(cout);
+        HostWeights::Off off{};
+        off.shift = alloc(cout);
+        for (int co = 0; co < cout; ++co) {
+            sc[co] = (double)g[co] / std::sqrt((double)va[co] + (double)eps);
+            out[off.shift + co] = (float)((double)be[co] - (double)mu[co] * sc[co]);
+        }
+        if (!first_done) {                       // FIRST layer layout: [tap][ci][co]
+            first_done = true;
+            off.w = alloc((size_t)9 * cin * cout);
+            for (int co = 0; co < cout; ++co)
+                for (int ci = 0; ci < cin; ++ci)
+                    for (int t = 0; t < 9; ++t)
+                        out[off.w + ((size_t)t * cin + ci) * cout + co] = (float)((double)w[((size_t)co * cin + ci) * 9 + t] * sc[co]);
+        } else {                                 // MFMA layout: [chunk][tap][n (padded)][KC]
+            const int nch = (cin + KC - 1) / KC;
+            const size_t cpad = round_up(cout, NPAD);
+            off.w = alloc((size_t)nch * 9 * cpad * KC);
+            for (int co = 0; co < cout; ++co)
+                for (int ci = 0; ci < cin; ++ci)
+                    for (int t = 0; t < 9; ++t)
+                        out[off.w + (((size_t)(ci / KC) * 9 + t) * cpad + co) * KC + ci % KC] =
+                            (float)((double)w[((size_t)co * cin + ci) * 9 + t] * sc[co]);
+        }
+        hw.conv.push_back(off);
+        return 0;
+    };
+    auto add_dconv = [&](int cin, int cout) -> int {
+        int rc = add_conv(cin, cout);
+        return rc ? rc : add_conv(cout, cout);
+    };
+    int rc = add_dconv(cfg.in_ch, ch[0]);
+    for (int i = 1; i <= L && !rc; ++i) rc = add_dconv(ch[i - 1], ch[i]);
+    for (int i = 1; i <= L && !rc; ++i) {
+        const int cin = ch[L - i + 1], cout = cin / 2;
+        const float *w = take((size_t)cin * cout * 4), *b = take(cout);
+        if (!w || !b) return fail(MI_UNET_EFILE, "weight blob: payload shorter than the topology needs");
+        HostWeights::Off off{};
+        off.shift = alloc(cout);
+        for (int co = 0; co < cout; ++co) out[off.shift + co] = b[co];
+        const int nch = (cin + KC - 1) / KC;
+        const size_t npad = round_up((size_t)4 * cout, NPAD);
+        off.w = alloc((size_t)nch * npad * KC);
+        for (int ci = 0; ci < cin; ++ci)
+            for (int co = 0; co < cout; ++co)
+                for (int k = 0; k < 4; ++k)
+                    out[off.w + ((size_t)(ci / KC) * npad + (size_t)k * cout + co) * KC + ci % KC] = w[((size_t)ci * cout + co) * 4 + k];
+        hw.convT.push_back(off);
+        rc = add_dconv(cin, cout);
+    }
+    if (rc) return rc;
+    const float *ow = take((size_t)cfg.classes * ch[0]), *ob = take(cfg.classes);
+    if (!ow || !ob || left != 0) return fail(MI_UNET_EFILE, "weight blob: payload length does not match the topology");
+    hw.head.w = alloc((size_t)cfg.classes * ch[0]);
+    memcpy(&out[hw.head.w], ow, sizeof(float) * cfg.classes * ch[0]);
+    hw.head.shift = alloc(cfg.classes);
+    memcpy(&out[hw.head.shift], ob, sizeof(float) * cfg.classes);
+    return 0;
+}
+
+void conv_cost(Step &s, int H, int W, int cin, int cout, int taps_flops, bool convT)
+{
+    const double px = (double)H * W;
+    s.flops_per_img = 2.0 * px * cin * cout * taps_flops;
+    const double out_px = convT ? 4.0 * px : px;
+    s.bytes_per_img = 4.0 * (px * cin + out_px * cout);
+    s.weight_bytes = 4.0 * (double)cin * cout * taps_flops;
+}
+
+// (re)build the launch plan for micro-batch capacity cfg.max_batch; pointers into d_weights need the offsets
+int build_plan(mi_unet *h, const HostWeights &hw)
+{
+    const mi_unet_config &c = h->cfg;
+    const int L = c.levels;
+    const int *ch = h->ch;
+    h->plan.clear();
+    size_t ci = 0, ti = 0;
+    auto W_ = [&](size_t off) { return h->d_weights + off; };
+
+    auto conv_step = [&](const std::string &name, const float *in, int ldc, int cin, float *out, int ldo, int co_off, int cout,
+                         int H, int Wd) {
+        Step s;
+        s.kind = Step::CONV; s.name = name;
+        s.a.in = in; s.a.wpk = W_(hw.conv[ci].w); s.a.bias = W_(hw.conv[ci].shift); s.a.out = out;
+        s.a.B = 0; s.a.H = H; s.a.W = Wd; s.a.Cin = cin; s.a.ldc = ldc; s.a.Cout = cout;
+        s.a.CoutPad = (int)round_up(cout, NPAD); s.a.ldo = ldo; s.a.co_off = co_off; s.a.relu = 1;
+        conv_cost(s, H, Wd, cin, cout, 9, false);
+        ++ci;
+        h->plan.push_back(s);
+    };
+
+    int H = c.height, Wd = c.width;
+    {   // inc.c1 : u8 image -> s0
+        Step s;
+        s.kind = Step::FIRST; s.name = "inc.c1";
+        s.w = W_(hw.conv[ci].w); s.shift = W_(hw.conv[ci].shift); s.dst = h->d_s0;
+        s.H = H; s.W = Wd; s.C = c.in_ch; s.Cout = ch[0]; s.ld = ch[0];
+        s.flops_per_img = 2.0 * H * Wd * 9.0 * c.in_ch * ch[0];
+        s.bytes_per_img = (double)H * Wd * (c.in_ch + 4.0 * ch[0]);
+        ++ci;
+        h->plan.push_back(s);
+    }
+    conv_step("inc.c2", h->d_s0, ch[0], ch[0], L > 0 ? h->d_cat[0] : h->d_s1, L > 0 ? 2 * ch[0] : ch[0], 0, ch[0], H, Wd);
+    for (int i = 1; i <= L; ++i) {
+        Step p;
+        p.kind = Step::POOL; p.name = "down" + std::to_string(i) + ".pool";
+        p.src = h->d_cat[i - 1]; p.ld = 2 * ch[i - 1]; p.dst = h->d_s0; p.H = H; p.W = Wd; p.C = ch[i - 1];
+        p.bytes_per_img = 4.0 * H * Wd * ch[i - 1] * 1.25;
+        h->plan.push_back(p);
+        H /= 2; Wd /= 2;
+        conv_step("down" + std::to_string(i) + ".c1", h->d_s0, ch[i - 1], ch[i - 1], h->d_s1, ch[i], 0, ch[i], H, Wd);
+        if (i < L)
+            conv_step("down" + std::to_string(i) + ".c2", h->d_s1, ch[i], ch[i], h->d_cat[i], 2 * ch[i], 0, ch[i], H, Wd);
+        else
+            conv_step("down" + std::to_string(i) + ".c2", h->d_s1, ch[i], ch[i], h->d_s0, ch[i], 0, ch[i], H, Wd);
+    }
+    // when L == 0 the feature map is in s1; otherwise in s0
+    float *cur = L > 0 ? h->d_s0 : h->d_s1;
+    for (int i = 1; i <= L; ++i) {
+        const int lvl = L - i, cin = ch[lvl + 1], cout = ch[lvl];
+        Step t;
+        t.kind = Step::CONVT; t.name = "up" + std::to_string(i) + ".t";
+        t.a.in = cur; t.a.wpk = W_(hw.convT[ti].w); t.a.bias = W_(hw.convT[ti].shift); t.a.out = h->d_cat[lvl];
+        t.a.H = H; t.a.W = Wd; t.a.Cin = cin; t.a.ldc = cin; t.a.Cout = cout;
+        t.a.CoutPad = (int)round_up((size_t)4 * cout, NPAD); t.a.ldo = 2 * cout; t.a.co_off = cout; t.a.relu = 0;
+        conv_cost(t, H, Wd, cin, cout, 4, true);
+        t.flops_per_img = 2.0 * (double)H * Wd * cin * cout * 4;
+        ++ti;
+        h->plan.push_back(t);
+        H *= 2; Wd *= 2;
+        conv_step("up" + std::to_string(i) + ".c1", h->d_cat[lvl], cin, cin, h->d_s1, cout, 0, cout, H, Wd);
+        conv_step("up" + std::to_string(i) + ".c2", h->d_s1, cout, cout, h->d_s0, cout, 0, cout, H, Wd);
+        cur = h->d_s0;
+    }
+    Step hd;
+    hd.kind = Step::HEAD; hd.name = "outc+argmax";
+    hd.src = cur; hd.w = W_(hw.head.w); hd.shift = W_(hw.head.shift); hd.H = H; hd.W = Wd; hd.C = ch[0]; hd.Cout = c.classes;
+    hd.flops_per_img = 2.0 * H * Wd * ch[0] * c.classes;
+    hd.bytes_per_img = (double)H * Wd * (4.0 * ch[0] + 1.0);
+    h->plan.push_back(hd);
+    return 0;
+}
+
+int run_microbatch(mi_unet *h, const uint8_t *d_imgs, int B, uint8_t *d_labels, float *d_logits)
+{
+    hipStream_t s = h->stream;
+    if (h->profiling) h->stats.clear();
+    for (Step &st : h->plan) {
+        if (h->profiling) HIP_TRY(hipEventRecord(h->ev0, s));
+        const char *kname = "";
+        hipError_t e = hipSuccess;
+        switch (st.kind) {
+        case Step::FIRST:
+            kname = "conv3x3_first";
+            e = launch_conv3x3_first(d_imgs, h->d_lut, st.w, st.shift, st.dst, B, st.H, st.W, st.C, st.Cout, st.ld, s);
+            break;
+        case Step::CONV: {
+            kname = "conv3x3_mfma";
+            ConvArgs a = st.a; a.B = B;
+            e = launch_conv3x3_mfma(a, s);
+            break;
+        }
+        case Step::CONVT: {
+            kname = "convT2x2_mfma";
+            ConvArgs a = st.a; a.B = B;
+            e = launch_convT2x2_mfma(a, s);
+            break;
+        }
+        case Step::POOL:
+            kname = "maxpool2x2";
+            e = launch_maxpool2x2(st.src, st.ld, st.dst, B, st.H, st.W, st.C, s);
+            break;
+        case Step::HEAD:
+            kname = "head_argmax";
+            e = launch_head_argmax(st.src, st.C, st.w, st.shift, st.Cout, d_logits, d_labels, B, st.H * st.W, s);
+            break;
+        }
+        if (e != hipSuccess) return fail(MI_UNET_EHIP, "launch " + st.name + ": " + hipGetErrorString(e));
+        if (h->profiling) {
+            HIP_TRY(hipEventRecord(h->ev1, s));
+            HIP_TRY(hipEventSynchronize(h->ev1));
+            mi_unet_kernel_stat ks{};
+            snprintf(ks.name, sizeof ks.name, "%s", st.name.c_str());
+            snprintf(ks.kernel, sizeof ks.kernel, "%s", kname);
+            ks.flops = st.flops_per_img * B;
+            ks.bytes = st.bytes_per_img * B + st.weight_bytes;
+            HIP_TRY(hipEventElapsedTime(&ks.ms, h->ev0, h->ev1));
+            h->stats.push_back(ks);
+        }
+    }
+    return 0;
+}
+
+int check_handle(mi_unet *h, bool need_weights)
+{
+    if (!h) return fail(MI_UNET_EARG, "null engine handle");
+    if (need_weights && !h->weights_loaded) return fail(MI_UNET_ESTATE, "Engine not initialized: load weights before inference");
+    return 0;
+}
+
+}  // namespace
+
+extern "C" {
+
+const char *mi_unet_last_error(void) { return g_err.c_str(); }
+
+int mi_unet_device_count(void)
+{
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+
+void mi_unet_default_config(mi_unet_config *cfg)
+{
+    if (!cfg) return;
+    cfg->height = 512; cfg->width = 512; cfg->in_ch = 1; cfg->base = 64; cfg->levels = 4; cfg->classes = 3;
+    cfg->max_batch = 16; cfg->device = 0;
+}
+
+int mi_unet_create(const mi_unet_config *cfg, mi_unet_t **out)
+{
+    if (!cfg || !out) return fail(MI_UNET_EARG, "mi_unet_create: null argument");
+    *out = nullptr;
+    const int L = cfg->levels;
+    if (L < 1 || L > 6) return fail(MI_UNET_EARG, "levels must be in 1..6");
+    if (cfg->height <= 0 || cfg->width <= 0 || cfg->height % (1 << L) || cfg->width % (1 << L))
+        return fail(MI_UNET_EARG, "height and width must be positive multiples of 2^levels");
+    if (cfg->in_ch != 1 && cfg->in_ch != 3) return fail(MI_UNET_EARG, "in_ch must be 1 or 3");
+    if (cfg->base < 16 || (cfg->base & (cfg->base - 1)) || cfg->base > 256)
+        return fail(MI_UNET_EARG, "base must be a power of two in 16..256");
+    if (cfg->classes < 2 || cfg->classes > 6) return fail(MI_UNET_EARG, "classes must be in 2..6");
+    if (cfg->max_batch < 1) return fail(MI_UNET_EARG, "max_batch must be >= 1");
+    int ndev = mi_unet_device_count();
+    if (ndev <= 0) return fail(MI_UNET_ENODEVICE, "no HIP device visible: libmiunet has no CPU fallback");
+    if (cfg->device < 0 || cfg->device >= ndev) return fail(MI_UNET_EARG, "device ordinal out of range");
+    HIP_TRY(hipSetDevice(cfg->device));
+
+    mi_unet *h = new mi_unet();
+    h->cfg = *cfg;
+    for (int i = 0; i <= L; ++i) h->ch[i] = cfg->base << i;
+    auto cleanup_fail = [&](int rc) { mi_unet_destroy(h); return rc; };
+#define HIP_TRY_H(expr)                                                                                        \
+    do {                                                                                                       \
+        hipError_t e__ = (expr);                                                                               \
+        if (e__ != hipSuccess)                                                                                 \
+            return cleanup_fail(fail(MI_UNET_EHIP, std::string(#expr) + ": " + hipGetErrorString(e__)));      \
+    } while (0)
+    HIP_TRY_H(hipStreamCreateWithFlags(&h->own_stream, hipStreamNonBlocking));
+    h->stream = h->own_stream;
+    HIP_TRY_H(hipEventCreate(&h->ev0));
+    HIP_TRY_H(hipEventCreate(&h->ev1));
+    HIP_TRY_H(hipEventCreate(&h->tev0));
+    HIP_TRY_H(hipEventCreate(&h->tev1));
+    const size_t Bm = cfg->max_batch, npix0 = Bm * cfg->height * cfg->width;
+    for (int i = 0; i < L; ++i)
+        HIP_TRY_H(hipMalloc(&h->d_cat[i], sizeof(float) * (npix0 >> (2 * i)) * 2 * h->ch[i]));
+    HIP_TRY_H(hipMalloc(&h->d_s0, sizeof(float) * npix0 * h->ch[0]));
+    HIP_TRY_H(hipMalloc(&h->d_s1, sizeof(float) * npix0 * h->ch[0]));
+    HIP_TRY_H(hipMalloc(&h->d_img, npix0 * cfg->in_ch));
+    HIP_TRY_H(hipMalloc(&h->d_labels, npix0));
+    HIP_TRY_H(hipMalloc(&h->d_logits, sizeof(float) * npix0 * cfg->classes));
+    HIP_TRY_H(hipHostMalloc(&h->h_img, npix0 * cfg->in_ch, hipHostMallocDefault));
+    HIP_TRY_H(hipHostMalloc(&h->h_labels, npix0, hipHostMallocDefault));
+    HIP_TRY_H(hipMalloc(&h->d_lut, sizeof(float) * 256));
+    float lut[256];
+    for (int i = 0; i < 256; ++i) lut[i] = static_cast<float>(i) / 255.0f;   // src/process.cpp:38, true division
+    HIP_TRY_H(hipMemcpy(h->d_lut, lut, sizeof lut, hipMemcpyHostToDevice));
+#undef HIP_TRY_H
+    *out = h;
+    return MI_UNET_OK;
+}
+
+int mi_unet_load_weights_from_memory(mi_unet_t *h, const void *blob, size_t len)
+{
+    if (int rc = check_handle(h, false)) return rc;
+    if (!blob) return fail(MI_UNET_EARG, "null weight blob");
+    HostWeights hw;
+    if (int rc = build_host_weights(h->cfg, blob, len, hw)) return rc;
+    HIP_TRY(hipSetDevice(h->cfg.device));
+    if (h->d_weights) { HIP_TRY(hipFree(h->d_weights)); h->d_weights = nullptr; }
+    h->weight_floats = hw.blob.size();
+    HIP_TRY(hipMalloc(&h->d_weights, sizeof(float) * hw.blob.size()));
+    HIP_TRY(hipMemcpy(h->d_weights, hw.blob.data(), sizeof(float) * hw.blob.size(), hipMemcpyHostToDevice));
+    if (int rc = build_plan(h, hw)) return rc;
+    h->weights_loaded = true;
+    return MI_UNET_OK;
+}
+
+int mi_unet_load_weights(mi_unet_t *h, const char *path)
+{
+    if (int rc = check_handle(h, false)) return rc;
+    if (!path) return fail(MI_UNET_EARG, "null weight path");
+    std::ifstream f(path, std::ios::binary | std::ios::ate);
+    if (!f.good()) return fail(MI_UNET_EFILE, std::string("Engine file not found: ") + path);
+    const std::streamsize sz = f.tellg();
+    f.seekg(0);
+    std::vector<char> buf((size_t)sz);
+    if (!f.read(buf.data(), sz)) return fail(MI_UNET_EFILE, std::string("cannot read ") + path);
+    return mi_unet_load_weights_from_memory(h, buf.data(), buf.size());
+}
+
+int mi_unet_infer_u8_device(mi_unet_t *h, const uint8_t *d_imgs, int B, uint8_t *d_labels, float *d_logits)
+{
+    if (int rc = check_handle(h, true)) return rc;
+    if (!d_imgs || !d_labels || B < 0) return fail(MI_UNET_EARG, "mi_unet_infer_u8_device: bad argument");
+    HIP_TRY(hipSetDevice(h->cfg.device));
+    const size_t hw = (size_t)h->cfg.height * h->cfg.width;
+    for (int b0 = 0; b0 < B; b0 += h->cfg.max_batch) {
+        const int bm = (B - b0) < h->cfg.max_batch ? (B - b0) : h->cfg.max_batch;
+        if (int rc = run_microbatch(h, d_imgs + b0 * hw * h->cfg.in_ch, bm, d_labels + b0 * hw,
+                                    d_logits ? d_logits + b0 * hw * h->cfg.classes : nullptr))
+            return rc;
+    }
+    return MI_UNET_OK;
+}
+
+int mi_unet_infer_u8(mi_unet_t *h, const uint8_t *imgs, int B, uint8_t *labels, float *logits)
+{
+    if (int rc = check_handle(h, true)) return rc;
+    if (!imgs || !labels || B < 0) return fail(MI_UNET_EARG, "mi_unet_infer_u8: bad argument");
+    HIP_TRY(hipSetDevice(h->cfg.device));
+    const size_t hw = (size_t)h->cfg.height * h->cfg.width;
+    hipStream_t s = h->stream;
+    for (int b0 = 0; b0 < B; b0 += h->cfg.max_batch) {
+        const int bm = (B - b0) < h->cfg.max_batch ? (B - b0) : h->cfg.max_batch;
+        const size_t in_bytes = bm * hw * h->cfg.in_ch;
+        memcpy(h->h_img, imgs + b0 * hw * h->cfg.in_ch, in_bytes);
+        HIP_TRY(hipMemcpyAsync(h->d_img, h->h_img, in_bytes, hipMemcpyHostToDevice, s));
+        if (int rc = run_microbatch(h, h->d_img, bm, h->d_labels, logits ? h->d_logits : nullptr)) return rc;
+        HIP_TRY(hipMemcpyAsync(h->h_labels, h->d_labels, bm * hw, hipMemcpyDeviceToHost, s));
+        if (logits)
+            HIP_TRY(hipMemcpyAsync(logits + b0 * hw * h->cfg.classes, h->d_logits, sizeof(float) * bm * hw * h->cfg.classes,
+                                   hipMemcpyDeviceToHost, s));
+        HIP_TRY(hipStreamSynchronize(s));
+        memcpy(labels + b0 * hw, h->h_labels, bm * hw);
+    }
+    return MI_UNET_OK;
+}
+
+int mi_unet_set_stream(mi_unet_t *h, void *hip_stream)
+{
+    if (int rc = check_handle(h, false)) return rc;
+    h->stream = hip_stream ? static_cast<hipStream_t>(hip_stream) : h->own_stream;
+    return MI_UNET_OK;
+}
+
+int mi_unet_sync(mi_unet_t *h)
+{
+    if (int rc = check_handle(h, false)) return rc;
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    return MI_UNET_OK;
+}
+
+int mi_unet_timer_begin(mi_unet_t *h)
+{
+    if (int rc = check_handle(h, false)) return rc;
+    HIP_TRY(hipEventRecord(h->tev0, h->stream));
+    return MI_UNET_OK;
+}
+
+int mi_unet_timer_end(mi_unet_t *h, float *ms)
+{
+    if (int rc = check_handle(h, false)) return rc;
+    if (!ms) return fail(MI_UNET_EARG, "null ms");
+    HIP_TRY(hipEventRecord(h->tev1, h->stream));
+    HIP_TRY(hipEventSynchronize(h->tev1));
+    HIP_TRY(hipEventElapsedTime(ms, h->tev0, h->tev1));
+    return MI_UNET_OK;
+}
+
+int mi_unet_set_profiling(mi_unet_t *h, int on)
+{
+    if (int rc = check_handle(h, false)) return rc;
+    h->profiling = on != 0;
+    return MI_UNET_OK;
+}
+
+int mi_unet_get_kernel_stats(mi_unet_t *h, mi_unet_kernel_stat *stats, int cap, int *n)
+{
+    if (int rc = check_handle(h, false)) return rc;
+    if (!n) return fail(MI_UNET_EARG, "null n");
+    *n = (int)h->stats.size();
+    for (int i = 0; i < *n && i < cap && stats; ++i) stats[i] = h->stats[i];
+    return MI_UNET_OK;
+}
+
+int mi_unet_layer_debug(int device, const char *op, const float *in, int B, int H, int W, int Cin, const float *w,
+                        const float *scale, const float *shift, int Cout, int relu, float *out)
+{
+    if (!op || !in || !out || B <= 0 || H <= 0 || W <= 0 || Cin <= 0) return fail(MI_UNET_EARG, "layer_debug: bad argument");
+    if (mi_unet_device_count() <= 0) return fail(MI_UNET_ENODEVICE, "no HIP device visible: libmiunet has no CPU fallback");
+    HIP_TRY(hipSetDevice(device));
+    const std::string o(op);
+    const size_t in_n = (size_t)B * H * W * Cin;
+    float *d_in = nullptr, *d_out = nullptr, *d_w = nullptr, *d_b = nullptr;
+    std::vector<float> wpk, bias;
+    size_t out_n = 0;
+    ConvArgs a{};
+    if (o == "conv3x3" || o == "convT2x2") {
+        if (!w || Cout <= 0 || Cin % 4) return fail(MI_UNET_EARG, "layer_debug: conv needs weights and Cin % 4 == 0");
+        const bool T = (o == "convT2x2");
+        const int nch = (Cin + KC - 1) / KC;
+        const size_t npad = round_up(T ? (size_t)4 * Cout : (size_t)Cout, NPAD);
+        wpk.assign((size_t)nch * (T ? 1 : 9) * npad * KC, 0.f);
+        bias.assign(Cout, 0.f);
+        for (int co = 0; co < Cout; ++co) bias[co] = shift ? shift[co] : 0.f;
+        if (!T) {
+            for (int co = 0; co < Cout; ++co)
+                for (int ci = 0; ci < Cin; ++ci)
+                    for (int t = 0; t < 9; ++t)
+                        wpk[(((size_t)(ci / KC) * 9 + t) * npad + co) * KC + ci % KC] =
+                            (float)((double)w[((size_t)co * Cin + ci) * 9 + t] * (scale ? (double)scale[co] : 1.0));
+            out_n = (size_t)B * H * W * Cout;
+        } else {
+            for (int ci = 0; ci < Cin; ++ci)
+                for (int co = 0; co < Cout; ++co)
+                    for (int k = 0; k < 4; ++k)
+                        wpk[((size_t)(ci / KC) * npad + (size_t)k * Cout + co) * KC + ci % KC] = w[((size_t)ci * Cout + co) * 4 + k];
+            out_n = (size_t)B * 4 * H * W * Cout;
+        }
+        a.B = B; a.H = H; a.W = W; a.Cin = Cin; a.ldc = Cin; a.Cout = Cout; a.CoutPad = (int)npad; a.ldo = Cout; a.co_off = 0;
+        a.relu = relu;
+    } else if (o == "maxpool") {
+        if (Cin % 4 || H % 2 || W % 2) return fail(MI_UNET_EARG, "layer_debug: maxpool needs C % 4 == 0 and even H, W");
+        out_n = (size_t)B * (H / 2) * (W / 2) * Cin;
+    } else {
+        return fail(MI_UNET_EARG, "layer_debug: unknown op " + o);
+    }
+    int rc = MI_UNET_OK;
+    hipError_t e = hipSuccess;
+#define DBG_TRY(expr) do { e = (expr); if (e != hipSuccess) { rc = fail(MI_UNET_EHIP, std::string(#expr) + ": " + hipGetErrorString(e)); goto done; } } while (0)
+    DBG_TRY(hipMalloc(&d_in, sizeof(float) * in_n));
+    DBG_TRY(hipMalloc(&d_out, sizeof(float) * out_n));
+    DBG_TRY(hipMemcpy(d_in, in, sizeof(float) * in_n, hipMemcpyHostToDevice));
+    DBG_TRY(hipMemset(d_out, 0xFF, sizeof(float) * out_n));      // NaN poison: unwritten outputs are visible
+    if (!wpk.empty()) {
+        DBG_TRY(hipMalloc(&d_w, sizeof(float) * wpk.size()));
+        DBG_TRY(hipMalloc(&d_b, sizeof(float) * bias.size()));
+        DBG_TRY(hipMemcpy(d_w, wpk.data(), sizeof(float) * wpk.size(), hipMemcpyHostToDevice));
+        DBG_TRY(hipMemcpy(d_b, bias.data(), sizeof(float) * bias.size(), hipMemcpyHostToDevice));
+        a.in = d_in; a.wpk = d_w; a.bias = d_b; a.out = d_out;
+        DBG_TRY(o == "conv3x3" ? launch_conv3x3_mfma(a, nullptr) : launch_convT2x2_mfma(a, nullptr));
+    } else {
+        DBG_TRY(launch_maxpool2x2(d_in, Cin, d_out, B, H, W, Cin, nullptr));
+    }
+    DBG_TRY(hipDeviceSynchronize());
+    DBG_TRY(hipMemcpy(out, d_out, sizeof(float) * out_n, hipMemcpyDeviceToHost));
+#undef DBG_TRY
+done:
+    if (d_in) (void)hipFree(d_in);
+    if (d_out) (void)hipFree(d_out);
+    if (d_w) (void)hipFree(d_w);
+    if (d_b) (void)hipFree(d_b);
+    return rc;
+}
+
+void mi_unet_destroy(mi_unet_t *h)
+{
+    if (!h) return;
+    (void)hipSetDevice(h->cfg.device);
+    if (h->own_stream) (void)hipStreamSynchronize(h->own_stream);
+    for (int i = 0; i < 8; ++i)
+        if (h->d_cat[i]) (void)hipFree(h->d_cat[i]);
+    void *dev[] = { h->d_weights, h->d_lut, h->d_s0, h->d_s1, h->d_img, h->d_labels, h->d_logits };
+    for (void *p : dev)
+        if (p) (void)hipFree(p);
+    if (h->h_img) (void)hipHostFree(h->h_img);
+    if (h->h_labels) (void)hipHostFree(h->h_labels);
+    hipEvent_t evs[] = { h->ev0, h->ev1, h->tev0, h->tev1 };
+    for (hipEvent_t e : evs)
+        if (e) (void)hipEventDestroy(e);
+    if (h->own_stream) (void)hipStreamDestroy(h->own_stream);
+    delete h;
+}
+
+}  // extern "C"

@@ -1,0 +1,43 @@
+// kernels.h -- launch interface of the gfx950 kernels (kernels.hip).  Internal to libmiunet.so.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stddef.h>
+#include <stdint.h>
+
+namespace miunet {
+
+// Channel counts of packed weights are padded to these granules with zeros.
+constexpr int KC = 16;        // input channels staged per K-chunk
+constexpr int NPAD = 128;     // packed Cout granule (covers both BN = 64 and BN = 128 tiles)
+
+// One implicit-GEMM launch: conv3x3 (taps = 9) or the 2x2-stride-2 transposed conv viewed as a 1-tap GEMM with
+// N = 4*Cout (taps = 1).  Activations are NHWC fp32; `ldc`/`ldo` are the channel strides of the input / output pixel
+// (so a tensor can live in one half of a concat buffer), `co_off` the first output channel written.
+struct ConvArgs {
+    const float *in;      // [B][H][W][ldc]
+    const float *wpk;     // packed weights [nchunks][taps][CoutPad][KC]  (CoutPad counts N = 4*Cout for convT)
+    const float *bias;    // [Cout] folded BN shift (conv) or convT bias
+    float *out;           // conv: [B][H][W][ldo]; convT: [B][2H][2W][ldo]
+    int B, H, W;          // INPUT spatial size
+    int Cin, ldc;
+    int Cout;             // real output channels (convT: per-tap channels, N = 4*Cout)
+    int CoutPad;          // padded N of wpk
+    int ldo, co_off;
+    int relu;
+};
+
+hipError_t launch_conv3x3_mfma(const ConvArgs &a, hipStream_t s);
+hipError_t launch_convT2x2_mfma(const ConvArgs &a, hipStream_t s);
+
+// First layer: u8 image -> (LUT /255) -> conv3x3 (Cin = 1..4) + shift + ReLU.  w is [9][Cin][Cout] (BN scale folded).
+hipError_t launch_conv3x3_first(const uint8_t *img, const float *lut256, const float *w, const float *shift, float *out,
+                                int B, int H, int W, int Cin, int Cout, int ldo, hipStream_t s);
+// Same arithmetic on an fp32 NHWC input (layer_debug / small-Cin fallback is not needed elsewhere).
+
+hipError_t launch_maxpool2x2(const float *in, int ldc, float *out, int B, int H, int W, int C, hipStream_t s);
+
+// 1x1 head + first-max-wins argmax: in [npix][Cin] -> planar logits [B][classes][H*W] (may be null) + u8 labels.
+hipError_t launch_head_argmax(const float *in, int Cin, const float *w, const float *bias, int classes, float *logits,
+                              uint8_t *labels, int B, int HW, hipStream_t s);
+
+}  // namespace miunet

@@ -1,0 +1,185 @@
+"""ctypes binding of libmiunet.so (include/mi_unet.h) for the tests and bench.py.
+
+The library is the product; this file is plumbing.  It raises if the shared object is missing or if a call fails --
+there is no Python/CPU fallback of any kind.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+import numpy as np
+
+PKG_DIR = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+LIB_PATH = os.path.join(PKG_DIR, "libmiunet.so")
+
+EXPORTS = [
+    "mi_unet_default_config", "mi_unet_create", "mi_unet_load_weights", "mi_unet_load_weights_from_memory",
+    "mi_unet_infer_u8", "mi_unet_infer_u8_device", "mi_unet_set_stream", "mi_unet_sync", "mi_unet_timer_begin",
+    "mi_unet_timer_end", "mi_unet_set_profiling", "mi_unet_get_kernel_stats", "mi_unet_layer_debug", "mi_unet_destroy",
+    "mi_unet_last_error", "mi_unet_device_count",
+]
+
+
+class Config(C.Structure):
+    _fields_ = [("height", C.c_int), ("width", C.c_int), ("in_ch", C.c_int), ("base", C.c_int), ("levels", C.c_int),
+                ("classes", C.c_int), ("max_batch", C.c_int), ("device", C.c_int)]
+
+
+class KernelStat(C.Structure):
+    _fields_ = [("name", C.c_char * 48), ("kernel", C.c_char * 32), ("flops", C.c_double), ("bytes", C.c_double),
+                ("ms", C.c_float)]
+
+
+class MiUnetError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__(f"libmiunet error {code}: {msg}")
+        self.code = code
+
+
+_LIB = None
+
+
+def lib():
+    global _LIB
+    if _LIB is None:
+        if not os.path.exists(LIB_PATH):
+            raise FileNotFoundError(f"{LIB_PATH} is not built: run `python -c 'import __graft_entry__ as g; g.build()'` "
+                                    "(make -C unet-medical-image-contour-segmentation-cpp_amd)")
+        L = C.CDLL(LIB_PATH)
+        L.mi_unet_last_error.restype = C.c_char_p
+        L.mi_unet_create.argtypes = [C.POINTER(Config), C.POINTER(C.c_void_p)]
+        L.mi_unet_load_weights.argtypes = [C.c_void_p, C.c_char_p]
+        L.mi_unet_load_weights_from_memory.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t]
+        L.mi_unet_infer_u8.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]
+        L.mi_unet_infer_u8_device.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]
+        L.mi_unet_set_stream.argtypes = [C.c_void_p, C.c_void_p]
+        L.mi_unet_sync.argtypes = [C.c_void_p]
+        L.mi_unet_timer_begin.argtypes = [C.c_void_p]
+        L.mi_unet_timer_end.argtypes = [C.c_void_p, C.POINTER(C.c_float)]
+        L.mi_unet_set_profiling.argtypes = [C.c_void_p, C.c_int]
+        L.mi_unet_get_kernel_stats.argtypes = [C.c_void_p, C.POINTER(KernelStat), C.c_int, C.POINTER(C.c_int)]
+        L.mi_unet_layer_debug.argtypes = [C.c_int, C.c_char_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p,
+                                          C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p]
+        L.mi_unet_destroy.argtypes = [C.c_void_p]
+        L.mi_unet_destroy.restype = None
+        L.mi_unet_default_config.argtypes = [C.POINTER(Config)]
+        L.mi_unet_default_config.restype = None
+        _LIB = L
+    return _LIB
+
+
+def _check(rc):
+    if rc != 0:
+        raise MiUnetError(rc, lib().mi_unet_last_error().decode(errors="replace"))
+
+
+def device_count() -> int:
+    return int(lib().mi_unet_device_count())
+
+
+def default_config() -> Config:
+    c = Config()
+    lib().mi_unet_default_config(C.byref(c))
+    return c
+
+
+def _ptr(a):
+    return None if a is None else a.ctypes.data_as(C.c_void_p)
+
+
+class Engine:
+    """One engine handle = one GPU's context (the reference's thread-local TensorRTContext, include/process.h:13-23)."""
+
+    def __init__(self, height=512, width=512, in_ch=1, base=64, levels=4, classes=3, max_batch=16, device=0):
+        self.cfg = Config(height, width, in_ch, base, levels, classes, max_batch, device)
+        self._h = C.c_void_p()
+        _check(lib().mi_unet_create(C.byref(self.cfg), C.byref(self._h)))
+
+    def close(self):
+        if self._h:
+            lib().mi_unet_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def load_weights(self, path_or_blob):
+        if isinstance(path_or_blob, (bytes, bytearray, memoryview)):
+            buf = (C.c_char * len(path_or_blob)).from_buffer_copy(path_or_blob)
+            _check(lib().mi_unet_load_weights_from_memory(self._h, C.cast(buf, C.c_void_p), len(path_or_blob)))
+        else:
+            _check(lib().mi_unet_load_weights(self._h, os.fsencode(path_or_blob)))
+
+    def infer(self, imgs: np.ndarray, want_logits=False):
+        """imgs u8 [B,H,W,C] (host) -> labels u8 [B,H,W], logits f32 [B,classes,H,W] or None"""
+        imgs = np.ascontiguousarray(imgs, dtype=np.uint8)
+        b = imgs.shape[0]
+        c = self.cfg
+        if imgs.shape[1:] != (c.height, c.width, c.in_ch):
+            raise ValueError(f"Input size must be {c.height}x{c.width}x{c.in_ch}, got {imgs.shape[1:]}")
+        labels = np.empty((b, c.height, c.width), np.uint8)
+        logits = np.empty((b, c.classes, c.height, c.width), np.float32) if want_logits else None
+        _check(lib().mi_unet_infer_u8(self._h, _ptr(imgs), b, _ptr(labels), _ptr(logits)))
+        return labels, logits
+
+    def infer_device(self, d_imgs_ptr: int, b: int, d_labels_ptr: int, d_logits_ptr: int = 0):
+        _check(lib().mi_unet_infer_u8_device(self._h, C.c_void_p(d_imgs_ptr), b, C.c_void_p(d_labels_ptr),
+                                             C.c_void_p(d_logits_ptr) if d_logits_ptr else None))
+
+    def set_stream(self, stream_ptr: int):
+        _check(lib().mi_unet_set_stream(self._h, C.c_void_p(stream_ptr) if stream_ptr else None))
+
+    def sync(self):
+        _check(lib().mi_unet_sync(self._h))
+
+    def timer_begin(self):
+        _check(lib().mi_unet_timer_begin(self._h))
+
+    def timer_end(self) -> float:
+        ms = C.c_float()
+        _check(lib().mi_unet_timer_end(self._h, C.byref(ms)))
+        return float(ms.value)
+
+    def set_profiling(self, on: bool):
+        _check(lib().mi_unet_set_profiling(self._h, int(on)))
+
+    def kernel_stats(self):
+        n = C.c_int()
+        arr = (KernelStat * 128)()
+        _check(lib().mi_unet_get_kernel_stats(self._h, arr, 128, C.byref(n)))
+        return [dict(name=arr[i].name.decode(), kernel=arr[i].kernel.decode(), flops=arr[i].flops, bytes=arr[i].bytes,
+                     ms=arr[i].ms) for i in range(min(n.value, 128))]
+
+
+def layer_debug(op, x, w=None, scale=None, shift=None, relu=False, device=0):
+    """Run one layer kernel on host NHWC fp32 data (parity hook)."""
+    x = np.ascontiguousarray(x, np.float32)
+    b, h, ww, cin = x.shape
+    cout = 0
+    if op == "conv3x3":
+        w = np.ascontiguousarray(w, np.float32)
+        cout = w.shape[0]
+        out = np.empty((b, h, ww, cout), np.float32)
+    elif op == "convT2x2":
+        w = np.ascontiguousarray(w, np.float32)
+        cout = w.shape[1]
+        out = np.empty((b, 2 * h, 2 * ww, cout), np.float32)
+    elif op == "maxpool":
+        out = np.empty((b, h // 2, ww // 2, cin), np.float32)
+    else:
+        raise ValueError(op)
+    scale = None if scale is None else np.ascontiguousarray(scale, np.float32)
+    shift = None if shift is None else np.ascontiguousarray(shift, np.float32)
+    _check(lib().mi_unet_layer_debug(device, op.encode(), _ptr(x), b, h, ww, cin, _ptr(w), _ptr(scale), _ptr(shift), cout,
+                                     int(relu), _ptr(out)))
+    return out
