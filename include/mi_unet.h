@@ -75,9 +75,10 @@ int mi_unet_sync(mi_unet_t *h);
 int mi_unet_timer_begin(mi_unet_t *h);
 int mi_unet_timer_end(mi_unet_t *h, float *ms);
 
-/* Per-kernel accounting of the most recent micro-batch, measured with hipEvents when profiling is enabled
- * (mi_unet_set_profiling(h,1): serialises launches, for bench/roofline use only).
- * Fills up to `cap` entries; returns the number of kernels launched in *n. */
+/* Per-launch accounting since profiling was last switched on: mi_unet_set_profiling(h,1) clears the log and from then on
+ * brackets every kernel launch with a hipEvent pair recorded on the launch stream (no host wait at launch time).
+ * mi_unet_get_kernel_stats synchronises the last event, fills up to `cap` entries (launch order) and returns the number
+ * of launches logged in *n. */
 typedef struct mi_unet_kernel_stat {
     char name[48];        /* layer name, e.g. "up4.c1" */
     char kernel[32];      /* kernel family: conv3x3_mfma, convT2x2_mfma, conv3x3_c1, maxpool2x2, head_argmax */

@@ -67,10 +67,13 @@ struct mi_unet {
     uint8_t *h_img = nullptr;
     uint8_t *h_labels = nullptr;
     std::vector<Step> plan;
-    // profiling
+    // profiling: one event pair per launch, recorded on the launch stream and only read back (synchronised) in
+    // mi_unet_get_kernel_stats, so the launches themselves never wait on the host
     bool profiling = false;
     std::vector<mi_unet_kernel_stat> stats;
-    hipEvent_t ev0 = nullptr, ev1 = nullptr, tev0 = nullptr, tev1 = nullptr;
+    std::vector<hipEvent_t> ev_pool;
+    size_t ev_used = 0;
+    hipEvent_t tev0 = nullptr, tev1 = nullptr;
 };
 
 namespace {
@@ -264,9 +267,18 @@ int build_plan(mi_unet *h, const HostWeights &hw)
 int run_microbatch(mi_unet *h, const uint8_t *d_imgs, int B, uint8_t *d_labels, float *d_logits)
 {
     hipStream_t s = h->stream;
-    if (h->profiling) h->stats.clear();
     for (Step &st : h->plan) {
-        if (h->profiling) HIP_TRY(hipEventRecord(h->ev0, s));
+        hipEvent_t e0 = nullptr, e1 = nullptr;
+        if (h->profiling) {
+            while (h->ev_pool.size() < h->ev_used + 2) {
+                hipEvent_t ev;
+                HIP_TRY(hipEventCreate(&ev));
+                h->ev_pool.push_back(ev);
+            }
+            e0 = h->ev_pool[h->ev_used++];
+            e1 = h->ev_pool[h->ev_used++];
+            HIP_TRY(hipEventRecord(e0, s));
+        }
         const char *kname = "";
         hipError_t e = hipSuccess;
         switch (st.kind) {
@@ -297,14 +309,13 @@ int run_microbatch(mi_unet *h, const uint8_t *d_imgs, int B, uint8_t *d_labels, 
         }
         if (e != hipSuccess) return fail(MI_UNET_EHIP, "launch " + st.name + ": " + hipGetErrorString(e));
         if (h->profiling) {
-            HIP_TRY(hipEventRecord(h->ev1, s));
-            HIP_TRY(hipEventSynchronize(h->ev1));
+            HIP_TRY(hipEventRecord(e1, s));
             mi_unet_kernel_stat ks{};
             snprintf(ks.name, sizeof ks.name, "%s", st.name.c_str());
             snprintf(ks.kernel, sizeof ks.kernel, "%s", kname);
             ks.flops = st.flops_per_img * B;
             ks.bytes = st.bytes_per_img * B + st.weight_bytes;
-            HIP_TRY(hipEventElapsedTime(&ks.ms, h->ev0, h->ev1));
+            ks.ms = -1.f;                      // filled by mi_unet_get_kernel_stats
             h->stats.push_back(ks);
         }
     }
@@ -368,8 +379,6 @@ int mi_unet_create(const mi_unet_config *cfg, mi_unet_t **out)
     } while (0)
     HIP_TRY_H(hipStreamCreateWithFlags(&h->own_stream, hipStreamNonBlocking));
     h->stream = h->own_stream;
-    HIP_TRY_H(hipEventCreate(&h->ev0));
-    HIP_TRY_H(hipEventCreate(&h->ev1));
     HIP_TRY_H(hipEventCreate(&h->tev0));
     HIP_TRY_H(hipEventCreate(&h->tev1));
     const size_t Bm = cfg->max_batch, npix0 = Bm * cfg->height * cfg->width;
@@ -493,6 +502,8 @@ int mi_unet_set_profiling(mi_unet_t *h, int on)
 {
     if (int rc = check_handle(h, false)) return rc;
     h->profiling = on != 0;
+    h->stats.clear();
+    h->ev_used = 0;
     return MI_UNET_OK;
 }
 
@@ -501,6 +512,9 @@ int mi_unet_get_kernel_stats(mi_unet_t *h, mi_unet_kernel_stat *stats, int cap, 
     if (int rc = check_handle(h, false)) return rc;
     if (!n) return fail(MI_UNET_EARG, "null n");
     *n = (int)h->stats.size();
+    if (!h->stats.empty()) HIP_TRY(hipEventSynchronize(h->ev_pool[2 * h->stats.size() - 1]));
+    for (size_t i = 0; i < h->stats.size(); ++i)
+        if (h->stats[i].ms < 0.f) HIP_TRY(hipEventElapsedTime(&h->stats[i].ms, h->ev_pool[2 * i], h->ev_pool[2 * i + 1]));
     for (int i = 0; i < *n && i < cap && stats; ++i) stats[i] = h->stats[i];
     return MI_UNET_OK;
 }
@@ -587,9 +601,10 @@ void mi_unet_destroy(mi_unet_t *h)
         if (p) (void)hipFree(p);
     if (h->h_img) (void)hipHostFree(h->h_img);
     if (h->h_labels) (void)hipHostFree(h->h_labels);
-    hipEvent_t evs[] = { h->ev0, h->ev1, h->tev0, h->tev1 };
+    hipEvent_t evs[] = { h->tev0, h->tev1 };
     for (hipEvent_t e : evs)
         if (e) (void)hipEventDestroy(e);
+    for (hipEvent_t e : h->ev_pool) (void)hipEventDestroy(e);
     if (h->own_stream) (void)hipStreamDestroy(h->own_stream);
     delete h;
 }

@@ -153,12 +153,12 @@ class Engine:
     def set_profiling(self, on: bool):
         _check(lib().mi_unet_set_profiling(self._h, int(on)))
 
-    def kernel_stats(self):
+    def kernel_stats(self, cap=8192):
         n = C.c_int()
-        arr = (KernelStat * 128)()
-        _check(lib().mi_unet_get_kernel_stats(self._h, arr, 128, C.byref(n)))
+        arr = (KernelStat * cap)()
+        _check(lib().mi_unet_get_kernel_stats(self._h, arr, cap, C.byref(n)))
         return [dict(name=arr[i].name.decode(), kernel=arr[i].kernel.decode(), flops=arr[i].flops, bytes=arr[i].bytes,
-                     ms=arr[i].ms) for i in range(min(n.value, 128))]
+                     ms=arr[i].ms) for i in range(min(n.value, cap))]
 
 
 def layer_debug(op, x, w=None, scale=None, shift=None, relu=False, device=0):
