@@ -24,7 +24,7 @@ sys.path.insert(0, os.path.join(ROOT, "unet-medical-image-contour-segmentation-c
 import numpy as np  # noqa: E402
 import torch  # noqa: E402
 
-from miunet import binding, synth  # noqa: E402
+from miunet import binding, shard, synth  # noqa: E402
 from miunet.spec import UNetSpec, pack_weights  # noqa: E402
 
 FP32_PEAK_TFLOPS = 157.3      # MI355X_MICROARCH.md: fp32 matrix peak (v_mfma_f32_32x32x2_f32)
@@ -100,17 +100,9 @@ def main():
     B = args.batch
 
     # ---- weights: rank 0 generates, everybody else receives them over RCCL
-    if rank == 0:
-        blob = pack_weights(spec, synth.make_weights(spec, 1234))
-        wt = torch.frombuffer(bytearray(blob), dtype=torch.uint8).to(dev)
-    else:
-        blob = None
-        wt = torch.empty(spec.n_params() * 4 + 36, dtype=torch.uint8, device=dev)
+    blob = pack_weights(spec, synth.make_weights(spec, 1234)) if rank == 0 else None
     if world > 1:
-        dist.broadcast(wt, src=0)
-        if rank != 0:
-            blob = wt.cpu().numpy().tobytes()
-    del wt
+        blob = shard.broadcast_blob(blob, spec.n_params() * 4 + 36, dev)
 
     eng = binding.Engine(H, W, spec.in_ch, spec.base, spec.levels, spec.classes, max_batch=B, device=local_rank)
     eng.load_weights(blob)
