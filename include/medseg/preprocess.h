@@ -1,0 +1,17 @@
+// Reference: include/preprocess.h:20-23, src/preprocess.cpp:76-141.
+#pragma once
+#include <cstdint>
+#include <string>
+
+#include "image.h"
+
+namespace Preprocess {
+
+// mmap the headerless little-endian u16 RAW (w*h*2 bytes), min/max, top-left-aligned bilinear resample to 512x512 in
+// double, quantise to u8, write the PNG (level 0) and the one-line size JSON.  false on failure.
+bool preprocess_raw(const std::string &raw_path, const std::string &png_path, const std::string &json_path, int w, int h);
+
+// The arithmetic of the above on memory (no files): src/preprocess.cpp:81-118.
+medseg::Image8 resample_normalize(const uint16_t *src, int w, int h, int outW = 512, int outH = 512);
+
+}  // namespace Preprocess

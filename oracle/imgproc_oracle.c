@@ -184,3 +184,95 @@ void orc_postprocess_mask(const uint8_t *src, uint8_t *out, int w, int h)
                 if (labels[p] == i) out[p] = FOREGROUND_VALUE;                       /* :71, :76 */
     free(st); free(labels); free(opened); free(bin); free(mask);
 }
+
+/* ---- A11: Mask2Polygon::extract_contours, src/mask2polygon.cpp:29-36 ----
+ * threshold(mask, 127, 255, THRESH_BINARY) then findContours(RETR_EXTERNAL, CHAIN_APPROX_SIMPLE).
+ * OpenCV is not available here (PARITY UNPINNED against it); this restates the Suzuki-Abe border following the way
+ * OpenCV's classic implementation documents it: the image is zero-padded by one pixel, scanned in raster order, an
+ * outer border starts at an unlabelled foreground pixel whose west neighbour is 0, and in RETR_EXTERNAL mode it is
+ * accepted only if the last labelled border pixel seen on this row is not a "still inside" (positive) one.  Border pixels
+ * are labelled 2, or -126 when the trace leaves them with background on their east side.  The trace looks for its first
+ * neighbour CLOCKWISE starting after west, every later one COUNTER-CLOCKWISE starting after the direction it came
+ * from; CHAIN_APPROX_SIMPLE emits a point only where the step direction changes.  Contours are returned newest first
+ * (each new contour is linked in front of its siblings).
+ *
+ * out_xy receives x,y pairs, contour after contour; out_start[c] is the index (in points) of contour c's first point,
+ * out_start[ncontours] the total.  Returns the number of contours, or -1 if a capacity is too small. */
+int orc_find_contours(const uint8_t *mask, int w, int h, int32_t *out_xy, int cap_points, int32_t *out_start,
+                      int cap_contours)
+{
+    static const int DX[8] = { 1, 1, 0, -1, -1, -1, 0, 1 };     /* 0=E 1=NE 2=N 3=NW 4=W 5=SW 6=S 7=SE (y grows down) */
+    static const int DY[8] = { 0, -1, -1, -1, 0, 1, 1, 1 };
+    const int pw = w + 2, ph = h + 2;
+    int8_t *img = (int8_t *)calloc((size_t)pw * ph, 1);
+    for (int y = 0; y < h; ++y)
+        for (int x = 0; x < w; ++x) img[(size_t)(y + 1) * pw + x + 1] = mask[(size_t)y * w + x] > 127 ? 1 : 0;
+    int32_t *pts = (int32_t *)malloc(sizeof(int32_t) * 2 * (size_t)cap_points);   /* discovery order */
+    int32_t *starts = (int32_t *)malloc(sizeof(int32_t) * ((size_t)cap_contours + 1));
+    int nc = 0, np = 0, overflow = 0;
+    for (int y = 1; y < ph - 1 && !overflow; ++y) {
+        int prev = 0, lnbd_x = 0;
+        for (int x = 1; x < pw - 1; ++x) {
+            const int p = img[(size_t)y * pw + x];
+            if (p != prev && prev == 0 && p == 1 && !(img[(size_t)y * pw + lnbd_x] > 0)) {
+                if (nc == cap_contours) { overflow = 1; break; }
+                starts[nc++] = np;
+                /* ---- follow the border starting at (x, y) */
+                int8_t *i0 = img + (size_t)y * pw + x;
+                int s = 4, s_end = 4;
+                int8_t *i1;
+                do { s = (s - 1) & 7; i1 = i0 + DY[s] * pw + DX[s]; } while (*i1 == 0 && s != s_end);
+                int px = x, py = y;
+                if (s == s_end) {                     /* isolated pixel */
+                    *i0 = (int8_t)(2 | -128);
+                    if (np == cap_points) { overflow = 1; break; }
+                    pts[2 * np] = px - 1; pts[2 * np + 1] = py - 1; ++np;
+                } else {
+                    int8_t *i3 = i0, *i4;
+                    int prev_s = s ^ 4;
+                    for (;;) {
+                        s_end = s;
+                        for (;;) { ++s; i4 = i3 + DY[s & 7] * pw + DX[s & 7]; if (*i4 != 0) break; }
+                        s &= 7;
+                        if ((unsigned)(s - 1) < (unsigned)s_end) *i3 = (int8_t)(2 | -128);   /* east side is background */
+                        else if (*i3 == 1) *i3 = 2;
+                        if (s != prev_s) {
+                            if (np == cap_points) { overflow = 1; break; }
+                            pts[2 * np] = px - 1; pts[2 * np + 1] = py - 1; ++np;
+                            prev_s = s;
+                        }
+                        px += DX[s]; py += DY[s];
+                        if (i4 == i0 && i3 == i1) break;
+                        i3 = i4;
+                        s = (s + 4) & 7;
+                    }
+                    if (overflow) break;
+                }
+            }
+            prev = img[(size_t)y * pw + x];
+            if (prev & -2) lnbd_x = x;
+        }
+    }
+    int ret = -1;
+    if (!overflow) {
+        starts[nc] = np;
+        int o = 0;
+        for (int c = nc - 1; c >= 0; --c) {           /* newest first */
+            out_start[nc - 1 - c] = o;
+            for (int k = starts[c]; k < starts[c + 1]; ++k) { out_xy[2 * o] = pts[2 * k]; out_xy[2 * o + 1] = pts[2 * k + 1]; ++o; }
+        }
+        out_start[nc] = o;
+        ret = nc;
+    }
+    free(pts); free(starts); free(img);
+    return ret;
+}
+
+/* ---- A12: map_contour_points, src/mask2polygon.cpp:41-63: int(pt * scale), truncation toward zero, double math ---- */
+void orc_map_points(const int32_t *xy, int n, double scale_x, double scale_y, int32_t *out)
+{
+    for (int i = 0; i < n; ++i) {
+        out[2 * i] = (int)(xy[2 * i] * scale_x);
+        out[2 * i + 1] = (int)(xy[2 * i + 1] * scale_y);
+    }
+}

@@ -160,3 +160,28 @@ def mask_to_image(mask):
     out = np.empty_like(m)
     lib().orc_mask_to_image(m.reshape(-1), m.size, out.reshape(-1))
     return out
+
+
+def find_contours(mask):
+    """list of [(x, y), ...] as extract_contours (threshold 127, external, simple)"""
+    m = np.ascontiguousarray(mask, np.uint8)
+    h, w = m.shape
+    L = lib()
+    L.orc_find_contours.argtypes = [_u8p, C.c_int, C.c_int, _i32p, C.c_int, _i32p, C.c_int]
+    L.orc_find_contours.restype = C.c_int
+    cap_p, cap_c = 2 * h * w + 16, h * w + 2
+    xy = np.zeros((cap_p, 2), np.int32)
+    st = np.zeros(cap_c + 1, np.int32)
+    n = L.orc_find_contours(m, w, h, xy.reshape(-1), cap_p, st, cap_c)
+    if n < 0:
+        raise RuntimeError("contour capacity")
+    return [[tuple(p) for p in xy[st[i]:st[i + 1]].tolist()] for i in range(n)]
+
+
+def map_points(pts, sx, sy):
+    a = np.ascontiguousarray(np.array(pts, np.int32).reshape(-1, 2))
+    out = np.empty_like(a)
+    L = lib()
+    L.orc_map_points.argtypes = [_i32p, C.c_int, C.c_double, C.c_double, _i32p]
+    L.orc_map_points(a.reshape(-1), a.shape[0], sx, sy, out.reshape(-1))
+    return [tuple(p) for p in out.tolist()]

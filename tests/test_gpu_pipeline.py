@@ -1,0 +1,77 @@
+"""The whole per-image pipeline through the reference's API names (MedicalSeg::initialize_engine /
+process_single_image / cleanup_resources, src/process.cpp:188-262) on the GPU, checked file by file against the oracle."""
+import json
+import os
+
+import numpy as np
+import pytest
+from PIL import Image
+
+import oracle_lib as orc
+from miunet import hostlib, synth
+from miunet.spec import UNetSpec, pack_weights
+
+pytestmark = pytest.mark.gpu
+
+
+def test_process_single_image_end_to_end(tmp_path, capfd):
+    spec = UNetSpec()
+    blob = pack_weights(spec, synth.make_threshold_weights(spec))
+    eng_dir = tmp_path / "engine"
+    eng_dir.mkdir()
+    wpath = eng_dir / "unet.miw"
+    wpath.write_bytes(blob)
+    log_dir = tmp_path / "log"
+    out_dir = tmp_path / "out"
+    out_dir.mkdir()
+
+    # before init: "Engine not initialized" -> false (src/process.cpp:195, :256-261)
+    assert not hostlib.process_single_image(str(tmp_path / "x.raw"), 8, 8, str(out_dir))
+    assert "Processing error: Engine not initialized" in capfd.readouterr().err
+    assert not hostlib.initialize_engine(str(eng_dir / "missing.miw"), str(log_dir))
+    assert hostlib.initialize_engine(str(wpath), str(log_dir))
+    assert hostlib.get_log_path() == str(log_dir) + "/segmentation_log.txt"
+
+    raw = synth.make_raw16(1536, 2048, seed=21)
+    rp = tmp_path / "caseA.raw"
+    raw.tofile(rp)
+    assert hostlib.process_single_image(str(rp), 2048, 1536, str(out_dir))
+    assert "Total processing time:" in capfd.readouterr().out
+
+    # ---- oracle chain on the same input
+    tile = orc.preprocess_raw(raw)
+    _, labels = orc.unet_forward(blob, tile[None, :, :, None], want_logits=False)
+    post = orc.postprocess_mask(labels[0])
+    vis = orc.mask_to_image(post)
+    contours = orc.find_contours(vis)
+    assert len(contours) >= 1, "the structured weights must produce a segment that survives postprocess_mask"
+
+    assert np.array_equal(np.array(Image.open(out_dir / "caseA_normalized.png")), tile)
+    assert (out_dir / "caseA_original_sizes.json").read_bytes() == \
+        b'{"caseA.raw":{"original_height":1536,"original_width":2048,"scaled_height":512,"scaled_width":512}}\n'
+    assert np.array_equal(np.array(Image.open(out_dir / "caseA_mask.png")), vis)
+    doc = json.load(open(out_dir / "caseA.json"))
+    got = [[tuple(p) for p in s["points"]] for s in doc["shapes"]]
+    assert got == [orc.map_points(c, 2048 / 512.0, 1536 / 512.0) for c in contours]
+    assert doc["version"] == "1.0.2.812" and doc["imagePath"] == "caseA.raw"
+    assert (out_dir / "caseA_contour_overlay.png").exists()
+
+    # a second image whose label map is erased by postprocess: still success, no JSON, no overlay (src/mask2polygon.cpp:183-186)
+    dark = np.full((600, 800), 100, np.uint16)
+    dark[0, 0] = 4000                                     # everything else normalises to ~0 -> class 0
+    dp = tmp_path / "dark.raw"
+    dark.tofile(dp)
+    assert hostlib.process_single_image(str(dp), 800, 600, str(out_dir))
+    assert (out_dir / "dark_mask.png").exists() and not (out_dir / "dark.json").exists()
+    assert not np.array(Image.open(out_dir / "dark_mask.png")).any()
+    # a RAW that is too short -> preprocessing fails -> false
+    assert not hostlib.process_single_image(str(dp), 4000, 3000, str(out_dir))
+    assert "Processing error: Preprocessing failed" in capfd.readouterr().err
+
+    hostlib.cleanup_resources()
+    log = open(hostlib.get_log_path()).read()
+    for line in ("=== Initializing Medical Image Segmentation Engine ===", "=== Processing Image: caseA.raw ===",
+                 "Inference time: ", "Total processing time: ", "Processing completed for: caseA",
+                 "=== Cleaning Up Resources ===", "All resources cleaned up successfully"):
+        assert line in log
+    assert not hostlib.process_single_image(str(rp), 2048, 1536, str(out_dir))       # engine is gone again

@@ -1,0 +1,145 @@
+#include "png_io.h"
+
+#include <zlib.h>
+
+#include <cstdio>
+#include <cstring>
+#include <fstream>
+#include <vector>
+
+namespace medseg {
+namespace {
+
+void put32(std::vector<uint8_t> &v, uint32_t x)
+{
+    v.push_back(x >> 24); v.push_back(x >> 16); v.push_back(x >> 8); v.push_back(x);
+}
+
+void chunk(std::vector<uint8_t> &out, const char type[4], const std::vector<uint8_t> &body)
+{
+    put32(out, (uint32_t)body.size());
+    const size_t at = out.size();
+    out.insert(out.end(), type, type + 4);
+    out.insert(out.end(), body.begin(), body.end());
+    put32(out, (uint32_t)crc32(0L, out.data() + at, (uInt)(out.size() - at)));
+}
+
+int paeth(int a, int b, int c)
+{
+    const int p = a + b - c, pa = std::abs(p - a), pb = std::abs(p - b), pc = std::abs(p - c);
+    return (pa <= pb && pa <= pc) ? a : (pb <= pc ? b : c);
+}
+
+}  // namespace
+
+bool write_png(const std::string &path, const Image8 &img, bool level0)
+{
+    if (img.empty() || (img.channels != 1 && img.channels != 3)) return false;
+    std::vector<uint8_t> out = { 0x89, 'P', 'N', 'G', '\r', '\n', 0x1A, '\n' };
+    std::vector<uint8_t> ihdr;
+    put32(ihdr, img.cols); put32(ihdr, img.rows);
+    ihdr.push_back(8); ihdr.push_back(img.channels == 1 ? 0 : 2); ihdr.push_back(0); ihdr.push_back(0); ihdr.push_back(0);
+    chunk(out, "IHDR", ihdr);
+    const size_t stride = (size_t)img.cols * img.channels;
+    std::vector<uint8_t> raw((stride + 1) * img.rows);
+    for (int y = 0; y < img.rows; ++y) {
+        raw[(stride + 1) * y] = 0;                                   // filter type None
+        if (img.channels == 1) {
+            memcpy(&raw[(stride + 1) * y + 1], img.ptr(y), stride);
+        } else {                                                     // memory is B,G,R (OpenCV order); PNG wants R,G,B
+            const uint8_t *s = img.ptr(y);
+            uint8_t *d = &raw[(stride + 1) * y + 1];
+            for (int x = 0; x < img.cols; ++x) { d[3 * x] = s[3 * x + 2]; d[3 * x + 1] = s[3 * x + 1]; d[3 * x + 2] = s[3 * x]; }
+        }
+    }
+    uLongf cap = compressBound((uLong)raw.size());
+    std::vector<uint8_t> z(cap);
+    if (compress2(z.data(), &cap, raw.data(), (uLong)raw.size(), level0 ? 0 : Z_DEFAULT_COMPRESSION) != Z_OK) return false;
+    z.resize(cap);
+    chunk(out, "IDAT", z);
+    chunk(out, "IEND", {});
+    std::ofstream f(path, std::ios::binary | std::ios::trunc);
+    if (!f.is_open()) return false;
+    f.write(reinterpret_cast<const char *>(out.data()), (std::streamsize)out.size());
+    return f.good();
+}
+
+Image8 read_png(const std::string &path, bool as_color)
+{
+    std::ifstream f(path, std::ios::binary);
+    if (!f.is_open()) return {};
+    std::vector<uint8_t> buf((std::istreambuf_iterator<char>(f)), std::istreambuf_iterator<char>());
+    static const uint8_t sig[8] = { 0x89, 'P', 'N', 'G', '\r', '\n', 0x1A, '\n' };
+    if (buf.size() < 8 || memcmp(buf.data(), sig, 8) != 0) return {};
+    uint32_t w = 0, h = 0;
+    int depth = 0, ctype = -1, interlace = 0;
+    std::vector<uint8_t> idat, plte;
+    size_t p = 8;
+    auto rd32 = [&](size_t o) { return (uint32_t)buf[o] << 24 | (uint32_t)buf[o + 1] << 16 | (uint32_t)buf[o + 2] << 8 | buf[o + 3]; };
+    while (p + 12 <= buf.size()) {
+        const uint32_t len = rd32(p);
+        if (p + 12 + len > buf.size()) return {};
+        const char *type = reinterpret_cast<const char *>(&buf[p + 4]);
+        const uint8_t *body = &buf[p + 8];
+        if (!memcmp(type, "IHDR", 4) && len >= 13) {
+            w = rd32(p + 8); h = rd32(p + 12); depth = body[8]; ctype = body[9]; interlace = body[12];
+        } else if (!memcmp(type, "PLTE", 4)) {
+            plte.assign(body, body + len);
+        } else if (!memcmp(type, "IDAT", 4)) {
+            idat.insert(idat.end(), body, body + len);
+        } else if (!memcmp(type, "IEND", 4)) {
+            break;
+        }
+        p += 12 + len;
+    }
+    if (!w || !h || interlace || (depth != 8 && !(depth == 16 && ctype == 0))) return {};
+    int spp;                                                       // samples per pixel
+    switch (ctype) {
+    case 0: spp = 1; break;
+    case 2: spp = 3; break;
+    case 3: spp = 1; break;
+    case 4: spp = 2; break;
+    case 6: spp = 4; break;
+    default: return {};
+    }
+    const int bpp = spp * depth / 8;
+    const size_t stride = (size_t)w * bpp;
+    std::vector<uint8_t> raw((stride + 1) * h);
+    uLongf got = (uLongf)raw.size();
+    if (uncompress(raw.data(), &got, idat.data(), (uLong)idat.size()) != Z_OK || got != raw.size()) return {};
+    std::vector<uint8_t> img(stride * h);
+    for (uint32_t y = 0; y < h; ++y) {
+        const int ft = raw[(stride + 1) * y];
+        const uint8_t *s = &raw[(stride + 1) * y + 1];
+        uint8_t *d = &img[stride * y];
+        const uint8_t *up = y ? d - stride : nullptr;
+        for (size_t i = 0; i < stride; ++i) {
+            const int a = i >= (size_t)bpp ? d[i - bpp] : 0, b = up ? up[i] : 0, c = (up && i >= (size_t)bpp) ? up[i - bpp] : 0;
+            int v = s[i];
+            switch (ft) {
+            case 0: break;
+            case 1: v += a; break;
+            case 2: v += b; break;
+            case 3: v += (a + b) >> 1; break;
+            case 4: v += paeth(a, b, c); break;
+            default: return {};
+            }
+            d[i] = (uint8_t)v;
+        }
+    }
+    Image8 out((int)h, (int)w, as_color ? 3 : 1);
+    for (uint32_t y = 0; y < h; ++y)
+        for (uint32_t x = 0; x < w; ++x) {
+            const uint8_t *px = &img[stride * y + (size_t)x * bpp];
+            int r, g, b;
+            if (ctype == 0) { r = g = b = px[0]; }                   // 16-bit gray: high byte (cv::imread without ANYDEPTH)
+            else if (ctype == 4) { r = g = b = px[0]; }
+            else if (ctype == 3) { const size_t k = (size_t)px[0] * 3; if (k + 2 >= plte.size() + 0 && plte.size() < k + 3) return {}; r = plte[k]; g = plte[k + 1]; b = plte[k + 2]; }
+            else { r = px[0]; g = px[1]; b = px[2]; }
+            if (as_color) { out.at(y, x, 0) = (uint8_t)b; out.at(y, x, 1) = (uint8_t)g; out.at(y, x, 2) = (uint8_t)r; }
+            else out.at(y, x) = (r == g && g == b) ? (uint8_t)r : (uint8_t)((r * 4899 + g * 9617 + b * 1868 + 8192) >> 14);
+        }
+    return out;
+}
+
+}  // namespace medseg

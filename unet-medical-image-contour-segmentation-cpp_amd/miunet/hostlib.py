@@ -1,0 +1,139 @@
+"""ctypes binding of libmedseg.so (include/medseg_c.h): the C view of the C++ host facade that keeps the reference's
+API names (MedicalSeg::*, Preprocess::*, postprocess_mask, Mask2Polygon::*)."""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+import numpy as np
+
+PKG_DIR = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+LIB_PATH = os.path.join(PKG_DIR, "libmedseg.so")
+_LIB = None
+_u8 = np.ctypeslib.ndpointer(np.uint8, flags="C_CONTIGUOUS")
+_u16 = np.ctypeslib.ndpointer(np.uint16, flags="C_CONTIGUOUS")
+_i32 = np.ctypeslib.ndpointer(np.int32, flags="C_CONTIGUOUS")
+
+EXPORTS = ["medseg_initialize_engine", "medseg_process_single_image", "medseg_cleanup_resources", "medseg_get_log_path",
+           "medseg_preprocess_raw", "medseg_resample_normalize", "medseg_postprocess_mask", "medseg_mask_to_image",
+           "medseg_extract_contours", "medseg_map_points", "medseg_generate_json", "medseg_process_single_mask",
+           "medseg_write_png", "medseg_read_png"]
+
+
+def lib():
+    global _LIB
+    if _LIB is None:
+        if not os.path.exists(LIB_PATH):
+            raise FileNotFoundError(f"{LIB_PATH} is not built (make -C unet-medical-image-contour-segmentation-cpp_amd)")
+        L = C.CDLL(LIB_PATH)
+        L.medseg_initialize_engine.argtypes = [C.c_char_p, C.c_char_p]
+        L.medseg_process_single_image.argtypes = [C.c_char_p, C.c_int, C.c_int, C.c_char_p]
+        L.medseg_cleanup_resources.restype = None
+        L.medseg_get_log_path.restype = C.c_char_p
+        L.medseg_preprocess_raw.argtypes = [C.c_char_p, C.c_char_p, C.c_char_p, C.c_int, C.c_int]
+        L.medseg_resample_normalize.argtypes = [_u16, C.c_int, C.c_int, _u8, C.c_int, C.c_int]
+        L.medseg_postprocess_mask.argtypes = [_u8, C.c_int, C.c_int, _u8]
+        L.medseg_mask_to_image.argtypes = [_u8, C.c_int, C.c_int, _u8]
+        L.medseg_extract_contours.argtypes = [_u8, C.c_int, C.c_int, _i32, C.c_int, _i32, C.c_int]
+        L.medseg_map_points.argtypes = [_i32, C.c_int, C.c_double, C.c_double, _i32]
+        L.medseg_map_points.restype = None
+        L.medseg_generate_json.argtypes = [_i32, _i32, C.c_int, C.c_char_p, C.c_char_p, C.c_int, C.c_int]
+        L.medseg_process_single_mask.argtypes = [C.c_char_p] * 5
+        L.medseg_process_single_mask.restype = None
+        L.medseg_write_png.argtypes = [C.c_char_p, _u8, C.c_int, C.c_int, C.c_int, C.c_int]
+        L.medseg_read_png.argtypes = [C.c_char_p, C.c_int, _u8, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int)]
+        _LIB = L
+    return _LIB
+
+
+def _b(s):
+    return os.fsencode(s)
+
+
+def resample_normalize(raw, out_w=512, out_h=512):
+    raw = np.ascontiguousarray(raw, np.uint16)
+    out = np.empty((out_h, out_w), np.uint8)
+    if lib().medseg_resample_normalize(raw, raw.shape[1], raw.shape[0], out, out_w, out_h):
+        raise RuntimeError("resample_normalize failed")
+    return out
+
+
+def preprocess_raw(raw_path, png_path, json_path, w, h) -> bool:
+    return lib().medseg_preprocess_raw(_b(raw_path), _b(png_path), _b(json_path), w, h) == 0
+
+
+def postprocess_mask(mask):
+    m = np.ascontiguousarray(mask, np.uint8)
+    out = np.empty_like(m)
+    if lib().medseg_postprocess_mask(m, m.shape[1], m.shape[0], out):
+        raise RuntimeError("postprocess_mask failed")
+    return out
+
+
+def mask_to_image(mask):
+    m = np.ascontiguousarray(mask, np.uint8)
+    out = np.empty_like(m)
+    lib().medseg_mask_to_image(m, m.shape[1], m.shape[0], out)
+    return out
+
+
+def extract_contours(mask):
+    m = np.ascontiguousarray(mask, np.uint8)
+    h, w = m.shape
+    cap_p, cap_c = 2 * h * w + 16, h * w + 2
+    xy = np.zeros((cap_p, 2), np.int32)
+    st = np.zeros(cap_c + 1, np.int32)
+    n = lib().medseg_extract_contours(m, w, h, xy.reshape(-1), cap_p, st, cap_c)
+    if n < 0:
+        raise RuntimeError("contour capacity")
+    return [[tuple(p) for p in xy[st[i]:st[i + 1]].tolist()] for i in range(n)]
+
+
+def map_points(pts, sx, sy):
+    a = np.ascontiguousarray(np.array(pts, np.int32).reshape(-1, 2))
+    out = np.empty_like(a)
+    lib().medseg_map_points(a.reshape(-1), a.shape[0], sx, sy, out.reshape(-1))
+    return [tuple(p) for p in out.tolist()]
+
+
+def generate_json(contours, json_path, base_name, ow, oh):
+    flat = np.array([p for c in contours for p in c], np.int32).reshape(-1, 2)
+    start = np.zeros(len(contours) + 1, np.int32)
+    start[1:] = np.cumsum([len(c) for c in contours])
+    if lib().medseg_generate_json(np.ascontiguousarray(flat).reshape(-1), start, len(contours), _b(json_path), base_name.encode(), ow, oh):
+        raise RuntimeError("generate_json failed")
+
+
+def process_single_mask(mask_path, output_dir, json_path, original_png, base_name):
+    lib().medseg_process_single_mask(_b(mask_path), _b(output_dir), _b(json_path), _b(original_png), base_name.encode())
+
+
+def write_png(path, img, level0=True):
+    a = np.ascontiguousarray(img, np.uint8)
+    ch = 1 if a.ndim == 2 else a.shape[2]
+    return lib().medseg_write_png(_b(path), a.reshape(-1), a.shape[1], a.shape[0], ch, int(level0)) == 0
+
+
+def read_png(path, as_color=False):
+    buf = np.empty(64 << 20, np.uint8)
+    w, h = C.c_int(), C.c_int()
+    if lib().medseg_read_png(_b(path), int(as_color), buf, buf.size, C.byref(w), C.byref(h)):
+        return None
+    n = w.value * h.value * (3 if as_color else 1)
+    return buf[:n].reshape((h.value, w.value, 3) if as_color else (h.value, w.value)).copy()
+
+
+def initialize_engine(weight_path, log_dir) -> bool:
+    return lib().medseg_initialize_engine(_b(weight_path), _b(log_dir)) == 0
+
+
+def process_single_image(raw_path, w, h, output_dir) -> bool:
+    return lib().medseg_process_single_image(_b(raw_path), w, h, _b(output_dir)) == 0
+
+
+def cleanup_resources():
+    lib().medseg_cleanup_resources()
+
+
+def get_log_path() -> str:
+    return lib().medseg_get_log_path().decode()

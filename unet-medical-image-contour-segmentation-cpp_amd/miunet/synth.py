@@ -117,3 +117,29 @@ def make_raw16(h: int, w: int, seed: int = 77, lo: int = 50, hi: int = 4000) -> 
     img = lo + (hi - lo) * (0.15 + 0.8 / (1.0 + d * d))
     noise = (splitmix64(seed ^ 0xABCDEF, h * w) >> np.uint64(58)).astype(np.float64).reshape(h, w)
     return np.clip(np.floor(img + noise), lo, hi).astype(np.uint16)
+
+
+def make_threshold_weights(spec: UNetSpec) -> dict:
+    """Structured weights for end-to-end runs: random weights give speckle label maps that postprocess_mask erases
+    (nothing reaches 6 % of the image), so the polygon half would never run.  Here the network is an intensity
+    classifier routed through the top skip connection: channel 0 carries x = pixel/255 unchanged (centre taps, BN
+    scale 1), everything else is zero, and the head is  class0 = 0.3, class1 = 0.5 x + 0.1, class2 = x - 0.15
+    =>  x < 0.4 -> 0,  0.4 < x < 0.5 -> 1,  x > 0.5 -> 2."""
+    t = {}
+    for name, shape in spec.tensor_list():
+        if name.endswith(".gamma"):
+            v = np.ones(shape, np.float32)
+        elif name.endswith(".var"):
+            v = np.full(shape, 1.0 - spec.bn_eps, np.float32)
+        else:
+            v = np.zeros(shape, np.float32)
+        t[name] = v
+    L = spec.levels
+    t["inc.c1.w"][0, 0, 1, 1] = 1.0
+    t["inc.c2.w"][0, 0, 1, 1] = 1.0
+    t[f"up{L}.c1.w"][0, 0, 1, 1] = 1.0          # input channel 0 of the concat = skip channel 0
+    t[f"up{L}.c2.w"][0, 0, 1, 1] = 1.0
+    t["outc.w"][1, 0] = 0.5
+    t["outc.w"][2, 0] = 1.0
+    t["outc.b"][:3] = [0.3, 0.1, -0.15]
+    return t
