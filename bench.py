@@ -76,6 +76,7 @@ def main():
     ap.add_argument("--size", type=int, default=512)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--per-layer", action="store_true", help="also print a per-layer table to stderr")
+    ap.add_argument("--conv-algo", choices=["auto", "direct", "winograd"], default="auto")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -104,7 +105,8 @@ def main():
     if world > 1:
         blob = shard.broadcast_blob(blob, spec.n_params() * 4 + 36, dev)
 
-    eng = binding.Engine(H, W, spec.in_ch, spec.base, spec.levels, spec.classes, max_batch=B, device=local_rank)
+    eng = binding.Engine(H, W, spec.in_ch, spec.base, spec.levels, spec.classes, max_batch=B, device=local_rank,
+                         conv_algo=args.conv_algo)
     eng.load_weights(blob)
     stream = torch.cuda.current_stream(dev)
     eng.set_stream(stream.cuda_stream)
@@ -145,7 +147,8 @@ def main():
         images = B * world * args.steps
         ips = images / dt
         # dominant kernel: the fp32 MFMA implicit-GEMM conv (17 launches per step, 97 % of the FLOPs)
-        dom = [s for s in stats if s["kernel"] == "conv3x3_mfma"]
+        dom = [s for s in stats if s["kernel"] in ("conv3x3_mfma", "conv3x3_wino")]
+        dom_kernel = dom[0]["kernel"] if dom else "conv3x3_mfma"
         dom_flops = sum(s["flops"] for s in dom)
         dom_ms = sum(s["ms"] for s in dom)
         all_ms = sum(s["ms"] for s in stats)
@@ -168,9 +171,11 @@ def main():
                                    "argmax label maps", "images_per_gpu_per_step": B, "global_batch": B * world,
                        "parallelism": f"dp{world}" + (" (RCCL weight broadcast + per-step label-map gather)" if world > 1 else "")},
             "roofline": {
-                "bound": "mfma", "kernel": "conv3x3_mfma (v_mfma_f32_32x32x2_f32)",
+                "bound": "mfma", "kernel": dom_kernel + " (v_mfma_f32_32x32x2_f32)",
+                "algorithm": "winograd F(2x2,3x3): achieved counts ALGORITHMIC (direct-convolution) FLOPs, the MFMA pipe "
+                             "executes 1/2.25 of them" if dom_kernel == "conv3x3_wino" else "direct implicit GEMM",
                 "achieved": achieved, "peak": FP32_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": achieved / FP32_PEAK_TFLOPS,
-                "traffic": pmc_traffic("miunet::conv_mfma_f32<9, 8, 64>"),
+                "traffic": pmc_traffic("miunet::conv3x3_wino_f32<2, 2>" if dom_kernel == "conv3x3_wino" else "miunet::conv_mfma_f32<9, 8, 64>"),
                 "launches": len(dom), "avg_launch_ms": dom_ms / max(1, len(dom)),
                 "avg_launch_gflop": dom_flops / max(1, len(dom)) / 1e9,
                 "share_of_device_time": dom_ms / all_ms if all_ms else None,

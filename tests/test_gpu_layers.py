@@ -26,13 +26,14 @@ def _tol(ref):
     (3, 4, 4, 128, 256),       # deep-layer shape
     (1, 2, 2, 1024, 64),       # bottleneck of a 32x32 input: K = 9216
 ])
-def test_conv3x3_mfma(B, H, W, Cin, Cout):
+@pytest.mark.parametrize("op", ["conv3x3", "conv3x3_wino"])
+def test_conv3x3_mfma(B, H, W, Cin, Cout, op):
     r = _rng(B * 1000 + H * 100 + W + Cin + Cout)
     x = r.standard_normal((B, H, W, Cin), dtype=np.float32)
     w = (r.standard_normal((Cout, Cin, 3, 3), dtype=np.float32) * np.sqrt(2.0 / (9 * Cin))).astype(np.float32)
     scale = (1.0 + 0.1 * r.standard_normal(Cout)).astype(np.float32)
     shift = (0.1 * r.standard_normal(Cout)).astype(np.float32)
-    got = binding.layer_debug("conv3x3", x, w, scale, shift, relu=True)
+    got = binding.layer_debug(op, x, w, scale, shift, relu=True)
     ref = orc.conv3x3(x, w) * scale + shift
     ref = np.maximum(ref, 0.0)
     assert not np.isnan(got).any(), "unwritten (NaN-poisoned) outputs"
@@ -68,6 +69,24 @@ def test_conv3x3_exact_integers_and_asymmetric_taps():
         want[0][ok] = x[0, np.clip(ys, 0, H - 1), np.clip(xs, 0, W - 1), ci][ok]
         assert np.array_equal(got[..., co], want)
         assert np.count_nonzero(got) == np.count_nonzero(want)
+
+
+def test_conv3x3_wino_exact_on_even_integers_and_tap_orientation():
+    # Winograd's G has halves: with weights that are multiples of 4 and small-integer inputs every intermediate is an
+    # exactly representable integer, so the result must equal the direct sum bit for bit; single-tap weights check the
+    # orientation of the transforms (a transposed G or B would mirror or swap taps).
+    r = _rng(12)
+    B, H, W, Cin, Cout = 2, 11, 19, 24, 64
+    x = r.integers(-4, 5, (B, H, W, Cin)).astype(np.float32)
+    w = (4 * r.integers(-3, 4, (Cout, Cin, 3, 3))).astype(np.float32)
+    got = binding.layer_debug("conv3x3_wino", x, w)
+    assert np.array_equal(got, orc.conv3x3(x, w))
+    for (ky, kx, ci, co) in [(0, 2, 5, 7), (2, 0, 23, 63), (1, 1, 0, 0), (0, 0, 17, 33), (2, 2, 9, 40), (1, 0, 3, 3)]:
+        w = np.zeros((Cout, Cin, 3, 3), np.float32)
+        w[co, ci, ky, kx] = 4.0
+        got = binding.layer_debug("conv3x3_wino", x, w)
+        assert np.array_equal(got, orc.conv3x3(x, w))
+        assert np.count_nonzero(got[..., [c for c in range(Cout) if c != co]]) == 0
 
 
 @pytest.mark.parametrize("B,H,W,Cin,Cout", [

@@ -33,23 +33,25 @@ def orc_argmax_batch(logits):
     return np.stack([orc.argmax_planar(l) for l in logits])
 
 
+@pytest.mark.parametrize("algo", ["direct", "winograd"])
 @pytest.mark.parametrize("name", ["unet_b64_l4_64", "unet_b64_l4_48x80", "unet_b16_l3_40x24", "unet_b32_l5_c3_64"])
-def test_against_golden(golden_dir, name):
+def test_against_golden(golden_dir, name, algo):
     spec, blob, imgs, want = load_case(os.path.join(golden_dir, name + ".npz"))
     b, h, w, _ = imgs.shape
-    with binding.Engine(h, w, spec.in_ch, spec.base, spec.levels, spec.classes, max_batch=2) as eng:
+    with binding.Engine(h, w, spec.in_ch, spec.base, spec.levels, spec.classes, max_batch=2, conv_algo=algo) as eng:
         eng.load_weights(blob)
         labels, logits = eng.infer(imgs, want_logits=True)
     flips = check_parity(labels, logits, want)
     assert flips == 0
 
 
-def test_against_oracle_128_batch_and_microbatching():
+@pytest.mark.parametrize("algo", ["direct", "winograd"])
+def test_against_oracle_128_batch_and_microbatching(algo):
     spec = UNetSpec()
     blob = pack_weights(spec, synth.make_weights(spec, 4321))
     imgs = synth.make_images(5, 128, 128, 1, 0xBEEF, "blobs")
     ref_logits, ref_labels = orc.unet_forward(blob, imgs)
-    with binding.Engine(128, 128, max_batch=2) as eng:      # 5 images through micro-batches of 2,2,1
+    with binding.Engine(128, 128, max_batch=2, conv_algo=algo) as eng:      # 5 images through micro-batches of 2,2,1
         eng.load_weights(blob)
         labels, logits = eng.infer(imgs, want_logits=True)
         flips = check_parity(labels, logits, ref_logits, ref_labels)
@@ -61,14 +63,15 @@ def test_against_oracle_128_batch_and_microbatching():
         assert np.array_equal(l1[0], labels[3]) and np.array_equal(g1[0], logits[3])
 
 
-def test_full_size_512_one_image_vs_oracle_and_batch16_properties():
+@pytest.mark.parametrize("algo", ["direct", "winograd"])
+def test_full_size_512_one_image_vs_oracle_and_batch16_properties(algo):
     """configs[1] of BASELINE.json: batch 16 at 512x512.  The oracle checks one image in full; the other 15 are
     covered by size-independent properties: batch independence (bit-identical to the single-image run), and
     determinism across two runs."""
     spec = UNetSpec()
     blob = pack_weights(spec, synth.make_weights(spec, 1234))
     imgs = synth.make_images(16, 512, 512, 1, 0x5EED, "bytes")
-    with binding.Engine(512, 512, max_batch=16) as eng:
+    with binding.Engine(512, 512, max_batch=16, conv_algo=algo) as eng:
         eng.load_weights(blob)
         labels, logits = eng.infer(imgs, want_logits=True)
         labels_b, logits_b = eng.infer(imgs, want_logits=True)

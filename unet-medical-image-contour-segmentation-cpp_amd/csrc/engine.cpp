@@ -7,6 +7,7 @@
 
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <fstream>
 #include <string>
@@ -54,6 +55,7 @@ struct mi_unet {
     hipStream_t own_stream = nullptr;
     hipStream_t stream = nullptr;
     bool weights_loaded = false;
+    bool wino = false;              // conv3x3 algorithm: false = direct implicit GEMM, true = Winograd F(2x2,3x3)
     // device memory
     float *d_weights = nullptr;     // one blob: every packed tensor (single allocation -> one broadcast / one free)
     size_t weight_floats = 0;
@@ -80,6 +82,30 @@ namespace {
 
 size_t round_up(size_t v, size_t g) { return (v + g - 1) / g * g; }
 
+// U = G g G^T for F(2x2,3x3); g is one 3x3 filter (row-major), out is 4x4 (row-major, position p = 4*xi + nu)
+void wino_filter_transform(const double g[9], double out[16])
+{
+    static const double G[4][3] = { { 1, 0, 0 }, { 0.5, 0.5, 0.5 }, { 0.5, -0.5, 0.5 }, { 0, 0, 1 } };
+    double t[4][3];
+    for (int i = 0; i < 4; ++i)
+        for (int j = 0; j < 3; ++j) t[i][j] = G[i][0] * g[0 * 3 + j] + G[i][1] * g[1 * 3 + j] + G[i][2] * g[2 * 3 + j];
+    for (int i = 0; i < 4; ++i)
+        for (int j = 0; j < 4; ++j) out[i * 4 + j] = t[i][0] * G[j][0] + t[i][1] * G[j][1] + t[i][2] * G[j][2];
+}
+
+// pack one conv3x3 (PyTorch [Cout][Cin][3][3], per-channel scale) into the Winograd layout [Cin/8][16][CoutPad][8]
+void pack_wino(const float *w, const double *scale, int cin, int cout, float *dst, size_t cpad)
+{
+    for (int co = 0; co < cout; ++co)
+        for (int ci = 0; ci < cin; ++ci) {
+            double g[9], u[16];
+            for (int t = 0; t < 9; ++t) g[t] = (double)w[((size_t)co * cin + ci) * 9 + t] * (scale ? scale[co] : 1.0);
+            wino_filter_transform(g, u);
+            for (int p = 0; p < 16; ++p)
+                dst[(((size_t)(ci / WINO_KC) * 16 + p) * cpad + co) * WINO_KC + ci % WINO_KC] = (float)u[p];
+        }
+}
+
 struct HostWeights {
     std::vector<float> blob;                    // packed, device layout
     struct Off { size_t w, shift; };
@@ -89,7 +115,7 @@ struct HostWeights {
 };
 
 // parse "MIUNETW1" (miunet/spec.py), fold BN, repack
-int build_host_weights(const mi_unet_config &cfg, const void *blob, size_t len, HostWeights &hw)
+int build_host_weights(const mi_unet_config &cfg, bool wino, const void *blob, size_t len, HostWeights &hw)
 {
     const unsigned char *p = static_cast<const unsigned char *>(blob);
     if (len < 36 || memcmp(p, "MIUNETW1", 8) != 0) return fail(MI_UNET_EFILE, "weight blob: bad magic (want MIUNETW1)");
@@ -135,6 +161,11 @@ int build_host_weights(const mi_unet_config &cfg, const void *blob, size_t len, 
                 for (int ci = 0; ci < cin; ++ci)
                     for (int t = 0; t < 9; ++t)
                         out[off.w + ((size_t)t * cin + ci) * cout + co] = (float)((double)w[((size_t)co * cin + ci) * 9 + t] * sc[co]);
+        } else if (wino) {                       // Winograd layout: [chunk8][pos][n (padded)][8], U = G g G^T
+            const int nch = (cin + WINO_KC - 1) / WINO_KC;
+            const size_t cpad = round_up(cout, NPAD);
+            off.w = alloc((size_t)nch * 16 * cpad * WINO_KC);
+            pack_wino(w, sc.data(), cin, cout, &out[off.w], cpad);
         } else {                                 // MFMA layout: [chunk][tap][n (padded)][KC]
             const int nch = (cin + KC - 1) / KC;
             const size_t cpad = round_up(cout, NPAD);
@@ -287,9 +318,9 @@ int run_microbatch(mi_unet *h, const uint8_t *d_imgs, int B, uint8_t *d_labels, 
             e = launch_conv3x3_first(d_imgs, h->d_lut, st.w, st.shift, st.dst, B, st.H, st.W, st.C, st.Cout, st.ld, s);
             break;
         case Step::CONV: {
-            kname = "conv3x3_mfma";
+            kname = h->wino ? "conv3x3_wino" : "conv3x3_mfma";
             ConvArgs a = st.a; a.B = B;
-            e = launch_conv3x3_mfma(a, s);
+            e = h->wino ? launch_conv3x3_wino(a, s) : launch_conv3x3_mfma(a, s);
             break;
         }
         case Step::CONVT: {
@@ -346,7 +377,7 @@ void mi_unet_default_config(mi_unet_config *cfg)
 {
     if (!cfg) return;
     cfg->height = 512; cfg->width = 512; cfg->in_ch = 1; cfg->base = 64; cfg->levels = 4; cfg->classes = 3;
-    cfg->max_batch = 16; cfg->device = 0;
+    cfg->max_batch = 16; cfg->device = 0; cfg->conv_algo = MI_UNET_CONV_AUTO;
 }
 
 int mi_unet_create(const mi_unet_config *cfg, mi_unet_t **out)
@@ -362,6 +393,7 @@ int mi_unet_create(const mi_unet_config *cfg, mi_unet_t **out)
         return fail(MI_UNET_EARG, "base must be a power of two in 16..256");
     if (cfg->classes < 2 || cfg->classes > 6) return fail(MI_UNET_EARG, "classes must be in 2..6");
     if (cfg->max_batch < 1) return fail(MI_UNET_EARG, "max_batch must be >= 1");
+    if (cfg->conv_algo < 0 || cfg->conv_algo > 2) return fail(MI_UNET_EARG, "conv_algo must be 0 (auto), 1 (direct) or 2 (winograd)");
     int ndev = mi_unet_device_count();
     if (ndev <= 0) return fail(MI_UNET_ENODEVICE, "no HIP device visible: libmiunet has no CPU fallback");
     if (cfg->device < 0 || cfg->device >= ndev) return fail(MI_UNET_EARG, "device ordinal out of range");
@@ -370,6 +402,16 @@ int mi_unet_create(const mi_unet_config *cfg, mi_unet_t **out)
     mi_unet *h = new mi_unet();
     h->cfg = *cfg;
     for (int i = 0; i <= L; ++i) h->ch[i] = cfg->base << i;
+    {
+        int algo = cfg->conv_algo;
+        if (algo == MI_UNET_CONV_AUTO) {
+            const char *env = getenv("MIUNET_CONV_ALGO");
+            if (env && !strcmp(env, "direct")) algo = MI_UNET_CONV_DIRECT;
+            else if (env && !strcmp(env, "winograd")) algo = MI_UNET_CONV_WINOGRAD;
+            else algo = MI_UNET_CONV_DEFAULT;
+        }
+        h->wino = (algo == MI_UNET_CONV_WINOGRAD);
+    }
     auto cleanup_fail = [&](int rc) { mi_unet_destroy(h); return rc; };
 #define HIP_TRY_H(expr)                                                                                        \
     do {                                                                                                       \
@@ -405,7 +447,7 @@ int mi_unet_load_weights_from_memory(mi_unet_t *h, const void *blob, size_t len)
     if (int rc = check_handle(h, false)) return rc;
     if (!blob) return fail(MI_UNET_EARG, "null weight blob");
     HostWeights hw;
-    if (int rc = build_host_weights(h->cfg, blob, len, hw)) return rc;
+    if (int rc = build_host_weights(h->cfg, h->wino, blob, len, hw)) return rc;
     HIP_TRY(hipSetDevice(h->cfg.device));
     if (h->d_weights) { HIP_TRY(hipFree(h->d_weights)); h->d_weights = nullptr; }
     h->weight_floats = hw.blob.size();
@@ -531,7 +573,19 @@ int mi_unet_layer_debug(int device, const char *op, const float *in, int B, int 
     std::vector<float> wpk, bias;
     size_t out_n = 0;
     ConvArgs a{};
-    if (o == "conv3x3" || o == "convT2x2") {
+    if (o == "conv3x3_wino") {
+        if (!w || Cout <= 0 || Cin % 4) return fail(MI_UNET_EARG, "layer_debug: conv needs weights and Cin % 4 == 0");
+        const int nch = (Cin + WINO_KC - 1) / WINO_KC;
+        const size_t npad = round_up((size_t)Cout, NPAD);
+        wpk.assign((size_t)nch * 16 * npad * WINO_KC, 0.f);
+        bias.assign(Cout, 0.f);
+        std::vector<double> sc(Cout, 1.0);
+        for (int co = 0; co < Cout; ++co) { bias[co] = shift ? shift[co] : 0.f; if (scale) sc[co] = scale[co]; }
+        pack_wino(w, sc.data(), Cin, Cout, wpk.data(), npad);
+        out_n = (size_t)B * H * W * Cout;
+        a.B = B; a.H = H; a.W = W; a.Cin = Cin; a.ldc = Cin; a.Cout = Cout; a.CoutPad = (int)npad; a.ldo = Cout; a.co_off = 0;
+        a.relu = relu;
+    } else if (o == "conv3x3" || o == "convT2x2") {
         if (!w || Cout <= 0 || Cin % 4) return fail(MI_UNET_EARG, "layer_debug: conv needs weights and Cin % 4 == 0");
         const bool T = (o == "convT2x2");
         const int nch = (Cin + KC - 1) / KC;
@@ -574,7 +628,8 @@ int mi_unet_layer_debug(int device, const char *op, const float *in, int B, int 
         DBG_TRY(hipMemcpy(d_w, wpk.data(), sizeof(float) * wpk.size(), hipMemcpyHostToDevice));
         DBG_TRY(hipMemcpy(d_b, bias.data(), sizeof(float) * bias.size(), hipMemcpyHostToDevice));
         a.in = d_in; a.wpk = d_w; a.bias = d_b; a.out = d_out;
-        DBG_TRY(o == "conv3x3" ? launch_conv3x3_mfma(a, nullptr) : launch_convT2x2_mfma(a, nullptr));
+        DBG_TRY(o == "conv3x3" ? launch_conv3x3_mfma(a, nullptr)
+                : o == "conv3x3_wino" ? launch_conv3x3_wino(a, nullptr) : launch_convT2x2_mfma(a, nullptr));
     } else {
         DBG_TRY(launch_maxpool2x2(d_in, Cin, d_out, B, H, W, Cin, nullptr));
     }

@@ -27,6 +27,11 @@ struct ConvArgs {
 };
 
 hipError_t launch_conv3x3_mfma(const ConvArgs &a, hipStream_t s);
+
+// Winograd F(2x2,3x3) form of the same layer: a.wpk holds the TRANSFORMED weights U = G g G^T packed as
+// [Cin/8][16 positions][CoutPad][8]  (WINO_KC = 8 input channels per K-chunk).  Same ConvArgs otherwise.
+constexpr int WINO_KC = 8;
+hipError_t launch_conv3x3_wino(const ConvArgs &a, hipStream_t s);
 hipError_t launch_convT2x2_mfma(const ConvArgs &a, hipStream_t s);
 
 // First layer: u8 image -> (LUT /255) -> conv3x3 (Cin = 1..4) + shift + ReLU.  w is [9][Cin][Cout] (BN scale folded).

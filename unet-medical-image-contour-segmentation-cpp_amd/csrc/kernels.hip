@@ -255,6 +255,231 @@ hipError_t launch_convT2x2_mfma(const ConvArgs &a, hipStream_t s)
 }
 
 // --------------------------------------------------------------------------------------------------------------------
+// Winograd F(2x2, 3x3) convolution on the fp32 MFMA (Lavin & Gray's minimal filtering: 16 multiplies per 2x2 output tile
+// and channel pair instead of 36 -- 2.25x fewer MACs, all arithmetic still fp32).
+//   Y = A^T [ sum_ci (G g G^T) .* (B^T d B) ] A
+// The 16 element-wise products are 16 independent GEMMs  M_p[tile][co] = sum_ci V_p[tile][ci] * U_p[ci][co]
+// (p = 4*xi + nu).  Mapping to CDNA4:
+//   * a workgroup = 4 waves (one per SIMD, the whole 512-entry register file each) owns 32*WM tiles (16 x 8*WM output
+//     pixels) x 32*WN output channels; wave (wm, wn) owns ONE 32-tile x 32-channel MFMA tile for ALL 16 positions
+//     = 16 accumulators of 32x32 (256 registers).  Because a lane then holds M_p for every p of the same (tile, channel),
+//     the inverse transform A^T M A is pure in-lane arithmetic: no LDS exchange, no second pass;
+//   * U fragments are wave-private (each wave has its own 32 output channels), so they never touch LDS: every lane
+//     loads its 16-byte fragment straight from global memory (one fully coalesced 1 KB wave-load per position), issued
+//     one whole K-chunk (64 MFMAs = 4096 cycles) ahead into the register the previous chunk just released;
+//   * V = B^T d B is shared by the waves of a tile row, so it is built once per chunk into a double-buffered LDS image
+//     [pos][tile][8 + 4 pad] (48-byte rows: 3i mod 16 is a bijection -> conflict-free ds_read_b128): 256 threads =
+//     64 tiles x 2 channel quads x 2 halves of xi; each thread loads its 3 x 4 pixels x 4 channels directly from the
+//     NHWC input (zero padding by predication), applies B^T .. B in registers and writes 8 x 16 bytes.  The loads for
+//     chunk c+1 are in flight during the MFMAs of chunk c; one barrier per chunk;
+//   * K order inside a chunk is permuted exactly as in the direct kernel (MFMA step s consumes k = 4h + s).
+template <int WM, int WN>
+__global__ __launch_bounds__(256, 1) void conv3x3_wino_f32(const ConvArgs a, const int tiles_x, const int tiles_y,
+                                                           const int m_tiles, const int nwg)
+{
+    static_assert(WM * WN == 4, "four waves");
+    constexpr int TMB = 32 * WM;              // 2x2 output tiles per workgroup
+    constexpr int VROW = WINO_KC + 4;         // padded floats per tile row in LDS
+    constexpr int VBUF = 16 * TMB * VROW;     // floats per V buffer
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave / WN, wn = wave % WN;
+    const int li = lane & 31, lh = lane >> 5;
+
+    const int L = xcd_remap(blockIdx.x, nwg);
+    const int n_tile = L / m_tiles;
+    int m = L - n_tile * m_tiles;
+    const int tx = m % tiles_x; m /= tiles_x;
+    const int ty = m % tiles_y;
+    const int b = m / tiles_y;
+    const int bx0 = tx * 16, by0 = ty * 8 * WM, n0 = n_tile * 32 * WN;
+    const float *in_img = a.in + (size_t)b * a.H * a.W * a.ldc;
+
+    // ---- input-transform role of this thread: (tile, channel quad, half of xi)
+    // half 0 builds V rows xi = 0,1 from patch rows (0,1,2); half 1 builds xi = 2,3 from patch rows (2,3,1).  With the
+    // rows taken in that order both halves use the SAME formulas
+    //     ta = l0 - l2          (xi 0: d0 - d2        | xi 2: d2 - d1)
+    //     tb = sgn * l1 + l2    (xi 1: d1 + d2        | xi 3: d1 - d3,  sgn = -1)
+    // so there is no per-lane select (multiplying by +-1 is exact).
+    const int t_tile = tid >> 2, t_quad = tid & 1, t_half = (tid >> 1) & 1;
+    const bool t_live = t_tile < TMB;
+    const float t_sgn = t_half ? -1.f : 1.f;
+    // The 3 x 4 pixels this thread needs are fetched with buffer loads: out-of-image taps (zero padding), dead threads
+    // and channels past Cin get voffset = 0xFFFFFFFF, which the hardware range check turns into zeros -- no branches.
+    unsigned p_boff[3];                       // byte offset of its row r, column 0, channel 4*quad inside the image
+    unsigned p_okmask = 0;                    // bit (4*r + c)
+    {
+        const int i = t_tile & 31, mt = t_tile >> 5;
+        const int iy0 = by0 + 2 * ((i >> 3) + 4 * mt) - 1;
+        const int ix0 = bx0 + 2 * (i & 7) - 1;
+#pragma unroll
+        for (int r = 0; r < 3; ++r) {
+            const int prow = t_half ? (r == 0 ? 2 : r == 1 ? 3 : 1) : r;
+            const int iy = iy0 + prow;
+            p_boff[r] = (unsigned)(((iy * a.W + ix0) * a.ldc + 4 * t_quad) * 4);
+            const bool rok = t_live && iy >= 0 && iy < a.H;
+#pragma unroll
+            for (int c = 0; c < 4; ++c)
+                if (rok && (ix0 + c) >= 0 && (ix0 + c) < a.W) p_okmask |= 1u << (4 * r + c);
+        }
+    }
+    const __amdgpu_buffer_rsrc_t in_rsrc =
+        __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(in_img), 0, a.H * a.W * a.ldc * 4, 0x00020000);
+    const unsigned col_bytes = (unsigned)a.ldc * 4;
+    f32x4 patch[3][4];
+    auto load_patch = [&](int chunk) {
+        const int c0 = chunk * WINO_KC;
+        const unsigned okm = (c0 + 4 * t_quad < a.Cin) ? p_okmask : 0u;
+#pragma unroll
+        for (int r = 0; r < 3; ++r)
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                const unsigned voff = (okm >> (4 * r + c)) & 1 ? p_boff[r] + c * col_bytes : 0xFFFFFFFFu;
+#ifdef WINO_EXP_NO_PATCH
+                patch[r][c] = f32x4{ (float)voff, 0.f, 0.f, (float)c0 };
+#else
+                patch[r][c] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(in_rsrc, voff, c0 * 4, 0));
+#endif
+            }
+    };
+    float *const v_wr = lds + (t_half * 8 * TMB + t_tile) * VROW + 4 * t_quad;   // + buf*VBUF + (xi_local*4 + nu)*TMB*VROW
+    // The transform is cut into 12 pieces so it can be threaded between MFMAs: pieces 0-3 = B^T d for patch column k,
+    // pieces 4-11 = one V position each (.. B, then its 16-byte store).
+    f32x4 t_rows[2][4];
+    auto transform_piece = [&](int k, int buf) {
+        if (k < 4) {
+            t_rows[0][k] = patch[0][k] - patch[2][k];
+            t_rows[1][k] = t_sgn * patch[1][k] + patch[2][k];
+        } else {
+            const int x = (k - 4) >> 2, nu = (k - 4) & 3;
+            const f32x4 *t = t_rows[x];
+            const f32x4 v = nu == 0 ? t[0] - t[2] : nu == 1 ? t[1] + t[2] : nu == 2 ? t[2] - t[1] : t[1] - t[3];
+            if (TMB * 4 >= 256 || t_live)     // WM = 2: every thread owns a tile, no branch
+                *reinterpret_cast<f32x4 *>(v_wr + buf * VBUF + (x * 4 + nu) * TMB * VROW) = v;
+        }
+    };
+
+    // ---- MFMA role: wave (wm, wn), all 16 positions
+    const int ncol = n0 + 32 * wn + li;
+    const size_t u_pos_stride = (size_t)a.CoutPad * WINO_KC;
+    const float *u_lane = a.wpk + (size_t)ncol * WINO_KC + 4 * lh;           // + (chunk*16 + pos) * u_pos_stride
+    const float *v_rd = lds + (32 * wm + li) * VROW + 4 * lh;                // + buf*VBUF + pos*TMB*VROW
+
+    f32x16 acc[16];
+#pragma unroll
+    for (int p = 0; p < 16; ++p)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[p][r] = 0.f;
+
+    const int nchunks = (a.Cin + WINO_KC - 1) / WINO_KC;
+    f32x4 u[16];
+#pragma unroll
+    for (int p = 0; p < 16; ++p) u[p] = *reinterpret_cast<const f32x4 *>(u_lane + (size_t)p * u_pos_stride);
+    load_patch(0);
+#pragma unroll
+    for (int k = 0; k < 12; ++k) transform_piece(k, 0);
+    __syncthreads();
+
+    for (int chunk = 0; chunk < nchunks; ++chunk) {
+        const int nxt = (chunk + 1 < nchunks) ? chunk + 1 : chunk;       // last iteration reloads itself: straight-line code
+        load_patch(nxt);                                                  // 12 buffer loads, consumed by the transform below
+        const float *vb = v_rd + (chunk & 1) * VBUF;
+        const float *un = u_lane + (size_t)nxt * 16 * u_pos_stride;
+        const int wbuf = (chunk + 1) & 1;
+        f32x4 av = *reinterpret_cast<const f32x4 *>(vb);
+        // A lone wave per SIMD issues in order: a filler only hides if it sits BETWEEN two MFMAs.  Positions 0-7 run
+        // bare (the patch loads are landing); positions 8-15 carry one transform piece after every other MFMA.
+#pragma unroll
+        for (int p = 0; p < 16; ++p) {
+            f32x4 avn = av;
+#ifdef WINO_EXP_NO_LDS
+            avn = av + 1.0f;
+#else
+            if (p + 1 < 16) avn = *reinterpret_cast<const f32x4 *>(vb + (p + 1) * TMB * VROW);   // V fragment one position ahead
+#endif
+            __builtin_amdgcn_sched_barrier(0);        // ... issued BEFORE this position's MFMAs (hipcc would sink it to its use)
+            const f32x4 bv = u[p];
+#pragma unroll
+            for (int s = 0; s < 4; ++s) {
+                acc[p] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[s], bv[s], acc[p], 0, 0, 0);
+                const int idx = (p - 8) * 4 + s;
+#ifndef WINO_EXP_NO_XFORM
+                if (p >= 8 && (idx & 1) == 0 && idx / 2 < 12) {
+                    transform_piece(idx / 2, wbuf);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+#endif
+            }
+#ifndef WINO_EXP_NO_U
+            u[p] = *reinterpret_cast<const f32x4 *>(un + (size_t)p * u_pos_stride);             // refill a full chunk ahead
+#endif
+            av = avn;
+            __builtin_amdgcn_sched_barrier(0);
+        }
+#ifndef WINO_EXP_NO_XFORM
+        __syncthreads();
+#endif
+    }
+
+    // ---- epilogue: Y = A^T M A in-lane, + shift, ReLU, 2x2 store.  Lane = channel, register r = tile row of the MFMA tile.
+    const bool n_ok = ncol < a.Cout;
+    const float sh = n_ok ? a.bias[ncol] : 0.f;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int i = (r & 3) + 8 * (r >> 2) + 4 * lh;
+        const int oy = by0 + 2 * ((i >> 3) + 4 * wm), ox = bx0 + 2 * (i & 7);
+        float s0[4], s1[4];
+#pragma unroll
+        for (int nu = 0; nu < 4; ++nu) {
+            const float m0 = acc[0 + nu][r], m1 = acc[4 + nu][r], m2 = acc[8 + nu][r], m3 = acc[12 + nu][r];
+            s0[nu] = m0 + m1 + m2;
+            s1[nu] = m1 - m2 - m3;
+        }
+        float y[2][2];
+        y[0][0] = s0[0] + s0[1] + s0[2]; y[0][1] = s0[1] - s0[2] - s0[3];
+        y[1][0] = s1[0] + s1[1] + s1[2]; y[1][1] = s1[1] - s1[2] - s1[3];
+#pragma unroll
+        for (int dy = 0; dy < 2; ++dy)
+#pragma unroll
+            for (int dx = 0; dx < 2; ++dx) {
+                float v = y[dy][dx] + sh;
+                if (a.relu) v = v > 0.f ? v : 0.f;
+                if (n_ok && oy + dy < a.H && ox + dx < a.W)
+                    a.out[(((size_t)b * a.H + oy + dy) * a.W + ox + dx) * a.ldo + a.co_off + ncol] = v;
+            }
+    }
+}
+
+template <int WM, int WN>
+static hipError_t launch_wino_cfg(const ConvArgs &a, hipStream_t s)
+{
+    const int tiles_x = (a.W + 15) / 16, tiles_y = (a.H + 8 * WM - 1) / (8 * WM);
+    const int m_tiles = tiles_x * tiles_y * a.B;
+    const int n_tiles = (a.Cout + 32 * WN - 1) / (32 * WN);
+    const int nwg = m_tiles * n_tiles;
+    constexpr size_t lds = sizeof(float) * 2 * 16 * (32 * WM) * (WINO_KC + 4);
+    static bool attr_set = false;
+    auto kern = conv3x3_wino_f32<WM, WN>;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return e;
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(kern, dim3(nwg), dim3(256), lds, s, a, tiles_x, tiles_y, m_tiles, nwg);
+    return hipGetLastError();
+}
+
+hipError_t launch_conv3x3_wino(const ConvArgs &a, hipStream_t s)
+{
+    if (a.Cin % 4 || a.ldc % 4 || a.CoutPad % NPAD) return hipErrorInvalidValue;
+    return launch_wino_cfg<2, 2>(a, s);
+}
+
+// --------------------------------------------------------------------------------------------------------------------
 // First layer (K = 9*Cin with Cin <= 4: HBM-bound on its output).  One thread = one pixel x 4 output channels; the
 // Cout/4 threads of a pixel write one contiguous NHWC row.  u8 -> fp32 through the host-built 256-entry table so the
 // input equals float(x)/255.0f bit for bit (src/process.cpp:36-39).

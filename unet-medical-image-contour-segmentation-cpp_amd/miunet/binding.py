@@ -23,7 +23,7 @@ EXPORTS = [
 
 class Config(C.Structure):
     _fields_ = [("height", C.c_int), ("width", C.c_int), ("in_ch", C.c_int), ("base", C.c_int), ("levels", C.c_int),
-                ("classes", C.c_int), ("max_batch", C.c_int), ("device", C.c_int)]
+                ("classes", C.c_int), ("max_batch", C.c_int), ("device", C.c_int), ("conv_algo", C.c_int)]
 
 
 class KernelStat(C.Structure):
@@ -91,8 +91,11 @@ def _ptr(a):
 class Engine:
     """One engine handle = one GPU's context (the reference's thread-local TensorRTContext, include/process.h:13-23)."""
 
-    def __init__(self, height=512, width=512, in_ch=1, base=64, levels=4, classes=3, max_batch=16, device=0):
-        self.cfg = Config(height, width, in_ch, base, levels, classes, max_batch, device)
+    CONV_ALGOS = {"auto": 0, "direct": 1, "winograd": 2}
+
+    def __init__(self, height=512, width=512, in_ch=1, base=64, levels=4, classes=3, max_batch=16, device=0,
+                 conv_algo="auto"):
+        self.cfg = Config(height, width, in_ch, base, levels, classes, max_batch, device, self.CONV_ALGOS[conv_algo])
         self._h = C.c_void_p()
         _check(lib().mi_unet_create(C.byref(self.cfg), C.byref(self._h)))
 
@@ -166,7 +169,7 @@ def layer_debug(op, x, w=None, scale=None, shift=None, relu=False, device=0):
     x = np.ascontiguousarray(x, np.float32)
     b, h, ww, cin = x.shape
     cout = 0
-    if op == "conv3x3":
+    if op in ("conv3x3", "conv3x3_wino"):
         w = np.ascontiguousarray(w, np.float32)
         cout = w.shape[0]
         out = np.empty((b, h, ww, cout), np.float32)
