@@ -31,6 +31,7 @@ hipError_t launch_conv3x3_mfma(const ConvArgs &a, hipStream_t s);
 // Winograd F(2x2,3x3) form of the same layer: a.wpk holds the TRANSFORMED weights U = G g G^T packed as
 // [Cin/8][16 positions][CoutPad][8]  (WINO_KC = 8 input channels per K-chunk).  Same ConvArgs otherwise.
 constexpr int WINO_KC = 8;
+constexpr int WINO_SC = 32;       // input channels per raw-patch staging step (4 K-chunks: one whole 128-byte line per pixel)
 hipError_t launch_conv3x3_wino(const ConvArgs &a, hipStream_t s);
 hipError_t launch_convT2x2_mfma(const ConvArgs &a, hipStream_t s);
 

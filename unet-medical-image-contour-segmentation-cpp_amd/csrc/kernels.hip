@@ -274,14 +274,29 @@ hipError_t launch_convT2x2_mfma(const ConvArgs &a, hipStream_t s)
 //     chunk c+1 are in flight during the MFMAs of chunk c; one barrier per chunk;
 //   * K order inside a chunk is permuted exactly as in the direct kernel (MFMA step s consumes k = 4h + s).
 template <int WM, int WN>
+struct WinoGeom {
+    static constexpr int TMB = 32 * WM;                    // 2x2 output tiles per workgroup (8 wide x 4*WM tall)
+    static constexpr int VROW = WINO_KC + 4;               // padded floats per tile row of V
+    static constexpr int VBUF = 16 * TMB * VROW;           // floats per V buffer
+    static constexpr int PROWS = 8 * WM + 2;               // raw patch rows (16 x 8*WM output pixels + halo)
+    static constexpr int RAWPIX = PROWS * 18;
+    static constexpr int RAW_P = WINO_SC + 4;              // padded floats per raw pixel (2-way worst case on ds_read_b128)
+    static constexpr int RAW_FLOATS = RAWPIX * RAW_P;
+    static constexpr int RAW_ITERS = (RAWPIX * (WINO_SC / 4) + 255) / 256;
+    static constexpr size_t LDS_BYTES = sizeof(float) * (2 * VBUF + RAW_FLOATS);
+};
+
+template <int WM, int WN>
 __global__ __launch_bounds__(256, 1) void conv3x3_wino_f32(const ConvArgs a, const int tiles_x, const int tiles_y,
                                                            const int m_tiles, const int nwg)
 {
     static_assert(WM * WN == 4, "four waves");
-    constexpr int TMB = 32 * WM;              // 2x2 output tiles per workgroup
-    constexpr int VROW = WINO_KC + 4;         // padded floats per tile row in LDS
-    constexpr int VBUF = 16 * TMB * VROW;     // floats per V buffer
+    using G = WinoGeom<WM, WN>;
+    constexpr int TMB = G::TMB, VROW = G::VROW, VBUF = G::VBUF, RAW_P = G::RAW_P;
+    constexpr int CPS = WINO_SC / WINO_KC;    // K-chunks per super-chunk
     extern __shared__ __attribute__((aligned(16))) float lds[];
+    float *const Vs = lds;                    // [2][16][TMB][VROW]
+    float *const Raw = lds + 2 * VBUF;        // [RAWPIX][RAW_P]: the input halo patch of ONE 32-channel super-chunk
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -298,7 +313,42 @@ __global__ __launch_bounds__(256, 1) void conv3x3_wino_f32(const ConvArgs a, con
     const int bx0 = tx * 16, by0 = ty * 8 * WM, n0 = n_tile * 32 * WN;
     const float *in_img = a.in + (size_t)b * a.H * a.W * a.ldc;
 
-    // ---- input-transform role of this thread: (tile, channel quad, half of xi)
+    // ---- stage 1 of the input path: the raw halo patch, 32 channels at a time, global -> registers -> LDS.
+    // 8 consecutive lanes fetch one pixel's 128 contiguous bytes (whole cache lines, each fetched once per workgroup);
+    // out-of-image pixels (zero padding), channels past Cin and dead slots get voffset 0xFFFFFFFF, which the buffer
+    // range check turns into zeros: no branches.
+    const __amdgpu_buffer_rsrc_t in_rsrc =
+        __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(in_img), 0, a.H * a.W * a.ldc * 4, 0x00020000);
+    unsigned raw_voff[G::RAW_ITERS];          // byte offset in the image (channel 4*q8 of super-chunk 0), or 0xFFFFFFFF
+    int raw_loff[G::RAW_ITERS];               // float offset in Raw, -1 = dead slot
+#pragma unroll
+    for (int s = 0; s < G::RAW_ITERS; ++s) {
+        const int e = tid + 256 * s;
+        const int pix = e >> 3, q8 = e & 7;
+        const int py = pix / 18, px = pix - py * 18;
+        const int gy = by0 - 1 + py, gx = bx0 - 1 + px;
+        const bool live = pix < G::RAWPIX;
+        const bool inb = live && gy >= 0 && gy < a.H && gx >= 0 && gx < a.W;
+        raw_voff[s] = inb ? (unsigned)(((gy * a.W + gx) * a.ldc + 4 * q8) * 4) : 0xFFFFFFFFu;
+        raw_loff[s] = live ? pix * RAW_P + 4 * q8 : -1;
+    }
+    f32x4 raw_reg[G::RAW_ITERS];
+    auto raw_load = [&](int super) {
+        const int c0 = super * WINO_SC;
+#pragma unroll
+        for (int s = 0; s < G::RAW_ITERS; ++s) {
+            const int q8 = (tid + 256 * s) & 7;
+            const unsigned voff = (c0 + 4 * q8 < a.Cin) ? raw_voff[s] : 0xFFFFFFFFu;
+            raw_reg[s] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(in_rsrc, voff, c0 * 4, 0));
+        }
+    };
+    auto raw_store = [&]() {
+#pragma unroll
+        for (int s = 0; s < G::RAW_ITERS; ++s)
+            if (raw_loff[s] >= 0) *reinterpret_cast<f32x4 *>(Raw + raw_loff[s]) = raw_reg[s];
+    };
+
+    // ---- stage 2: V = B^T d B for one K-chunk (8 channels), thread = (tile, channel quad, half of xi).
     // half 0 builds V rows xi = 0,1 from patch rows (0,1,2); half 1 builds xi = 2,3 from patch rows (2,3,1).  With the
     // rows taken in that order both halves use the SAME formulas
     //     ta = l0 - l2          (xi 0: d0 - d2        | xi 2: d2 - d1)
@@ -307,45 +357,23 @@ __global__ __launch_bounds__(256, 1) void conv3x3_wino_f32(const ConvArgs a, con
     const int t_tile = tid >> 2, t_quad = tid & 1, t_half = (tid >> 1) & 1;
     const bool t_live = t_tile < TMB;
     const float t_sgn = t_half ? -1.f : 1.f;
-    // The 3 x 4 pixels this thread needs are fetched with buffer loads: out-of-image taps (zero padding), dead threads
-    // and channels past Cin get voffset = 0xFFFFFFFF, which the hardware range check turns into zeros -- no branches.
-    unsigned p_boff[3];                       // byte offset of its row r, column 0, channel 4*quad inside the image
-    unsigned p_okmask = 0;                    // bit (4*r + c)
+    int p_loff[3];                            // float offset in Raw of its patch row r, column 0, channel 4*quad
     {
         const int i = t_tile & 31, mt = t_tile >> 5;
-        const int iy0 = by0 + 2 * ((i >> 3) + 4 * mt) - 1;
-        const int ix0 = bx0 + 2 * (i & 7) - 1;
+        const int pr0 = 2 * ((i >> 3) + 4 * mt), pc0 = 2 * (i & 7);
 #pragma unroll
         for (int r = 0; r < 3; ++r) {
             const int prow = t_half ? (r == 0 ? 2 : r == 1 ? 3 : 1) : r;
-            const int iy = iy0 + prow;
-            p_boff[r] = (unsigned)(((iy * a.W + ix0) * a.ldc + 4 * t_quad) * 4);
-            const bool rok = t_live && iy >= 0 && iy < a.H;
-#pragma unroll
-            for (int c = 0; c < 4; ++c)
-                if (rok && (ix0 + c) >= 0 && (ix0 + c) < a.W) p_okmask |= 1u << (4 * r + c);
+            p_loff[r] = t_live ? ((pr0 + prow) * 18 + pc0) * RAW_P + 4 * t_quad : 0;
         }
     }
-    const __amdgpu_buffer_rsrc_t in_rsrc =
-        __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(in_img), 0, a.H * a.W * a.ldc * 4, 0x00020000);
-    const unsigned col_bytes = (unsigned)a.ldc * 4;
     f32x4 patch[3][4];
-    auto load_patch = [&](int chunk) {
-        const int c0 = chunk * WINO_KC;
-        const unsigned okm = (c0 + 4 * t_quad < a.Cin) ? p_okmask : 0u;
+    auto patch_read = [&](int r, int chunk_in_super) {       // one patch row (4 pixels) of this thread, LDS -> registers
 #pragma unroll
-        for (int r = 0; r < 3; ++r)
-#pragma unroll
-            for (int c = 0; c < 4; ++c) {
-                const unsigned voff = (okm >> (4 * r + c)) & 1 ? p_boff[r] + c * col_bytes : 0xFFFFFFFFu;
-#ifdef WINO_EXP_NO_PATCH
-                patch[r][c] = f32x4{ (float)voff, 0.f, 0.f, (float)c0 };
-#else
-                patch[r][c] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(in_rsrc, voff, c0 * 4, 0));
-#endif
-            }
+        for (int c = 0; c < 4; ++c)
+            patch[r][c] = *reinterpret_cast<const f32x4 *>(Raw + p_loff[r] + c * RAW_P + chunk_in_super * WINO_KC);
     };
-    float *const v_wr = lds + (t_half * 8 * TMB + t_tile) * VROW + 4 * t_quad;   // + buf*VBUF + (xi_local*4 + nu)*TMB*VROW
+    float *const v_wr = Vs + (t_half * 8 * TMB + t_tile) * VROW + 4 * t_quad;   // + buf*VBUF + (xi_local*4 + nu)*TMB*VROW
     // The transform is cut into 12 pieces so it can be threaded between MFMAs: pieces 0-3 = B^T d for patch column k,
     // pieces 4-11 = one V position each (.. B, then its 16-byte store).
     f32x4 t_rows[2][4];
@@ -366,7 +394,7 @@ __global__ __launch_bounds__(256, 1) void conv3x3_wino_f32(const ConvArgs a, con
     const int ncol = n0 + 32 * wn + li;
     const size_t u_pos_stride = (size_t)a.CoutPad * WINO_KC;
     const float *u_lane = a.wpk + (size_t)ncol * WINO_KC + 4 * lh;           // + (chunk*16 + pos) * u_pos_stride
-    const float *v_rd = lds + (32 * wm + li) * VROW + 4 * lh;                // + buf*VBUF + pos*TMB*VROW
+    const float *v_rd = Vs + (32 * wm + li) * VROW + 4 * lh;                 // + buf*VBUF + pos*TMB*VROW
 
     f32x16 acc[16];
 #pragma unroll
@@ -375,53 +403,60 @@ __global__ __launch_bounds__(256, 1) void conv3x3_wino_f32(const ConvArgs a, con
         for (int r = 0; r < 16; ++r) acc[p][r] = 0.f;
 
     const int nchunks = (a.Cin + WINO_KC - 1) / WINO_KC;
+    const int nsuper = (a.Cin + WINO_SC - 1) / WINO_SC;
     f32x4 u[16];
 #pragma unroll
     for (int p = 0; p < 16; ++p) u[p] = *reinterpret_cast<const f32x4 *>(u_lane + (size_t)p * u_pos_stride);
-    load_patch(0);
+    // prologue: raw patch of super-chunk 0 -> LDS, V of chunk 0
+    raw_load(0);
+    raw_store();
+    __syncthreads();
+#pragma unroll
+    for (int r = 0; r < 3; ++r) patch_read(r, 0);
 #pragma unroll
     for (int k = 0; k < 12; ++k) transform_piece(k, 0);
     __syncthreads();
 
+    // Per K-chunk c (super-chunk S = c / 4, j = c % 4):
+    //   j == 0 : issue the buffer loads of super-chunk S+1's raw patch (registers; they have three chunks to land)
+    //   j == 3 : write them to Raw (its last reader, the transform of chunk (S,3), ran during chunk (S,2)) + one extra barrier
+    //   always : 64 MFMAs; the V fragment one position ahead; the U refill one chunk ahead; during positions 4-6 the 12
+    //            ds_reads of the NEXT chunk's patch, during positions 8-13 its transform, one piece after every other MFMA
+    //            (a lone wave per SIMD issues in order: a filler only hides if it sits BETWEEN two MFMAs); one barrier.
     for (int chunk = 0; chunk < nchunks; ++chunk) {
-        const int nxt = (chunk + 1 < nchunks) ? chunk + 1 : chunk;       // last iteration reloads itself: straight-line code
-        load_patch(nxt);                                                  // 12 buffer loads, consumed by the transform below
+        const int j = chunk & (CPS - 1), S = chunk / CPS;
+        if (j == 0 && S + 1 < nsuper) raw_load(S + 1);
+        if (j == CPS - 1 && S + 1 < nsuper) {
+            raw_store();
+            __syncthreads();
+        }
+        const int nxt = (chunk + 1 < nchunks) ? chunk + 1 : chunk;       // last iteration re-does itself: straight-line code
+        const int nxt_j = nxt & (CPS - 1);
         const float *vb = v_rd + (chunk & 1) * VBUF;
         const float *un = u_lane + (size_t)nxt * 16 * u_pos_stride;
         const int wbuf = (chunk + 1) & 1;
         f32x4 av = *reinterpret_cast<const f32x4 *>(vb);
-        // A lone wave per SIMD issues in order: a filler only hides if it sits BETWEEN two MFMAs.  Positions 0-7 run
-        // bare (the patch loads are landing); positions 8-15 carry one transform piece after every other MFMA.
 #pragma unroll
         for (int p = 0; p < 16; ++p) {
             f32x4 avn = av;
-#ifdef WINO_EXP_NO_LDS
-            avn = av + 1.0f;
-#else
             if (p + 1 < 16) avn = *reinterpret_cast<const f32x4 *>(vb + (p + 1) * TMB * VROW);   // V fragment one position ahead
-#endif
-            __builtin_amdgcn_sched_barrier(0);        // ... issued BEFORE this position's MFMAs (hipcc would sink it to its use)
+            if (p >= 4 && p < 7) patch_read(p - 4, nxt_j);
+            __builtin_amdgcn_sched_barrier(0);        // ... issued BEFORE this position's MFMAs (hipcc would sink them to their use)
             const f32x4 bv = u[p];
 #pragma unroll
             for (int s = 0; s < 4; ++s) {
                 acc[p] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[s], bv[s], acc[p], 0, 0, 0);
                 const int idx = (p - 8) * 4 + s;
-#ifndef WINO_EXP_NO_XFORM
                 if (p >= 8 && (idx & 1) == 0 && idx / 2 < 12) {
                     transform_piece(idx / 2, wbuf);
                     __builtin_amdgcn_sched_barrier(0);
                 }
-#endif
             }
-#ifndef WINO_EXP_NO_U
             u[p] = *reinterpret_cast<const f32x4 *>(un + (size_t)p * u_pos_stride);             // refill a full chunk ahead
-#endif
             av = avn;
             __builtin_amdgcn_sched_barrier(0);
         }
-#ifndef WINO_EXP_NO_XFORM
         __syncthreads();
-#endif
     }
 
     // ---- epilogue: Y = A^T M A in-lane, + shift, ReLU, 2x2 store.  Lane = channel, register r = tile row of the MFMA tile.
@@ -460,7 +495,7 @@ static hipError_t launch_wino_cfg(const ConvArgs &a, hipStream_t s)
     const int m_tiles = tiles_x * tiles_y * a.B;
     const int n_tiles = (a.Cout + 32 * WN - 1) / (32 * WN);
     const int nwg = m_tiles * n_tiles;
-    constexpr size_t lds = sizeof(float) * 2 * 16 * (32 * WM) * (WINO_KC + 4);
+    constexpr size_t lds = WinoGeom<WM, WN>::LDS_BYTES;
     static bool attr_set = false;
     auto kern = conv3x3_wino_f32<WM, WN>;
     if (!attr_set) {
