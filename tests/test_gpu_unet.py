@@ -102,3 +102,23 @@ def test_error_paths():
             eng.infer(np.zeros((1, 32, 32, 1), np.uint8))                             # src/process.cpp:126-128
     with pytest.raises(binding.MiUnetError):
         binding.Engine(100, 64)                                                      # not a multiple of 2^levels
+
+
+@pytest.mark.parametrize("algo", ["direct", "winograd"])
+def test_fused_pooling_is_bit_identical_to_the_pool_kernel(algo, monkeypatch):
+    """The conv epilogues write the 2x2-max-pooled tensor themselves; MIUNET_FUSE_POOL=0 runs the stand-alone pooling
+    kernel instead.  max and (+shift, ReLU) commute exactly, so logits must agree bit for bit."""
+    spec = UNetSpec()
+    blob = pack_weights(spec, synth.make_weights(spec, 77))
+    imgs = synth.make_images(2, 96, 160, 1, 0x1111, "blobs")
+    outs = []
+    for flag in ("1", "0"):
+        monkeypatch.setenv("MIUNET_FUSE_POOL", flag)
+        with binding.Engine(96, 160, max_batch=2, conv_algo=algo) as eng:
+            eng.load_weights(blob)
+            eng.set_profiling(True)
+            labels, logits = eng.infer(imgs, want_logits=True)
+            kernels = [s["kernel"] for s in eng.kernel_stats()]
+        assert ("maxpool2x2" in kernels) == (flag == "0")
+        outs.append((labels, logits))
+    assert np.array_equal(outs[0][0], outs[1][0]) and np.array_equal(outs[0][1], outs[1][1])

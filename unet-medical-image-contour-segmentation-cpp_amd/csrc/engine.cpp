@@ -45,6 +45,7 @@ struct Step {
     const float *w = nullptr, *shift = nullptr;
     int H = 0, W = 0, C = 0, Cout = 0, ld = 0;
     double flops_per_img = 0, bytes_per_img = 0, weight_bytes = 0;
+    bool fused_away = false;      // POOL steps whose work is done by the preceding conv's epilogue
 };
 
 }  // namespace
@@ -56,6 +57,7 @@ struct mi_unet {
     hipStream_t stream = nullptr;
     bool weights_loaded = false;
     bool wino = false;              // conv3x3 algorithm: false = direct implicit GEMM, true = Winograd F(2x2,3x3)
+    bool fuse_pool = true;          // MIUNET_FUSE_POOL=0 keeps the stand-alone pooling kernel (A/B and parity checks)
     // device memory
     float *d_weights = nullptr;     // one blob: every packed tensor (single allocation -> one broadcast / one free)
     size_t weight_floats = 0;
@@ -247,19 +249,29 @@ int build_plan(mi_unet *h, const HostWeights &hw)
     {   // inc.c1 : u8 image -> s0
         Step s;
         s.kind = Step::FIRST; s.name = "inc.c1";
-        s.w = W_(hw.conv[ci].w); s.shift = W_(hw.conv[ci].shift); s.dst = h->d_s0;
+        s.w = W_(hw.conv[ci].w); s.shift = W_(hw.conv[ci].shift); s.dst = h->d_s1;   // s0 receives inc.c2's pooled output
         s.H = H; s.W = Wd; s.C = c.in_ch; s.Cout = ch[0]; s.ld = ch[0];
         s.flops_per_img = 2.0 * H * Wd * 9.0 * c.in_ch * ch[0];
         s.bytes_per_img = (double)H * Wd * (c.in_ch + 4.0 * ch[0]);
         ++ci;
         h->plan.push_back(s);
     }
-    conv_step("inc.c2", h->d_s0, ch[0], ch[0], L > 0 ? h->d_cat[0] : h->d_s1, L > 0 ? 2 * ch[0] : ch[0], 0, ch[0], H, Wd);
+    conv_step("inc.c2", h->d_s1, ch[0], ch[0], h->d_cat[0], 2 * ch[0], 0, ch[0], H, Wd);
     for (int i = 1; i <= L; ++i) {
+        // 2x2 max pooling: fused into the epilogue of the conv that produced the skip tensor (it holds every pooling
+        // window inside one lane); the stand-alone kernel stays in the plan for configurations that cannot fuse
+        Step &prod = h->plan.back();
+        const bool fuse = h->fuse_pool && prod.kind == Step::CONV && H % 2 == 0 && Wd % 2 == 0;
+        if (fuse) {
+            prod.a.pool_out = h->d_s0;
+            prod.a.pool_ld = ch[i - 1];
+            prod.bytes_per_img += 4.0 * (H / 2) * (Wd / 2) * ch[i - 1];
+        }
         Step p;
         p.kind = Step::POOL; p.name = "down" + std::to_string(i) + ".pool";
         p.src = h->d_cat[i - 1]; p.ld = 2 * ch[i - 1]; p.dst = h->d_s0; p.H = H; p.W = Wd; p.C = ch[i - 1];
         p.bytes_per_img = 4.0 * H * Wd * ch[i - 1] * 1.25;
+        p.fused_away = fuse;
         h->plan.push_back(p);
         H /= 2; Wd /= 2;
         conv_step("down" + std::to_string(i) + ".c1", h->d_s0, ch[i - 1], ch[i - 1], h->d_s1, ch[i], 0, ch[i], H, Wd);
@@ -268,8 +280,7 @@ int build_plan(mi_unet *h, const HostWeights &hw)
         else
             conv_step("down" + std::to_string(i) + ".c2", h->d_s1, ch[i], ch[i], h->d_s0, ch[i], 0, ch[i], H, Wd);
     }
-    // when L == 0 the feature map is in s1; otherwise in s0
-    float *cur = L > 0 ? h->d_s0 : h->d_s1;
+    float *cur = h->d_s0;         // bottleneck feature map (levels >= 1 is enforced by mi_unet_create)
     for (int i = 1; i <= L; ++i) {
         const int lvl = L - i, cin = ch[lvl + 1], cout = ch[lvl];
         Step t;
@@ -299,6 +310,7 @@ int run_microbatch(mi_unet *h, const uint8_t *d_imgs, int B, uint8_t *d_labels, 
 {
     hipStream_t s = h->stream;
     for (Step &st : h->plan) {
+        if (st.fused_away) continue;
         hipEvent_t e0 = nullptr, e1 = nullptr;
         if (h->profiling) {
             while (h->ev_pool.size() < h->ev_used + 2) {
@@ -411,6 +423,8 @@ int mi_unet_create(const mi_unet_config *cfg, mi_unet_t **out)
             else algo = MI_UNET_CONV_DEFAULT;
         }
         h->wino = (algo == MI_UNET_CONV_WINOGRAD);
+        const char *fp = getenv("MIUNET_FUSE_POOL");
+        h->fuse_pool = !(fp && !strcmp(fp, "0"));
     }
     auto cleanup_fail = [&](int rc) { mi_unet_destroy(h); return rc; };
 #define HIP_TRY_H(expr)                                                                                        \

@@ -24,6 +24,10 @@ struct ConvArgs {
     int CoutPad;          // padded N of wpk
     int ldo, co_off;
     int relu;
+    // optional fused 2x2/stride-2 max pooling of the (post-ReLU) output: a second store of [B][H/2][W/2][pool_ld] at
+    // channel 0.  Both conv kernels hold every 2x2 output block inside one lane, so this costs one max3 + one store.
+    float *pool_out;
+    int pool_ld;
 };
 
 hipError_t launch_conv3x3_mfma(const ConvArgs &a, hipStream_t s);

@@ -199,6 +199,18 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_f32(const ConvArgs a, const 
         }
         const bool n_ok = (TAPS == 9) ? (n < a.Cout) : (n < 4 * a.Cout);
         const float sh = n_ok ? a.bias[co] : 0.f;
+        if (TAPS == 9 && MT == 2 && a.pool_out != nullptr) {
+            // rows (y, y+1) are the wave's two MFMA tiles, columns (x, x+1) are registers (r, r+1), r even
+            const int yp = (y0 + wave * MT) >> 1;
+#pragma unroll
+            for (int r = 0; r < 16; r += 2) {
+                const int x = x0 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+                float m = fmaxf(fmaxf(acc[0][j][r], acc[0][j][r + 1]), fmaxf(acc[MT - 1][j][r], acc[MT - 1][j][r + 1])) + sh;
+                if (a.relu) m = m > 0.f ? m : 0.f;             // max and (+shift, ReLU) commute: both are monotone
+                if (n_ok && y0 + wave * MT + 1 < a.H && x + 1 < a.W)
+                    a.pool_out[(((size_t)b * (a.H >> 1) + yp) * (a.W >> 1) + (x >> 1)) * a.pool_ld + co] = m;
+            }
+        }
 #pragma unroll
         for (int i = 0; i < MT; ++i) {
             const int y = y0 + wave * MT + i;
@@ -476,15 +488,19 @@ __global__ __launch_bounds__(256, 1) void conv3x3_wino_f32(const ConvArgs a, con
         float y[2][2];
         y[0][0] = s0[0] + s0[1] + s0[2]; y[0][1] = s0[1] - s0[2] - s0[3];
         y[1][0] = s1[0] + s1[1] + s1[2]; y[1][1] = s1[1] - s1[2] - s1[3];
+        float vmax = -3.402823466e+38f;
 #pragma unroll
         for (int dy = 0; dy < 2; ++dy)
 #pragma unroll
             for (int dx = 0; dx < 2; ++dx) {
                 float v = y[dy][dx] + sh;
                 if (a.relu) v = v > 0.f ? v : 0.f;
+                vmax = fmaxf(vmax, v);
                 if (n_ok && oy + dy < a.H && ox + dx < a.W)
                     a.out[(((size_t)b * a.H + oy + dy) * a.W + ox + dx) * a.ldo + a.co_off + ncol] = v;
             }
+        if (a.pool_out != nullptr && n_ok && oy + 1 < a.H && ox + 1 < a.W)    // the lane's 2x2 tile IS one pooling window
+            a.pool_out[(((size_t)b * (a.H >> 1) + (oy >> 1)) * (a.W >> 1) + (ox >> 1)) * a.pool_ld + ncol] = vmax;
     }
 }
 
