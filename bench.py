@@ -76,7 +76,7 @@ def main():
     ap.add_argument("--size", type=int, default=512)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--per-layer", action="store_true", help="also print a per-layer table to stderr")
-    ap.add_argument("--conv-algo", choices=["auto", "direct", "winograd"], default="auto")
+    ap.add_argument("--conv-algo", choices=["auto", "direct", "winograd", "winograd16"], default="auto")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -147,7 +147,7 @@ def main():
         images = B * world * args.steps
         ips = images / dt
         # dominant kernel: the fp32 MFMA implicit-GEMM conv (17 launches per step, 97 % of the FLOPs)
-        dom = [s for s in stats if s["kernel"] in ("conv3x3_mfma", "conv3x3_wino")]
+        dom = [s for s in stats if s["kernel"] in ("conv3x3_mfma", "conv3x3_wino", "conv3x3_wino16")]
         dom_kernel = dom[0]["kernel"] if dom else "conv3x3_mfma"
         dom_flops = sum(s["flops"] for s in dom)
         dom_ms = sum(s["ms"] for s in dom)
@@ -173,9 +173,10 @@ def main():
             "roofline": {
                 "bound": "mfma", "kernel": dom_kernel + " (v_mfma_f32_32x32x2_f32)",
                 "algorithm": "winograd F(2x2,3x3): achieved counts ALGORITHMIC (direct-convolution) FLOPs, the MFMA pipe "
-                             "executes 1/2.25 of them" if dom_kernel == "conv3x3_wino" else "direct implicit GEMM",
+                             "executes 1/2.25 of them" if dom_kernel.startswith("conv3x3_wino") else "direct implicit GEMM",
                 "achieved": achieved, "peak": FP32_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": achieved / FP32_PEAK_TFLOPS,
-                "traffic": pmc_traffic("miunet::conv3x3_wino_f32<2, 2>" if dom_kernel == "conv3x3_wino" else "miunet::conv_mfma_f32<9, 8, 64>"),
+                "traffic": pmc_traffic({"conv3x3_wino": "miunet::conv3x3_wino_f32<*>", "conv3x3_wino16": "miunet::conv3x3_wino16_f32"}.get(
+                    dom_kernel, "miunet::conv_mfma_f32<9, 8, 64, 16, false>")),
                 "launches": len(dom), "avg_launch_ms": dom_ms / max(1, len(dom)),
                 "avg_launch_gflop": dom_flops / max(1, len(dom)) / 1e9,
                 "share_of_device_time": dom_ms / all_ms if all_ms else None,

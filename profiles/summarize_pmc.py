@@ -20,6 +20,12 @@ def agg(path, counter):
 
 
 f, w = agg(sys.argv[1], "FETCH_SIZE"), agg(sys.argv[2], "WRITE_SIZE")
+# kernel families: template instantiations of one kernel are also summed into "<name>" without its <...> arguments
+for d in (f, w):
+    for k in list(d):
+        fam = k.split("<")[0]
+        if fam != k:
+            d.setdefault(fam + "<*>", []).extend(d[k])
 out = {}
 for k in f:
     if k not in w:

@@ -26,7 +26,7 @@ def _tol(ref):
     (3, 4, 4, 128, 256),       # deep-layer shape
     (1, 2, 2, 1024, 64),       # bottleneck of a 32x32 input: K = 9216
 ])
-@pytest.mark.parametrize("op", ["conv3x3", "conv3x3_wino"])
+@pytest.mark.parametrize("op", ["conv3x3", "conv3x3_wino", "conv3x3_wino16"])
 def test_conv3x3_mfma(B, H, W, Cin, Cout, op):
     r = _rng(B * 1000 + H * 100 + W + Cin + Cout)
     x = r.standard_normal((B, H, W, Cin), dtype=np.float32)
@@ -71,7 +71,8 @@ def test_conv3x3_exact_integers_and_asymmetric_taps():
         assert np.count_nonzero(got) == np.count_nonzero(want)
 
 
-def test_conv3x3_wino_exact_on_even_integers_and_tap_orientation():
+@pytest.mark.parametrize("op", ["conv3x3_wino", "conv3x3_wino16"])
+def test_conv3x3_wino_exact_on_even_integers_and_tap_orientation(op):
     # Winograd's G has halves: with weights that are multiples of 4 and small-integer inputs every intermediate is an
     # exactly representable integer, so the result must equal the direct sum bit for bit; single-tap weights check the
     # orientation of the transforms (a transposed G or B would mirror or swap taps).
@@ -79,12 +80,12 @@ def test_conv3x3_wino_exact_on_even_integers_and_tap_orientation():
     B, H, W, Cin, Cout = 2, 11, 19, 24, 64
     x = r.integers(-4, 5, (B, H, W, Cin)).astype(np.float32)
     w = (4 * r.integers(-3, 4, (Cout, Cin, 3, 3))).astype(np.float32)
-    got = binding.layer_debug("conv3x3_wino", x, w)
+    got = binding.layer_debug(op, x, w)
     assert np.array_equal(got, orc.conv3x3(x, w))
     for (ky, kx, ci, co) in [(0, 2, 5, 7), (2, 0, 23, 63), (1, 1, 0, 0), (0, 0, 17, 33), (2, 2, 9, 40), (1, 0, 3, 3)]:
         w = np.zeros((Cout, Cin, 3, 3), np.float32)
         w[co, ci, ky, kx] = 4.0
-        got = binding.layer_debug("conv3x3_wino", x, w)
+        got = binding.layer_debug(op, x, w)
         assert np.array_equal(got, orc.conv3x3(x, w))
         assert np.count_nonzero(got[..., [c for c in range(Cout) if c != co]]) == 0
 

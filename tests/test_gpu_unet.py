@@ -33,7 +33,7 @@ def orc_argmax_batch(logits):
     return np.stack([orc.argmax_planar(l) for l in logits])
 
 
-@pytest.mark.parametrize("algo", ["direct", "winograd"])
+@pytest.mark.parametrize("algo", ["direct", "winograd", "winograd16"])
 @pytest.mark.parametrize("name", ["unet_b64_l4_64", "unet_b64_l4_48x80", "unet_b16_l3_40x24", "unet_b32_l5_c3_64"])
 def test_against_golden(golden_dir, name, algo):
     spec, blob, imgs, want = load_case(os.path.join(golden_dir, name + ".npz"))
@@ -45,7 +45,7 @@ def test_against_golden(golden_dir, name, algo):
     assert flips == 0
 
 
-@pytest.mark.parametrize("algo", ["direct", "winograd"])
+@pytest.mark.parametrize("algo", ["direct", "winograd", "winograd16"])
 def test_against_oracle_128_batch_and_microbatching(algo):
     spec = UNetSpec()
     blob = pack_weights(spec, synth.make_weights(spec, 4321))
@@ -63,7 +63,7 @@ def test_against_oracle_128_batch_and_microbatching(algo):
         assert np.array_equal(l1[0], labels[3]) and np.array_equal(g1[0], logits[3])
 
 
-@pytest.mark.parametrize("algo", ["direct", "winograd"])
+@pytest.mark.parametrize("algo", ["direct", "winograd", "winograd16"])
 def test_full_size_512_one_image_vs_oracle_and_batch16_properties(algo):
     """configs[1] of BASELINE.json: batch 16 at 512x512.  The oracle checks one image in full; the other 15 are
     covered by size-independent properties: batch independence (bit-identical to the single-image run), and
@@ -104,7 +104,7 @@ def test_error_paths():
         binding.Engine(100, 64)                                                      # not a multiple of 2^levels
 
 
-@pytest.mark.parametrize("algo", ["direct", "winograd"])
+@pytest.mark.parametrize("algo", ["direct", "winograd", "winograd16"])
 def test_fused_pooling_is_bit_identical_to_the_pool_kernel(algo, monkeypatch):
     """The conv epilogues write the 2x2-max-pooled tensor themselves; MIUNET_FUSE_POOL=0 runs the stand-alone pooling
     kernel instead.  max and (+shift, ReLU) commute exactly, so logits must agree bit for bit."""

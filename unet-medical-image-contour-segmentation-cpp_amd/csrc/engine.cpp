@@ -56,7 +56,7 @@ struct mi_unet {
     hipStream_t own_stream = nullptr;
     hipStream_t stream = nullptr;
     bool weights_loaded = false;
-    bool wino = false;              // conv3x3 algorithm: false = direct implicit GEMM, true = Winograd F(2x2,3x3)
+    int algo = MI_UNET_CONV_DIRECT; // resolved conv3x3 algorithm (MI_UNET_CONV_DIRECT / _WINOGRAD / _WINOGRAD16)
     bool fuse_pool = true;          // MIUNET_FUSE_POOL=0 keeps the stand-alone pooling kernel (A/B and parity checks)
     // device memory
     float *d_weights = nullptr;     // one blob: every packed tensor (single allocation -> one broadcast / one free)
@@ -108,6 +108,20 @@ void pack_wino(const float *w, const double *scale, int cin, int cout, float *ds
         }
 }
 
+// same U, packed for conv3x3_wino16_f32: [Cin/8][8 position pairs][CoutPad][16], element 4*(k/2) + 2*(pos&1) + (k&1)
+void pack_wino16(const float *w, const double *scale, int cin, int cout, float *dst, size_t cpad)
+{
+    for (int co = 0; co < cout; ++co)
+        for (int ci = 0; ci < cin; ++ci) {
+            double g[9], u[16];
+            for (int t = 0; t < 9; ++t) g[t] = (double)w[((size_t)co * cin + ci) * 9 + t] * (scale ? scale[co] : 1.0);
+            wino_filter_transform(g, u);
+            const int k = ci % WINO_KC;
+            for (int p = 0; p < 16; ++p)
+                dst[(((size_t)(ci / WINO_KC) * 8 + p / 2) * cpad + co) * 16 + (k >> 1) * 4 + (p & 1) * 2 + (k & 1)] = (float)u[p];
+        }
+}
+
 struct HostWeights {
     std::vector<float> blob;                    // packed, device layout
     struct Off { size_t w, shift; };
@@ -117,7 +131,7 @@ struct HostWeights {
 };
 
 // parse "MIUNETW1" (miunet/spec.py), fold BN, repack
-int build_host_weights(const mi_unet_config &cfg, bool wino, const void *blob, size_t len, HostWeights &hw)
+int build_host_weights(const mi_unet_config &cfg, int algo, const void *blob, size_t len, HostWeights &hw)
 {
     const unsigned char *p = static_cast<const unsigned char *>(blob);
     if (len < 36 || memcmp(p, "MIUNETW1", 8) != 0) return fail(MI_UNET_EFILE, "weight blob: bad magic (want MIUNETW1)");
@@ -163,11 +177,12 @@ int build_host_weights(const mi_unet_config &cfg, bool wino, const void *blob, s
                 for (int ci = 0; ci < cin; ++ci)
                     for (int t = 0; t < 9; ++t)
                         out[off.w + ((size_t)t * cin + ci) * cout + co] = (float)((double)w[((size_t)co * cin + ci) * 9 + t] * sc[co]);
-        } else if (wino) {                       // Winograd layout: [chunk8][pos][n (padded)][8], U = G g G^T
+        } else if (algo != MI_UNET_CONV_DIRECT) {  // Winograd layouts (same size): U = G g G^T
             const int nch = (cin + WINO_KC - 1) / WINO_KC;
             const size_t cpad = round_up(cout, NPAD);
             off.w = alloc((size_t)nch * 16 * cpad * WINO_KC);
-            pack_wino(w, sc.data(), cin, cout, &out[off.w], cpad);
+            if (algo == MI_UNET_CONV_WINOGRAD16) pack_wino16(w, sc.data(), cin, cout, &out[off.w], cpad);
+            else pack_wino(w, sc.data(), cin, cout, &out[off.w], cpad);
         } else {                                 // MFMA layout: [chunk][tap][n (padded)][KC]
             const int nch = (cin + KC - 1) / KC;
             const size_t cpad = round_up(cout, NPAD);
@@ -330,9 +345,10 @@ int run_microbatch(mi_unet *h, const uint8_t *d_imgs, int B, uint8_t *d_labels, 
             e = launch_conv3x3_first(d_imgs, h->d_lut, st.w, st.shift, st.dst, B, st.H, st.W, st.C, st.Cout, st.ld, s);
             break;
         case Step::CONV: {
-            kname = h->wino ? "conv3x3_wino" : "conv3x3_mfma";
             ConvArgs a = st.a; a.B = B;
-            e = h->wino ? launch_conv3x3_wino(a, s) : launch_conv3x3_mfma(a, s);
+            if (h->algo == MI_UNET_CONV_WINOGRAD16) { kname = "conv3x3_wino16"; e = launch_conv3x3_wino16(a, s); }
+            else if (h->algo == MI_UNET_CONV_WINOGRAD) { kname = "conv3x3_wino"; e = launch_conv3x3_wino(a, s); }
+            else { kname = "conv3x3_mfma"; e = launch_conv3x3_mfma(a, s); }
             break;
         }
         case Step::CONVT: {
@@ -405,7 +421,8 @@ int mi_unet_create(const mi_unet_config *cfg, mi_unet_t **out)
         return fail(MI_UNET_EARG, "base must be a power of two in 16..256");
     if (cfg->classes < 2 || cfg->classes > 6) return fail(MI_UNET_EARG, "classes must be in 2..6");
     if (cfg->max_batch < 1) return fail(MI_UNET_EARG, "max_batch must be >= 1");
-    if (cfg->conv_algo < 0 || cfg->conv_algo > 2) return fail(MI_UNET_EARG, "conv_algo must be 0 (auto), 1 (direct) or 2 (winograd)");
+    if (cfg->conv_algo < 0 || cfg->conv_algo > 3)
+        return fail(MI_UNET_EARG, "conv_algo must be 0 (auto), 1 (direct), 2 (winograd) or 3 (winograd16)");
     int ndev = mi_unet_device_count();
     if (ndev <= 0) return fail(MI_UNET_ENODEVICE, "no HIP device visible: libmiunet has no CPU fallback");
     if (cfg->device < 0 || cfg->device >= ndev) return fail(MI_UNET_EARG, "device ordinal out of range");
@@ -420,9 +437,10 @@ int mi_unet_create(const mi_unet_config *cfg, mi_unet_t **out)
             const char *env = getenv("MIUNET_CONV_ALGO");
             if (env && !strcmp(env, "direct")) algo = MI_UNET_CONV_DIRECT;
             else if (env && !strcmp(env, "winograd")) algo = MI_UNET_CONV_WINOGRAD;
+            else if (env && !strcmp(env, "winograd16")) algo = MI_UNET_CONV_WINOGRAD16;
             else algo = MI_UNET_CONV_DEFAULT;
         }
-        h->wino = (algo == MI_UNET_CONV_WINOGRAD);
+        h->algo = algo;
         const char *fp = getenv("MIUNET_FUSE_POOL");
         h->fuse_pool = !(fp && !strcmp(fp, "0"));
     }
@@ -461,7 +479,7 @@ int mi_unet_load_weights_from_memory(mi_unet_t *h, const void *blob, size_t len)
     if (int rc = check_handle(h, false)) return rc;
     if (!blob) return fail(MI_UNET_EARG, "null weight blob");
     HostWeights hw;
-    if (int rc = build_host_weights(h->cfg, h->wino, blob, len, hw)) return rc;
+    if (int rc = build_host_weights(h->cfg, h->algo, blob, len, hw)) return rc;
     HIP_TRY(hipSetDevice(h->cfg.device));
     if (h->d_weights) { HIP_TRY(hipFree(h->d_weights)); h->d_weights = nullptr; }
     h->weight_floats = hw.blob.size();
@@ -587,7 +605,7 @@ int mi_unet_layer_debug(int device, const char *op, const float *in, int B, int 
     std::vector<float> wpk, bias;
     size_t out_n = 0;
     ConvArgs a{};
-    if (o == "conv3x3_wino") {
+    if (o == "conv3x3_wino" || o == "conv3x3_wino16") {
         if (!w || Cout <= 0 || Cin % 4) return fail(MI_UNET_EARG, "layer_debug: conv needs weights and Cin % 4 == 0");
         const int nch = (Cin + WINO_KC - 1) / WINO_KC;
         const size_t npad = round_up((size_t)Cout, NPAD);
@@ -595,7 +613,8 @@ int mi_unet_layer_debug(int device, const char *op, const float *in, int B, int 
         bias.assign(Cout, 0.f);
         std::vector<double> sc(Cout, 1.0);
         for (int co = 0; co < Cout; ++co) { bias[co] = shift ? shift[co] : 0.f; if (scale) sc[co] = scale[co]; }
-        pack_wino(w, sc.data(), Cin, Cout, wpk.data(), npad);
+        if (o == "conv3x3_wino16") pack_wino16(w, sc.data(), Cin, Cout, wpk.data(), npad);
+        else pack_wino(w, sc.data(), Cin, Cout, wpk.data(), npad);
         out_n = (size_t)B * H * W * Cout;
         a.B = B; a.H = H; a.W = W; a.Cin = Cin; a.ldc = Cin; a.Cout = Cout; a.CoutPad = (int)npad; a.ldo = Cout; a.co_off = 0;
         a.relu = relu;
@@ -643,7 +662,8 @@ int mi_unet_layer_debug(int device, const char *op, const float *in, int B, int 
         DBG_TRY(hipMemcpy(d_b, bias.data(), sizeof(float) * bias.size(), hipMemcpyHostToDevice));
         a.in = d_in; a.wpk = d_w; a.bias = d_b; a.out = d_out;
         DBG_TRY(o == "conv3x3" ? launch_conv3x3_mfma(a, nullptr)
-                : o == "conv3x3_wino" ? launch_conv3x3_wino(a, nullptr) : launch_convT2x2_mfma(a, nullptr));
+                : o == "conv3x3_wino" ? launch_conv3x3_wino(a, nullptr)
+                : o == "conv3x3_wino16" ? launch_conv3x3_wino16(a, nullptr) : launch_convT2x2_mfma(a, nullptr));
     } else {
         DBG_TRY(launch_maxpool2x2(d_in, Cin, d_out, B, H, W, Cin, nullptr));
     }

@@ -37,6 +37,9 @@ hipError_t launch_conv3x3_mfma(const ConvArgs &a, hipStream_t s);
 constexpr int WINO_KC = 8;
 constexpr int WINO_SC = 32;       // input channels per raw-patch staging step (4 K-chunks: one whole 128-byte line per pixel)
 hipError_t launch_conv3x3_wino(const ConvArgs &a, hipStream_t s);
+// 8-wave / two-waves-per-SIMD re-tiling of the same algorithm on v_mfma_f32_16x16x4_f32; a.wpk is packed as
+// [Cin/8][8 position pairs][CoutPad][16] with element 4*kq + 2*(pos & 1) + s = U_pos[k = 2*kq + s].
+hipError_t launch_conv3x3_wino16(const ConvArgs &a, hipStream_t s);
 hipError_t launch_convT2x2_mfma(const ConvArgs &a, hipStream_t s);
 
 // First layer: u8 image -> (LUT /255) -> conv3x3 (Cin = 1..4) + shift + ReLU.  w is [9][Cin][Cout] (BN scale folded).

@@ -24,28 +24,31 @@
 // 16-byte-per-lane NHWC access.
 #include "kernels.h"
 
+#include <cstdlib>
+
 namespace miunet {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
-constexpr int LDS_ROW = KC + 4;   // padded floats per (pixel | cout) row in LDS
-
-template <int TAPS, int TH>
+// KCT = input channels staged per K-chunk (a multiple of KC = 16, the granule of the packed weights)
+template <int TAPS, int TH, int KCT>
 struct TileGeom {
+    static constexpr int LDS_ROW = KCT + 4;                   // padded floats per (pixel | cout) row in LDS
     static constexpr int HALO = (TAPS == 9) ? 1 : 0;
     static constexpr int PW = 32 + 2 * HALO;
     static constexpr int PH = TH + 2 * HALO;
     static constexpr int NPIX = PW * PH;
-    static constexpr int NA4 = NPIX * (KC / 4);               // float4 pieces of the A patch
+    static constexpr int QPP = KCT / 4;                       // float4 pieces per pixel
+    static constexpr int NA4 = NPIX * QPP;                    // float4 pieces of the A patch
     static constexpr int A_ITERS = (NA4 + 255) / 256;
     static constexpr int A_FLOATS = NPIX * LDS_ROW;
 };
 
-template <int TAPS, int TH, int BN>
+template <int TAPS, int TH, int BN, int KCT>
 constexpr size_t conv_lds_bytes()
 {
-    return sizeof(float) * (size_t)(TileGeom<TAPS, TH>::A_FLOATS + TAPS * BN * LDS_ROW);
+    return sizeof(float) * (size_t)(TileGeom<TAPS, TH, KCT>::A_FLOATS + TAPS * BN * TileGeom<TAPS, TH, KCT>::LDS_ROW);
 }
 
 // bijective XCD remap (cdna_hip_programming.md §5): blocks b and b+8 share an XCD; give XCD x the logical range
@@ -57,16 +60,21 @@ __device__ __forceinline__ int xcd_remap(int bid, int nwg)
     return start + (bid >> 3);
 }
 
-template <int TAPS, int TH, int BN>
+// NFAST: walk the n-tiles fastest (the workgroups that share an input tile run together on one XCD).  Used for the
+// transposed conv, whose K is short and whose N = 4*Cout is wide: the input tile is then fetched from HBM once and
+// re-read from L2 by its 8..32 column tiles, instead of once per column tile.
+template <int TAPS, int TH, int BN, int KCT, bool NFAST>
 __global__ __launch_bounds__(256, 2) void conv_mfma_f32(const ConvArgs a, const int tiles_x, const int tiles_y,
                                                         const int m_tiles, const int nwg)
 {
-    using G = TileGeom<TAPS, TH>;
+    using G = TileGeom<TAPS, TH, KCT>;
+    constexpr int LDS_ROW = G::LDS_ROW;
     constexpr int MT = TH / 4;            // 32-row MFMA tiles per wave (one image row each)
     constexpr int NT = BN / 32;           // 32-col MFMA tiles per wave
     constexpr int B_PARTS = BN / 64;      // 64-cout slabs per tap staged by 256 threads x float4
-    constexpr int B_ITERS = TAPS * B_PARTS;
-    static_assert(TH % 4 == 0 && BN % 64 == 0, "tile shape");
+    constexpr int SUBS = KCT / KC;        // 16-channel weight granules per K-chunk
+    constexpr int B_ITERS = TAPS * B_PARTS * SUBS;
+    static_assert(TH % 4 == 0 && BN % 64 == 0 && KCT % KC == 0, "tile shape");
 
     extern __shared__ __attribute__((aligned(16))) float lds[];
     float *const As = lds;
@@ -80,8 +88,9 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_f32(const ConvArgs a, const 
 
     // ---- which tile
     const int L = xcd_remap(blockIdx.x, nwg);
-    const int n_tile = L / m_tiles;
-    int m = L - n_tile * m_tiles;
+    const int n_tiles = nwg / m_tiles;
+    const int n_tile = NFAST ? L % n_tiles : L / m_tiles;
+    int m = NFAST ? L / n_tiles : L - n_tile * m_tiles;
     const int tx = m % tiles_x; m /= tiles_x;
     const int ty = m % tiles_y;
     const int b = m / tiles_y;
@@ -95,7 +104,7 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_f32(const ConvArgs a, const 
 #pragma unroll
     for (int s = 0; s < G::A_ITERS; ++s) {
         const int e = tid + 256 * s;
-        const int pix = e >> 2, q = e & 3;
+        const int pix = e / G::QPP, q = e % G::QPP;
         const int py = pix / G::PW, px = pix - py * G::PW;
         const int gy = y0 - G::HALO + py, gx = x0 - G::HALO + px;
         const bool live = e < G::NA4;
@@ -110,20 +119,25 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_f32(const ConvArgs a, const 
     f32x4 a_reg[G::A_ITERS];
     f32x4 b_reg[B_ITERS];
 
+    const int nsub16 = (a.Cin + KC - 1) / KC;     // 16-channel granules the packed weights hold
     auto load_chunk = [&](int chunk) {
-        const int c0 = chunk * KC;
+        const int c0 = chunk * KCT;
 #pragma unroll
         for (int s = 0; s < G::A_ITERS; ++s) {
-            const int q4 = 4 * ((tid + 256 * s) & 3);
+            const int q4 = 4 * ((tid + 256 * s) % G::QPP);
             f32x4 v = { 0.f, 0.f, 0.f, 0.f };
             if (a_goff[s] >= 0 && c0 + q4 < a.Cin) v = *reinterpret_cast<const f32x4 *>(in_img + a_goff[s] + c0);
             a_reg[s] = v;
         }
 #pragma unroll
         for (int it = 0; it < B_ITERS; ++it) {
-            const int tap = it / B_PARTS, part = it % B_PARTS;
-            b_reg[it] = *reinterpret_cast<const f32x4 *>(
-                w_base + (((size_t)chunk * TAPS + tap) * a.CoutPad + part * 64) * KC);
+            const int sub = it % SUBS, tp = it / SUBS;
+            const int tap = tp / B_PARTS, part = tp % B_PARTS;
+            const int c16 = chunk * SUBS + sub;
+            f32x4 v = { 0.f, 0.f, 0.f, 0.f };
+            if (SUBS == 1 || c16 < nsub16)
+                v = *reinterpret_cast<const f32x4 *>(w_base + (((size_t)c16 * TAPS + tap) * a.CoutPad + part * 64) * KC);
+            b_reg[it] = v;
         }
     };
     auto store_chunk = [&]() {
@@ -132,8 +146,9 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_f32(const ConvArgs a, const 
             if (a_loff[s] >= 0) *reinterpret_cast<f32x4 *>(As + a_loff[s]) = a_reg[s];
 #pragma unroll
         for (int it = 0; it < B_ITERS; ++it) {
-            const int tap = it / B_PARTS, part = it % B_PARTS;
-            *reinterpret_cast<f32x4 *>(Bs + (tap * BN + part * 64) * LDS_ROW + b_loff) = b_reg[it];
+            const int sub = it % SUBS, tp = it / SUBS;
+            const int tap = tp / B_PARTS, part = tp % B_PARTS;
+            *reinterpret_cast<f32x4 *>(Bs + (tap * BN + part * 64) * LDS_ROW + KC * sub + b_loff) = b_reg[it];
         }
     };
 
@@ -148,7 +163,7 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_f32(const ConvArgs a, const 
     const float *a_frag = As + ((wave * MT) * G::PW + li) * LDS_ROW + 4 * lh;
     const float *b_frag = Bs + li * LDS_ROW + 4 * lh;
 
-    const int nchunks = (a.Cin + KC - 1) / KC;
+    const int nchunks = (a.Cin + KCT - 1) / KCT;
     load_chunk(0);
     store_chunk();
     __syncthreads();
@@ -161,7 +176,7 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_f32(const ConvArgs a, const 
         for (int tap = 0; tap < TAPS; ++tap) {
             const int dy = (TAPS == 9) ? tap / 3 : 0, dx = (TAPS == 9) ? tap % 3 : 0;
 #pragma unroll
-            for (int g = 0; g < KC / 8; ++g) {
+            for (int g = 0; g < KCT / 8; ++g) {
                 f32x4 af[MT], bf[NT];
 #pragma unroll
                 for (int i = 0; i < MT; ++i)
@@ -232,7 +247,7 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_f32(const ConvArgs a, const 
     }
 }
 
-template <int TAPS, int TH, int BN>
+template <int TAPS, int TH, int BN, int KCT, bool NFAST>
 static hipError_t launch_conv_cfg(const ConvArgs &a, hipStream_t s)
 {
     const int n_total = (TAPS == 9) ? a.Cout : 4 * a.Cout;
@@ -240,9 +255,9 @@ static hipError_t launch_conv_cfg(const ConvArgs &a, hipStream_t s)
     const int m_tiles = tiles_x * tiles_y * a.B;
     const int n_tiles = (n_total + BN - 1) / BN;
     const int nwg = m_tiles * n_tiles;
-    constexpr size_t lds = conv_lds_bytes<TAPS, TH, BN>();
+    constexpr size_t lds = conv_lds_bytes<TAPS, TH, BN, KCT>();
     static bool attr_set = false;
-    auto kern = conv_mfma_f32<TAPS, TH, BN>;
+    auto kern = conv_mfma_f32<TAPS, TH, BN, KCT, NFAST>;
     if (!attr_set) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -256,14 +271,21 @@ static hipError_t launch_conv_cfg(const ConvArgs &a, hipStream_t s)
 hipError_t launch_conv3x3_mfma(const ConvArgs &a, hipStream_t s)
 {
     if (a.Cin % 4 || a.ldc % 4 || a.CoutPad % NPAD) return hipErrorInvalidValue;
-    return launch_conv_cfg<9, 8, 64>(a, s);
+    return launch_conv_cfg<9, 8, 64, 16, false>(a, s);
 }
 
 hipError_t launch_convT2x2_mfma(const ConvArgs &a, hipStream_t s)
 {
     if (a.Cin % 4 || a.ldc % 4 || a.CoutPad % NPAD) return hipErrorInvalidValue;
     // a GEMM column tile must not straddle two (dy,dx) taps unless masked per lane: co/kidx are per lane, so any Cout works
-    return launch_conv_cfg<1, 8, 64>(a, s);
+    static int cfg = -1;
+    if (cfg < 0) { const char *e = getenv("MIUNET_CONVT_CFG"); cfg = e ? atoi(e) : 1; }
+    switch (cfg) {
+    case 0: return launch_conv_cfg<1, 8, 64, 16, false>(a, s);
+    case 1: return launch_conv_cfg<1, 8, 64, 16, true>(a, s);
+    case 2: return launch_conv_cfg<1, 8, 64, 32, false>(a, s);
+    default: return launch_conv_cfg<1, 8, 64, 32, true>(a, s);
+    }
 }
 
 // --------------------------------------------------------------------------------------------------------------------
@@ -360,52 +382,68 @@ __global__ __launch_bounds__(256, 1) void conv3x3_wino_f32(const ConvArgs a, con
             if (raw_loff[s] >= 0) *reinterpret_cast<f32x4 *>(Raw + raw_loff[s]) = raw_reg[s];
     };
 
-    // ---- stage 2: V = B^T d B for one K-chunk (8 channels), thread = (tile, channel quad, half of xi).
-    // half 0 builds V rows xi = 0,1 from patch rows (0,1,2); half 1 builds xi = 2,3 from patch rows (2,3,1).  With the
-    // rows taken in that order both halves use the SAME formulas
-    //     ta = l0 - l2          (xi 0: d0 - d2        | xi 2: d2 - d1)
-    //     tb = sgn * l1 + l2    (xi 1: d1 + d2        | xi 3: d1 - d3,  sgn = -1)
-    // so there is no per-lane select (multiplying by +-1 is exact).
-    const int t_tile = tid >> 2, t_quad = tid & 1, t_half = (tid >> 1) & 1;
-    const bool t_live = t_tile < TMB;
-    const float t_sgn = t_half ? -1.f : 1.f;
-    int p_loff[3];                            // float offset in Raw of its patch row r, column 0, channel 4*quad
+    // ---- stage 2: V = B^T d B for one K-chunk (8 channels).  256 threads share 32*WM tiles x 2 channel quads:
+    //   WM = 2: thread = (tile, quad, HALF of xi): half 0 builds xi = 0,1 from patch rows (0,1,2), half 1 builds xi = 2,3
+    //           from rows (2,3,1); with the rows in that order both halves use  ta = l0 - l2,  tb = sgn*l1 + l2.
+    //   WM = 1: thread = (tile, quad, ONE xi): row xi of B^T d is  la + sgn*lb  with (la, lb, sgn) =
+    //           xi 0: (d0, d2, -) | xi 1: (d1, d2, +) | xi 2: (d2, d1, -) | xi 3: (d1, d3, -).
+    // Either way there is no per-lane select (multiplying by +-1 is exact) and every thread has work.
+    constexpr bool XI_MODE = (WM == 1);
+    constexpr int NROWS = XI_MODE ? 2 : 3;        // patch rows a thread reads
+    constexpr int NXI = XI_MODE ? 1 : 2;          // xi rows a thread produces
+    constexpr int NPIECES = 4 + 4 * NXI;          // transform pieces threaded between the MFMAs
+    const int t_tile = XI_MODE ? (tid >> 3) : (tid >> 2);
+    const int t_quad = tid & 1;
+    const int t_sel = XI_MODE ? ((tid >> 1) & 3) : ((tid >> 1) & 1);      // xi (WM = 1) or half (WM = 2)
+    const float t_sgn = XI_MODE ? (t_sel == 1 ? 1.f : -1.f) : (t_sel ? -1.f : 1.f);
+    int p_loff[NROWS];                        // float offset in Raw of its patch row r, column 0, channel 4*quad
     {
         const int i = t_tile & 31, mt = t_tile >> 5;
         const int pr0 = 2 * ((i >> 3) + 4 * mt), pc0 = 2 * (i & 7);
 #pragma unroll
-        for (int r = 0; r < 3; ++r) {
-            const int prow = t_half ? (r == 0 ? 2 : r == 1 ? 3 : 1) : r;
-            p_loff[r] = t_live ? ((pr0 + prow) * 18 + pc0) * RAW_P + 4 * t_quad : 0;
+        for (int r = 0; r < NROWS; ++r) {
+            int prow;
+            if (XI_MODE) prow = r == 0 ? (t_sel == 0 ? 0 : t_sel == 2 ? 2 : 1) : (t_sel == 0 ? 2 : t_sel == 1 ? 2 : t_sel == 2 ? 1 : 3);
+            else prow = t_sel ? (r == 0 ? 2 : r == 1 ? 3 : 1) : r;
+            p_loff[r] = ((pr0 + prow) * 18 + pc0) * RAW_P + 4 * t_quad;
         }
     }
-    f32x4 patch[3][4];
+    f32x4 patch[NROWS][4];
     auto patch_read = [&](int r, int chunk_in_super) {       // one patch row (4 pixels) of this thread, LDS -> registers
 #pragma unroll
         for (int c = 0; c < 4; ++c)
             patch[r][c] = *reinterpret_cast<const f32x4 *>(Raw + p_loff[r] + c * RAW_P + chunk_in_super * WINO_KC);
     };
-    float *const v_wr = Vs + (t_half * 8 * TMB + t_tile) * VROW + 4 * t_quad;   // + buf*VBUF + (xi_local*4 + nu)*TMB*VROW
-    // The transform is cut into 12 pieces so it can be threaded between MFMAs: pieces 0-3 = B^T d for patch column k,
-    // pieces 4-11 = one V position each (.. B, then its 16-byte store).
-    f32x4 t_rows[2][4];
+    float *const v_wr = Vs + ((XI_MODE ? t_sel * 4 : t_sel * 8) * TMB + t_tile) * VROW + 4 * t_quad;   // + buf*VBUF + (xi_local*4 + nu)*TMB*VROW
+    // pieces 0-3 = B^T d for patch column k, pieces 4.. = one V position each (.. B, then its 16-byte store)
+    f32x4 t_rows[NXI][4];
     auto transform_piece = [&](int k, int buf) {
         if (k < 4) {
-            t_rows[0][k] = patch[0][k] - patch[2][k];
-            t_rows[1][k] = t_sgn * patch[1][k] + patch[2][k];
+            if constexpr (XI_MODE) {
+                t_rows[0][k] = t_sgn * patch[1][k] + patch[0][k];
+            } else {
+                t_rows[0][k] = patch[0][k] - patch[2][k];
+                t_rows[1][k] = t_sgn * patch[1][k] + patch[2][k];
+            }
         } else {
             const int x = (k - 4) >> 2, nu = (k - 4) & 3;
             const f32x4 *t = t_rows[x];
             const f32x4 v = nu == 0 ? t[0] - t[2] : nu == 1 ? t[1] + t[2] : nu == 2 ? t[2] - t[1] : t[1] - t[3];
-            if (TMB * 4 >= 256 || t_live)     // WM = 2: every thread owns a tile, no branch
-                *reinterpret_cast<f32x4 *>(v_wr + buf * VBUF + (x * 4 + nu) * TMB * VROW) = v;
+            *reinterpret_cast<f32x4 *>(v_wr + buf * VBUF + (x * 4 + nu) * TMB * VROW) = v;
         }
     };
 
     // ---- MFMA role: wave (wm, wn), all 16 positions
+    // U fragments: buffer loads whose per-position / per-chunk displacement is a SCALAR offset (no per-lane address
+    // arithmetic in the loop); the descriptor covers this layer's whole packed U (< 4 GB).
     const int ncol = n0 + 32 * wn + li;
-    const size_t u_pos_stride = (size_t)a.CoutPad * WINO_KC;
-    const float *u_lane = a.wpk + (size_t)ncol * WINO_KC + 4 * lh;           // + (chunk*16 + pos) * u_pos_stride
+    const unsigned u_pos_bytes = (unsigned)a.CoutPad * WINO_KC * 4;
+    const unsigned u_voff = (unsigned)(ncol * WINO_KC + 4 * lh) * 4;
+    const __amdgpu_buffer_rsrc_t u_rsrc = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<float *>(a.wpk), 0, (int)(((a.Cin + WINO_KC - 1) / WINO_KC) * 16 * u_pos_bytes), 0x00020000);
+    auto u_load = [&](int chunk, int p) {
+        return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(u_rsrc, u_voff, (chunk * 16 + p) * u_pos_bytes, 0));
+    };
     const float *v_rd = Vs + (32 * wm + li) * VROW + 4 * lh;                 // + buf*VBUF + pos*TMB*VROW
 
     f32x16 acc[16];
@@ -418,15 +456,15 @@ __global__ __launch_bounds__(256, 1) void conv3x3_wino_f32(const ConvArgs a, con
     const int nsuper = (a.Cin + WINO_SC - 1) / WINO_SC;
     f32x4 u[16];
 #pragma unroll
-    for (int p = 0; p < 16; ++p) u[p] = *reinterpret_cast<const f32x4 *>(u_lane + (size_t)p * u_pos_stride);
+    for (int p = 0; p < 16; ++p) u[p] = u_load(0, p);
     // prologue: raw patch of super-chunk 0 -> LDS, V of chunk 0
     raw_load(0);
     raw_store();
     __syncthreads();
 #pragma unroll
-    for (int r = 0; r < 3; ++r) patch_read(r, 0);
+    for (int r = 0; r < NROWS; ++r) patch_read(r, 0);
 #pragma unroll
-    for (int k = 0; k < 12; ++k) transform_piece(k, 0);
+    for (int k = 0; k < NPIECES; ++k) transform_piece(k, 0);
     __syncthreads();
 
     // Per K-chunk c (super-chunk S = c / 4, j = c % 4):
@@ -445,26 +483,25 @@ __global__ __launch_bounds__(256, 1) void conv3x3_wino_f32(const ConvArgs a, con
         const int nxt = (chunk + 1 < nchunks) ? chunk + 1 : chunk;       // last iteration re-does itself: straight-line code
         const int nxt_j = nxt & (CPS - 1);
         const float *vb = v_rd + (chunk & 1) * VBUF;
-        const float *un = u_lane + (size_t)nxt * 16 * u_pos_stride;
         const int wbuf = (chunk + 1) & 1;
         f32x4 av = *reinterpret_cast<const f32x4 *>(vb);
 #pragma unroll
         for (int p = 0; p < 16; ++p) {
             f32x4 avn = av;
             if (p + 1 < 16) avn = *reinterpret_cast<const f32x4 *>(vb + (p + 1) * TMB * VROW);   // V fragment one position ahead
-            if (p >= 4 && p < 7) patch_read(p - 4, nxt_j);
+            if (p >= 4 && p < 4 + NROWS) patch_read(p - 4, nxt_j);
             __builtin_amdgcn_sched_barrier(0);        // ... issued BEFORE this position's MFMAs (hipcc would sink them to their use)
             const f32x4 bv = u[p];
 #pragma unroll
             for (int s = 0; s < 4; ++s) {
                 acc[p] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[s], bv[s], acc[p], 0, 0, 0);
                 const int idx = (p - 8) * 4 + s;
-                if (p >= 8 && (idx & 1) == 0 && idx / 2 < 12) {
+                if (p >= 8 && (idx & 1) == 0 && idx / 2 < NPIECES) {
                     transform_piece(idx / 2, wbuf);
                     __builtin_amdgcn_sched_barrier(0);
                 }
             }
-            u[p] = *reinterpret_cast<const f32x4 *>(un + (size_t)p * u_pos_stride);             // refill a full chunk ahead
+            u[p] = u_load(nxt, p);                                                              // refill a full chunk ahead
             av = avn;
             __builtin_amdgcn_sched_barrier(0);
         }
@@ -504,6 +541,230 @@ __global__ __launch_bounds__(256, 1) void conv3x3_wino_f32(const ConvArgs a, con
     }
 }
 
+// --------------------------------------------------------------------------------------------------------------------
+// conv3x3_wino16_f32 -- the same Winograd F(2x2,3x3) algorithm re-tiled for TWO waves per SIMD.
+// The 4-wave kernel above gives each wave a 32x32 MFMA tile for all 16 positions = 256 accumulator registers, which
+// leaves one wave per SIMD: every in-order issue stall (a VMEM issue, an LDS wait, the per-chunk barrier) idles the
+// matrix pipe.  Here a workgroup is 8 waves and each wave owns 32 tiles x 16 output channels on
+// v_mfma_f32_16x16x4_f32 (two 16x16 blocks per position -> 128 accumulator registers), so two waves share a SIMD and
+// cover each other's stalls, while a lane STILL holds all 16 positions of its (tile, channel) pairs: the inverse
+// transform stays in-lane.  Same workgroup tile (64 tiles x 64 channels), same LDS images (raw patch + double-buffered
+// V), same register-streamed U -- packed so that one 16-byte load per lane covers a pair of positions.
+//   MFMA operand maps (16x16x4): A[i = lane & 15][k = lane >> 4], B[k = lane >> 4][j = lane & 15],
+//   C/D col = lane & 15, row = 4 * (lane >> 4) + reg.  Lane group kq = lane >> 4 feeds k = 2*kq + s in step s (K order
+//   inside a chunk is free), so a lane's two k come from one ds_read_b64 / one half of its 16-byte U fragment.
+constexpr int W16_THREADS = 512;
+
+__global__ __launch_bounds__(W16_THREADS, 2) void conv3x3_wino16_f32(const ConvArgs a, const int tiles_x, const int tiles_y,
+                                                                    const int m_tiles, const int nwg)
+{
+    using G = WinoGeom<2, 2>;
+    constexpr int TMB = G::TMB, VROW = G::VROW, VBUF = G::VBUF, RAW_P = G::RAW_P;
+    constexpr int CPS = WINO_SC / WINO_KC;
+    constexpr int RAW_ITERS = (G::RAWPIX * (WINO_SC / 4) + W16_THREADS - 1) / W16_THREADS;
+    typedef float f32x2 __attribute__((ext_vector_type(2)));
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    float *const Vs = lds;
+    float *const Raw = lds + 2 * VBUF;
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 2, wq = wave & 3;          // 32-tile group, 16-channel group
+    const int i16 = lane & 15, kq = lane >> 4;
+
+    const int L = xcd_remap(blockIdx.x, nwg);
+    const int n_tile = L / m_tiles;
+    int m = L - n_tile * m_tiles;
+    const int tx = m % tiles_x; m /= tiles_x;
+    const int ty = m % tiles_y;
+    const int b = m / tiles_y;
+    const int bx0 = tx * 16, by0 = ty * 16, n0 = n_tile * 64;
+    const float *in_img = a.in + (size_t)b * a.H * a.W * a.ldc;
+
+    // ---- raw halo patch, 32 channels at a time (whole 128-byte lines; zero padding through the buffer range check)
+    const __amdgpu_buffer_rsrc_t in_rsrc =
+        __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(in_img), 0, a.H * a.W * a.ldc * 4, 0x00020000);
+    unsigned raw_voff[RAW_ITERS];
+#pragma unroll
+    for (int s = 0; s < RAW_ITERS; ++s) {
+        const int e = tid + W16_THREADS * s;
+        const int pix = e >> 3, q8 = e & 7;
+        const int py = pix / 18, px = pix - py * 18;
+        const int gy = by0 - 1 + py, gx = bx0 - 1 + px;
+        const bool inb = pix < G::RAWPIX && gy >= 0 && gy < a.H && gx >= 0 && gx < a.W;
+        raw_voff[s] = inb ? (unsigned)(((gy * a.W + gx) * a.ldc + 4 * q8) * 4) : 0xFFFFFFFFu;
+    }
+    f32x4 raw_reg[RAW_ITERS];
+    auto raw_load = [&](int super) {
+        const int c0 = super * WINO_SC;
+#pragma unroll
+        for (int s = 0; s < RAW_ITERS; ++s) {
+            const int q8 = (tid + W16_THREADS * s) & 7;
+            const unsigned voff = (c0 + 4 * q8 < a.Cin) ? raw_voff[s] : 0xFFFFFFFFu;
+            raw_reg[s] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(in_rsrc, voff, c0 * 4, 0));
+        }
+    };
+    auto raw_store = [&]() {
+#pragma unroll
+        for (int s = 0; s < RAW_ITERS; ++s) {
+            const int e = tid + W16_THREADS * s;
+            if ((e >> 3) < G::RAWPIX) *reinterpret_cast<f32x4 *>(Raw + (e >> 3) * RAW_P + 4 * (e & 7)) = raw_reg[s];
+        }
+    };
+
+    // ---- input transform role: thread = (tile, channel quad, xi).  Row xi of B^T d is  la + sgn * lb  with
+    //      xi 0: d0 - d2 | xi 1: d1 + d2 | xi 2: d2 - d1 | xi 3: d1 - d3   (one fma per element, no select)
+    const int t_tile = tid >> 3, t_quad = tid & 1, t_xi = (tid >> 1) & 3;
+    const float t_sgn = t_xi == 1 ? 1.f : -1.f;
+    int p_la, p_lb;
+    {
+        const int i = t_tile & 31, mt = t_tile >> 5;
+        const int pr0 = 2 * ((i >> 3) + 4 * mt), pc0 = 2 * (i & 7);
+        const int ra = t_xi == 0 ? 0 : t_xi == 2 ? 2 : 1;
+        const int rb = t_xi == 0 ? 2 : t_xi == 1 ? 2 : t_xi == 2 ? 1 : 3;
+        p_la = ((pr0 + ra) * 18 + pc0) * RAW_P + 4 * t_quad;
+        p_lb = ((pr0 + rb) * 18 + pc0) * RAW_P + 4 * t_quad;
+    }
+    float *const v_wr = Vs + (t_xi * 4 * TMB + t_tile) * VROW + 4 * t_quad;     // + buf*VBUF + nu*TMB*VROW
+    f32x4 pa[4], pb[4], tcol[4];
+    auto xf_read = [&](int c, int cj) {
+        pa[c] = *reinterpret_cast<const f32x4 *>(Raw + p_la + c * RAW_P + cj * WINO_KC);
+        pb[c] = *reinterpret_cast<const f32x4 *>(Raw + p_lb + c * RAW_P + cj * WINO_KC);
+    };
+    auto xf_rows = [&](int c) { tcol[c] = t_sgn * pb[c] + pa[c]; };
+    auto xf_out = [&](int nu, int buf) {
+        const f32x4 v = nu == 0 ? tcol[0] - tcol[2] : nu == 1 ? tcol[1] + tcol[2] : nu == 2 ? tcol[2] - tcol[1] : tcol[1] - tcol[3];
+        *reinterpret_cast<f32x4 *>(v_wr + buf * VBUF + nu * TMB * VROW) = v;
+    };
+
+    // ---- MFMA role
+    const int ncol = n0 + 16 * wq + i16;
+    const size_t u_pp_stride = (size_t)a.CoutPad * 16;                         // floats per position pair
+    const float *u_lane = a.wpk + (size_t)ncol * 16 + 4 * kq;                  // + (chunk*8 + pp) * u_pp_stride
+    const float *v_rd = Vs + (32 * wm + i16) * VROW + 2 * kq;                  // + buf*VBUF + pos*TMB*VROW + mb*16*VROW
+
+    f32x4 acc[16][2];
+#pragma unroll
+    for (int p = 0; p < 16; ++p)
+#pragma unroll
+        for (int mb = 0; mb < 2; ++mb) acc[p][mb] = f32x4{ 0.f, 0.f, 0.f, 0.f };
+
+    const int nchunks = (a.Cin + WINO_KC - 1) / WINO_KC;
+    const int nsuper = (a.Cin + WINO_SC - 1) / WINO_SC;
+    f32x4 u[8];
+#pragma unroll
+    for (int pp = 0; pp < 8; ++pp) u[pp] = *reinterpret_cast<const f32x4 *>(u_lane + (size_t)pp * u_pp_stride);
+    raw_load(0);
+    raw_store();
+    __syncthreads();
+#pragma unroll
+    for (int c = 0; c < 4; ++c) { xf_read(c, 0); xf_rows(c); }
+#pragma unroll
+    for (int nu = 0; nu < 4; ++nu) xf_out(nu, 0);
+    __syncthreads();
+
+    for (int chunk = 0; chunk < nchunks; ++chunk) {
+        const int j = chunk & (CPS - 1), S = chunk / CPS;
+        if (j == 0 && S + 1 < nsuper) raw_load(S + 1);
+        if (j == CPS - 1 && S + 1 < nsuper) {
+            raw_store();
+            __syncthreads();
+        }
+        const int nxt = (chunk + 1 < nchunks) ? chunk + 1 : chunk;
+        const int nxt_j = nxt & (CPS - 1);
+        const float *vb = v_rd + (chunk & 1) * VBUF;
+        const float *un = u_lane + (size_t)nxt * 8 * u_pp_stride;
+        const int wbuf = (chunk + 1) & 1;
+        f32x2 a0 = *reinterpret_cast<const f32x2 *>(vb), a1 = *reinterpret_cast<const f32x2 *>(vb + 16 * VROW);
+#pragma unroll
+        for (int p = 0; p < 16; ++p) {
+            f32x2 n0v = a0, n1v = a1;
+            if (p + 1 < 16) {
+                n0v = *reinterpret_cast<const f32x2 *>(vb + (p + 1) * TMB * VROW);
+                n1v = *reinterpret_cast<const f32x2 *>(vb + (p + 1) * TMB * VROW + 16 * VROW);
+            }
+            // next chunk's input transform, spread over the positions: LDS reads first, then rows, then outputs
+            if (p == 1) xf_read(0, nxt_j);
+            if (p == 2) xf_read(1, nxt_j);
+            if (p == 3) { xf_rows(0); xf_read(2, nxt_j); }
+            if (p == 4) { xf_rows(1); xf_read(3, nxt_j); }
+            if (p == 5) xf_rows(2);
+            if (p == 6) xf_rows(3);
+            if (p >= 8 && p < 12) xf_out(p - 8, wbuf);
+            __builtin_amdgcn_sched_barrier(0);
+            const f32x4 uv = u[p >> 1];
+            const float b0 = (p & 1) ? uv[2] : uv[0], b1 = (p & 1) ? uv[3] : uv[1];
+            acc[p][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0[0], b0, acc[p][0], 0, 0, 0);
+            acc[p][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1[0], b0, acc[p][1], 0, 0, 0);
+            acc[p][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0[1], b1, acc[p][0], 0, 0, 0);
+            acc[p][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1[1], b1, acc[p][1], 0, 0, 0);
+            if (p & 1) u[p >> 1] = *reinterpret_cast<const f32x4 *>(un + (size_t)(p >> 1) * u_pp_stride);   // refill one chunk ahead
+            a0 = n0v; a1 = n1v;
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        __syncthreads();
+    }
+
+    // ---- epilogue: Y = A^T M A in-lane.  Lane = channel, (mb, reg) = tile.
+    const bool n_ok = ncol < a.Cout;
+    const float sh = n_ok ? a.bias[ncol] : 0.f;
+#pragma unroll
+    for (int mb = 0; mb < 2; ++mb)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int i = 16 * mb + 4 * kq + r;
+            const int oy = by0 + 2 * ((i >> 3) + 4 * wm), ox = bx0 + 2 * (i & 7);
+            float s0[4], s1[4];
+#pragma unroll
+            for (int nu = 0; nu < 4; ++nu) {
+                const float m0 = acc[0 + nu][mb][r], m1 = acc[4 + nu][mb][r], m2 = acc[8 + nu][mb][r], m3 = acc[12 + nu][mb][r];
+                s0[nu] = m0 + m1 + m2;
+                s1[nu] = m1 - m2 - m3;
+            }
+            float y[2][2];
+            y[0][0] = s0[0] + s0[1] + s0[2]; y[0][1] = s0[1] - s0[2] - s0[3];
+            y[1][0] = s1[0] + s1[1] + s1[2]; y[1][1] = s1[1] - s1[2] - s1[3];
+            float vmax = -3.402823466e+38f;
+#pragma unroll
+            for (int dy = 0; dy < 2; ++dy)
+#pragma unroll
+                for (int dx = 0; dx < 2; ++dx) {
+                    float v = y[dy][dx] + sh;
+                    if (a.relu) v = v > 0.f ? v : 0.f;
+                    vmax = fmaxf(vmax, v);
+                    if (n_ok && oy + dy < a.H && ox + dx < a.W)
+                        a.out[(((size_t)b * a.H + oy + dy) * a.W + ox + dx) * a.ldo + a.co_off + ncol] = v;
+                }
+            if (a.pool_out != nullptr && n_ok && oy + 1 < a.H && ox + 1 < a.W)
+                a.pool_out[(((size_t)b * (a.H >> 1) + (oy >> 1)) * (a.W >> 1) + (ox >> 1)) * a.pool_ld + ncol] = vmax;
+        }
+}
+
+static hipError_t launch_wino16(const ConvArgs &a, hipStream_t s)
+{
+    const int tiles_x = (a.W + 15) / 16, tiles_y = (a.H + 15) / 16;
+    const int m_tiles = tiles_x * tiles_y * a.B;
+    const int n_tiles = (a.Cout + 63) / 64;
+    const int nwg = m_tiles * n_tiles;
+    constexpr size_t lds = WinoGeom<2, 2>::LDS_BYTES;
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(conv3x3_wino16_f32),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return e;
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(conv3x3_wino16_f32, dim3(nwg), dim3(W16_THREADS), lds, s, a, tiles_x, tiles_y, m_tiles, nwg);
+    return hipGetLastError();
+}
+
+hipError_t launch_conv3x3_wino16(const ConvArgs &a, hipStream_t s)
+{
+    if (a.Cin % 4 || a.ldc % 4 || a.CoutPad % NPAD) return hipErrorInvalidValue;
+    return launch_wino16(a, s);
+}
+
 template <int WM, int WN>
 static hipError_t launch_wino_cfg(const ConvArgs &a, hipStream_t s)
 {
@@ -527,6 +788,8 @@ static hipError_t launch_wino_cfg(const ConvArgs &a, hipStream_t s)
 hipError_t launch_conv3x3_wino(const ConvArgs &a, hipStream_t s)
 {
     if (a.Cin % 4 || a.ldc % 4 || a.CoutPad % NPAD) return hipErrorInvalidValue;
+    // Cout >= 128: 32 tiles x 128 channels per workgroup (half the input-transform work per MFMA); else 64 x 64
+    if (a.Cout > 64) return launch_wino_cfg<1, 4>(a, s);
     return launch_wino_cfg<2, 2>(a, s);
 }
 
