@@ -91,9 +91,13 @@ def main():
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     dist = None
-    if world > 1:
+    # BENCH_FORCE_DIST=1 runs the RCCL code path (init, weight broadcast, label gather, barrier) even with one rank, so it
+    # can be rehearsed on a 1-GPU box
+    use_dist = world > 1 or os.environ.get("BENCH_FORCE_DIST") == "1"
+    if use_dist:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29531")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
     spec = UNetSpec()
@@ -102,7 +106,7 @@ def main():
 
     # ---- weights: rank 0 generates, everybody else receives them over RCCL
     blob = pack_weights(spec, synth.make_weights(spec, 1234)) if rank == 0 else None
-    if world > 1:
+    if use_dist:
         blob = shard.broadcast_blob(blob, spec.n_params() * 4 + 36, dev)
 
     eng = binding.Engine(H, W, spec.in_ch, spec.base, spec.levels, spec.classes, max_batch=B, device=local_rank,
@@ -114,15 +118,15 @@ def main():
     # ---- this rank's shard of the synthetic batch, resident in HBM before the timed region
     imgs = torch.from_numpy(synth.make_images(B, H, W, 1, 0x5EED + 1000 * rank, "bytes")).to(dev)
     labels = torch.empty((B, H, W), dtype=torch.uint8, device=dev)
-    gathered = [torch.empty_like(labels) for _ in range(world)] if (world > 1 and rank == 0) else None
+    gathered = [torch.empty_like(labels) for _ in range(world)] if (use_dist and rank == 0) else None
 
     def step():
         eng.infer_device(imgs.data_ptr(), B, labels.data_ptr(), 0)
-        if world > 1:
+        if use_dist:
             dist.gather(labels, gathered, dst=0)
 
     def fence():
-        if world > 1:
+        if use_dist:
             dist.barrier()
         torch.cuda.synchronize(dev)
 
@@ -139,7 +143,7 @@ def main():
     eng.set_profiling(False)
 
     tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
-    if world > 1:
+    if use_dist:
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
     dt = float(tmax.item())
 
@@ -197,7 +201,9 @@ def main():
         else:
             out["cpu_baseline"] = None
         print(json.dumps(out))
-    if world > 1:
+    if use_dist:
+        if rank == 0 and gathered is not None and not torch.equal(gathered[0], labels):
+            raise SystemExit("gathered label maps differ from rank 0's own")
         dist.barrier()
         dist.destroy_process_group()
     eng.close()
