@@ -122,3 +122,24 @@ def test_fused_pooling_is_bit_identical_to_the_pool_kernel(algo, monkeypatch):
         assert ("maxpool2x2" in kernels) == (flag == "0")
         outs.append((labels, logits))
     assert np.array_equal(outs[0][0], outs[1][0]) and np.array_equal(outs[0][1], outs[1][1])
+
+
+def test_graph_replay_matches_eager(monkeypatch):
+    """The forward pass is captured into a hipGraph on the second call of a (buffers, batch) key and replayed afterwards
+    (the reference replays a CUDA graph, src/process.cpp:147); results must be bit-identical to eager launches."""
+    spec = UNetSpec()
+    blob = pack_weights(spec, synth.make_weights(spec, 5))
+    imgs = synth.make_images(3, 64, 96, 1, 0x2222, "blobs")
+    res = {}
+    for flag in ("0", "1"):
+        monkeypatch.setenv("MIUNET_GRAPH", flag)
+        with binding.Engine(64, 96, max_batch=2) as eng:
+            eng.load_weights(blob)
+            runs = [eng.infer(imgs, want_logits=True) for _ in range(4)]     # eager, capture+launch, replay, replay
+            for lab, lg in runs[1:]:
+                assert np.array_equal(lab, runs[0][0]) and np.array_equal(lg, runs[0][1])
+            eng.load_weights(blob)                                             # reload invalidates the captured graphs
+            lab, lg = eng.infer(imgs, want_logits=True)
+            assert np.array_equal(lg, runs[0][1])
+            res[flag] = runs[0]
+    assert np.array_equal(res["0"][1], res["1"][1]) and np.array_equal(res["0"][0], res["1"][0])

@@ -71,6 +71,14 @@ struct mi_unet {
     uint8_t *h_img = nullptr;
     uint8_t *h_labels = nullptr;
     std::vector<Step> plan;
+    // hipGraph replay of the forward pass (the reference replays a captured CUDA graph per image, src/process.cpp:99-105,
+    // :147): one captured graph per (stream, buffers, batch) key; the first call of a key runs eagerly.
+    struct GraphEntry {
+        hipStream_t stream; const uint8_t *imgs; uint8_t *labels; float *logits; int B;
+        int uses; hipGraphExec_t exec;
+    };
+    std::vector<GraphEntry> graphs;
+    bool use_graph = true;          // MIUNET_GRAPH=0 disables
     // profiling: one event pair per launch, recorded on the launch stream and only read back (synchronised) in
     // mi_unet_get_kernel_stats, so the launches themselves never wait on the host
     bool profiling = false;
@@ -321,7 +329,42 @@ int build_plan(mi_unet *h, const HostWeights &hw)
     return 0;
 }
 
+int launch_plan(mi_unet *h, const uint8_t *d_imgs, int B, uint8_t *d_labels, float *d_logits);
+
 int run_microbatch(mi_unet *h, const uint8_t *d_imgs, int B, uint8_t *d_labels, float *d_logits)
+{
+    if (!h->use_graph || h->profiling) return launch_plan(h, d_imgs, B, d_labels, d_logits);
+    hipStream_t s = h->stream;
+    mi_unet::GraphEntry *ge = nullptr;
+    for (auto &g : h->graphs)
+        if (g.stream == s && g.imgs == d_imgs && g.labels == d_labels && g.logits == d_logits && g.B == B) ge = &g;
+    if (!ge) {
+        if (h->graphs.size() >= 16) {                    // bounded cache: drop the oldest entry
+            if (h->graphs.front().exec) (void)hipGraphExecDestroy(h->graphs.front().exec);
+            h->graphs.erase(h->graphs.begin());
+        }
+        h->graphs.push_back({ s, d_imgs, d_labels, d_logits, B, 0, nullptr });
+        ge = &h->graphs.back();
+    }
+    if (ge->exec) {
+        HIP_TRY(hipGraphLaunch(ge->exec, s));
+        return 0;
+    }
+    if (ge->uses++ == 0) return launch_plan(h, d_imgs, B, d_labels, d_logits);   // eager once (also sets kernel attributes)
+    hipGraph_t graph = nullptr;
+    HIP_TRY(hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal));
+    const int rc = launch_plan(h, d_imgs, B, d_labels, d_logits);
+    const hipError_t e = hipStreamEndCapture(s, &graph);
+    if (rc) { if (graph) (void)hipGraphDestroy(graph); return rc; }
+    if (e != hipSuccess) return fail(MI_UNET_EHIP, std::string("hipStreamEndCapture: ") + hipGetErrorString(e));
+    const hipError_t ei = hipGraphInstantiate(&ge->exec, graph, nullptr, nullptr, 0);
+    (void)hipGraphDestroy(graph);
+    if (ei != hipSuccess) { ge->exec = nullptr; return fail(MI_UNET_EHIP, std::string("hipGraphInstantiate: ") + hipGetErrorString(ei)); }
+    HIP_TRY(hipGraphLaunch(ge->exec, s));
+    return 0;
+}
+
+int launch_plan(mi_unet *h, const uint8_t *d_imgs, int B, uint8_t *d_labels, float *d_logits)
 {
     hipStream_t s = h->stream;
     for (Step &st : h->plan) {
@@ -443,6 +486,8 @@ int mi_unet_create(const mi_unet_config *cfg, mi_unet_t **out)
         h->algo = algo;
         const char *fp = getenv("MIUNET_FUSE_POOL");
         h->fuse_pool = !(fp && !strcmp(fp, "0"));
+        const char *gr = getenv("MIUNET_GRAPH");
+        h->use_graph = !(gr && !strcmp(gr, "0"));
     }
     auto cleanup_fail = [&](int rc) { mi_unet_destroy(h); return rc; };
 #define HIP_TRY_H(expr)                                                                                        \
@@ -481,6 +526,9 @@ int mi_unet_load_weights_from_memory(mi_unet_t *h, const void *blob, size_t len)
     HostWeights hw;
     if (int rc = build_host_weights(h->cfg, h->algo, blob, len, hw)) return rc;
     HIP_TRY(hipSetDevice(h->cfg.device));
+    for (auto &g : h->graphs)
+        if (g.exec) (void)hipGraphExecDestroy(g.exec);
+    h->graphs.clear();
     if (h->d_weights) { HIP_TRY(hipFree(h->d_weights)); h->d_weights = nullptr; }
     h->weight_floats = hw.blob.size();
     HIP_TRY(hipMalloc(&h->d_weights, sizeof(float) * hw.blob.size()));
@@ -694,6 +742,8 @@ void mi_unet_destroy(mi_unet_t *h)
     for (hipEvent_t e : evs)
         if (e) (void)hipEventDestroy(e);
     for (hipEvent_t e : h->ev_pool) (void)hipEventDestroy(e);
+    for (auto &g : h->graphs)
+        if (g.exec) (void)hipGraphExecDestroy(g.exec);
     if (h->own_stream) (void)hipStreamDestroy(h->own_stream);
     delete h;
 }
