@@ -13,6 +13,8 @@ extern "C" {
 /* MedicalSeg::initialize_engine / process_single_image / cleanup_resources (include/initialize.h:12, process.h:29, cleanup.h:7) */
 int medseg_initialize_engine(const char *weight_path, const char *log_dir);
 int medseg_process_single_image(const char *raw_path, int width, int height, const char *output_dir);
+/* MedicalSeg::process_image_batch: n RAW paths of sizes widths[i] x heights[i]; returns the number of successes */
+int medseg_process_image_batch(const char *const *raw_paths, const int *widths, const int *heights, int n, const char *output_dir);
 void medseg_cleanup_resources(void);
 const char *medseg_get_log_path(void);
 

@@ -75,6 +75,13 @@ int mi_unet_infer_u8(mi_unet_t *h, const uint8_t *imgs, int B, uint8_t *labels, 
  * Call mi_unet_sync() before reading results from another stream. */
 int mi_unet_infer_u8_device(mi_unet_t *h, const uint8_t *d_imgs, int B, uint8_t *d_labels, float *d_logits);
 
+/* SURVEY §8f row f1 -- the arithmetic of Preprocess::preprocess_raw (src/preprocess.cpp:65-118) on the device, fused in
+ * front of the network: B headerless little-endian u16 RAW images (host pointers; image i is heights[i] x widths[i]) ->
+ * exact min/max -> top-left-aligned bilinear resample to the engine's H x W in fp64 -> u8 tiles (bit-exact with the
+ * reference's CPU loop) -> UNet -> labels.  tiles (u8 [B][H][W], host) and logits may be NULL.  in_ch must be 1. */
+int mi_unet_infer_raw16(mi_unet_t *h, const uint16_t *const *raws, const int *widths, const int *heights, int B,
+                        uint8_t *tiles, uint8_t *labels, float *logits);
+
 /* Use an external hipStream_t (e.g. the caller framework's current stream) instead of the engine's own. NULL restores it. */
 int mi_unet_set_stream(mi_unet_t *h, void *hip_stream);
 int mi_unet_sync(mi_unet_t *h);

@@ -14,7 +14,11 @@ from miunet.spec import UNetSpec, pack_weights
 pytestmark = pytest.mark.gpu
 
 
-def test_process_single_image_end_to_end(tmp_path, capfd):
+@pytest.mark.parametrize("host_pre", ["0", "1"])
+def test_process_single_image_end_to_end(tmp_path, capfd, monkeypatch, host_pre):
+    # "0": device-first (min/max + resample + quantise on the GPU in front of the network); "1": the reference's own order
+    # (CPU preprocess -> PNG on disk -> read back -> inference).  Both must produce the same files.
+    monkeypatch.setenv("MEDSEG_HOST_PREPROCESS", host_pre)
     spec = UNetSpec()
     blob = pack_weights(spec, synth.make_threshold_weights(spec))
     eng_dir = tmp_path / "engine"
@@ -75,3 +79,36 @@ def test_process_single_image_end_to_end(tmp_path, capfd):
                  "=== Cleaning Up Resources ===", "All resources cleaned up successfully"):
         assert line in log
     assert not hostlib.process_single_image(str(rp), 2048, 1536, str(out_dir))       # engine is gone again
+
+
+def test_process_image_batch(tmp_path):
+    """Directory mode as ONE device call: N RAW files of different sizes -> the reference's five artefacts per image."""
+    spec = UNetSpec()
+    blob = pack_weights(spec, synth.make_threshold_weights(spec))
+    wpath = tmp_path / "unet.miw"
+    wpath.write_bytes(blob)
+    out_dir = tmp_path / "out"
+    out_dir.mkdir()
+    assert hostlib.initialize_engine(str(wpath), str(tmp_path / "log"))
+    sizes = [(1536, 2048), (600, 800), (512, 512)]
+    paths, raws = [], []
+    for k, (h, w) in enumerate(sizes):
+        raw = synth.make_raw16(h, w, seed=40 + k)
+        p = tmp_path / f"b{k}.raw"
+        raw.tofile(p)
+        paths.append(str(p)); raws.append(raw)
+    paths.append(str(tmp_path / "missing.raw"))               # unreadable file: skipped, the others still succeed
+    n_ok = hostlib.process_image_batch(paths, [w for _, w in sizes] + [10], [h for h, _ in sizes] + [10], str(out_dir))
+    assert n_ok == 3
+    for k, raw in enumerate(raws):
+        tile = orc.preprocess_raw(raw)
+        _, labels = orc.unet_forward(blob, tile[None, :, :, None], want_logits=False)
+        vis = orc.mask_to_image(orc.postprocess_mask(labels[0]))
+        assert np.array_equal(np.array(Image.open(out_dir / f"b{k}_normalized.png")), tile)
+        assert np.array_equal(np.array(Image.open(out_dir / f"b{k}_mask.png")), vis)
+        contours = orc.find_contours(vis)
+        if contours:
+            h, w = raw.shape
+            doc = json.load(open(out_dir / f"b{k}.json"))
+            assert [[tuple(p) for p in s["points"]] for s in doc["shapes"]] == [orc.map_points(c, w / 512.0, h / 512.0) for c in contours]
+    hostlib.cleanup_resources()

@@ -67,6 +67,10 @@ struct mi_unet {
     uint8_t *d_img = nullptr;       // staging for the host-buffer entry point
     uint8_t *d_labels = nullptr;
     float *d_logits = nullptr;
+    uint16_t *d_raw = nullptr;      // RAW16 staging for mi_unet_infer_raw16 (grown on demand)
+    size_t raw_cap = 0;             // samples
+    uint16_t *h_raw = nullptr;      // pinned
+    unsigned *d_mnmx = nullptr;     // [max_batch][2]
     // pinned host staging (the reference used pageable std::vector, src/process.cpp:138,152)
     uint8_t *h_img = nullptr;
     uint8_t *h_labels = nullptr;
@@ -589,6 +593,51 @@ int mi_unet_infer_u8(mi_unet_t *h, const uint8_t *imgs, int B, uint8_t *labels, 
     return MI_UNET_OK;
 }
 
+int mi_unet_infer_raw16(mi_unet_t *h, const uint16_t *const *raws, const int *widths, const int *heights, int B,
+                        uint8_t *tiles, uint8_t *labels, float *logits)
+{
+    if (int rc = check_handle(h, true)) return rc;
+    if (!raws || !widths || !heights || !labels || B < 0) return fail(MI_UNET_EARG, "mi_unet_infer_raw16: bad argument");
+    if (h->cfg.in_ch != 1) return fail(MI_UNET_EARG, "mi_unet_infer_raw16 needs a single-channel engine");
+    HIP_TRY(hipSetDevice(h->cfg.device));
+    const size_t hw = (size_t)h->cfg.height * h->cfg.width;
+    hipStream_t s = h->stream;
+    if (!h->d_mnmx) HIP_TRY(hipMalloc(&h->d_mnmx, sizeof(unsigned) * 2 * h->cfg.max_batch));
+    for (int b0 = 0; b0 < B; b0 += h->cfg.max_batch) {
+        const int bm = (B - b0) < h->cfg.max_batch ? (B - b0) : h->cfg.max_batch;
+        for (int i = 0; i < bm; ++i) {
+            const int w = widths[b0 + i], ht = heights[b0 + i];
+            if (!raws[b0 + i] || w <= 0 || ht <= 0) return fail(MI_UNET_EARG, "mi_unet_infer_raw16: bad image description");
+            const size_t n = (size_t)w * ht;
+            if (n > h->raw_cap) {                    // grow the staging pair (outside any captured region)
+                HIP_TRY(hipStreamSynchronize(s));
+                if (h->d_raw) HIP_TRY(hipFree(h->d_raw));
+                if (h->h_raw) HIP_TRY(hipHostFree(h->h_raw));
+                h->d_raw = nullptr; h->h_raw = nullptr; h->raw_cap = 0;
+                HIP_TRY(hipMalloc(&h->d_raw, n * sizeof(uint16_t)));
+                HIP_TRY(hipHostMalloc(&h->h_raw, n * sizeof(uint16_t), hipHostMallocDefault));
+                h->raw_cap = n;
+            }
+            // one staging buffer: the previous image's kernels must have consumed it before it is overwritten
+            HIP_TRY(hipStreamSynchronize(s));
+            memcpy(h->h_raw, raws[b0 + i], n * sizeof(uint16_t));
+            HIP_TRY(hipMemcpyAsync(h->d_raw, h->h_raw, n * sizeof(uint16_t), hipMemcpyHostToDevice, s));
+            hipError_t e = launch_minmax_u16(h->d_raw, n, h->d_mnmx + 2 * i, s);
+            if (e == hipSuccess) e = launch_resample_u8(h->d_raw, w, ht, h->d_mnmx + 2 * i, h->d_img + i * hw, h->cfg.width, h->cfg.height, s);
+            if (e != hipSuccess) return fail(MI_UNET_EHIP, std::string("preprocess launch: ") + hipGetErrorString(e));
+        }
+        if (int rc = run_microbatch(h, h->d_img, bm, h->d_labels, logits ? h->d_logits : nullptr)) return rc;
+        if (tiles) HIP_TRY(hipMemcpyAsync(tiles + b0 * hw, h->d_img, bm * hw, hipMemcpyDeviceToHost, s));
+        HIP_TRY(hipMemcpyAsync(h->h_labels, h->d_labels, bm * hw, hipMemcpyDeviceToHost, s));
+        if (logits)
+            HIP_TRY(hipMemcpyAsync(logits + b0 * hw * h->cfg.classes, h->d_logits, sizeof(float) * bm * hw * h->cfg.classes,
+                                   hipMemcpyDeviceToHost, s));
+        HIP_TRY(hipStreamSynchronize(s));
+        memcpy(labels + b0 * hw, h->h_labels, bm * hw);
+    }
+    return MI_UNET_OK;
+}
+
 int mi_unet_set_stream(mi_unet_t *h, void *hip_stream)
 {
     if (int rc = check_handle(h, false)) return rc;
@@ -733,11 +782,12 @@ void mi_unet_destroy(mi_unet_t *h)
     if (h->own_stream) (void)hipStreamSynchronize(h->own_stream);
     for (int i = 0; i < 8; ++i)
         if (h->d_cat[i]) (void)hipFree(h->d_cat[i]);
-    void *dev[] = { h->d_weights, h->d_lut, h->d_s0, h->d_s1, h->d_img, h->d_labels, h->d_logits };
+    void *dev[] = { h->d_weights, h->d_lut, h->d_s0, h->d_s1, h->d_img, h->d_labels, h->d_logits, h->d_raw, h->d_mnmx };
     for (void *p : dev)
         if (p) (void)hipFree(p);
     if (h->h_img) (void)hipHostFree(h->h_img);
     if (h->h_labels) (void)hipHostFree(h->h_labels);
+    if (h->h_raw) (void)hipHostFree(h->h_raw);
     hipEvent_t evs[] = { h->tev0, h->tev1 };
     for (hipEvent_t e : evs)
         if (e) (void)hipEventDestroy(e);

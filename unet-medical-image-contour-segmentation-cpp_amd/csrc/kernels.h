@@ -53,4 +53,12 @@ hipError_t launch_maxpool2x2(const float *in, int ldc, float *out, int B, int H,
 hipError_t launch_head_argmax(const float *in, int Cin, const float *w, const float *bias, int classes, float *logits,
                               uint8_t *labels, int B, int HW, hipStream_t s);
 
+// Device form of the RAW16 preprocessing arithmetic (reference: src/preprocess.cpp:65-118), bit-exact:
+//   minmax   : exact u16 min / max of n samples into mnmx[0], mnmx[1] (u32 words, pre-set to 65535 / 0 by the launcher)
+//   resample : top-left aligned 4-tap bilinear in fp64 with the reference's operand order and NO fma contraction,
+//              quantised with (uchar)(int)((v - mn) * (255.0 / (mx - mn)) + 0.5); mx = (u16)(mn + 1) when mn == mx.
+hipError_t launch_minmax_u16(const uint16_t *raw, size_t n, unsigned *mnmx, hipStream_t s);
+hipError_t launch_resample_u8(const uint16_t *raw, int w, int h, const unsigned *mnmx, uint8_t *dst, int outW, int outH,
+                              hipStream_t s);
+
 }  // namespace miunet

@@ -961,4 +961,90 @@ hipError_t launch_head_argmax(const float *in, int Cin, const float *w, const fl
     return hipGetLastError();
 }
 
+// --------------------------------------------------------------------------------------------------------------------
+// RAW16 preprocessing on the device: HBM-bound integer scan + a 262144-pixel fp64 gather.
+__global__ __launch_bounds__(256) void minmax_init_kernel(unsigned *mnmx)
+{
+    if (threadIdx.x == 0) { mnmx[0] = 65535u; mnmx[1] = 0u; }
+}
+
+__global__ __launch_bounds__(256) void minmax_u16_kernel(const uint16_t *__restrict__ raw, size_t n, unsigned *mnmx)
+{
+    unsigned lo = 65535u, hi = 0u;
+    const size_t n8 = n / 8;                                   // 16 bytes = 8 samples per lane
+    const uint4 *v = reinterpret_cast<const uint4 *>(raw);
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n8; i += (size_t)gridDim.x * 256) {
+        const uint4 q = v[i];
+        const unsigned ws[4] = { q.x, q.y, q.z, q.w };
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const unsigned a = ws[k] & 0xFFFFu, b = ws[k] >> 16;
+            lo = min(lo, min(a, b));
+            hi = max(hi, max(a, b));
+        }
+    }
+    if (blockIdx.x == 0 && threadIdx.x < (n & 7)) {            // ragged tail
+        const unsigned a = raw[n8 * 8 + threadIdx.x];
+        lo = min(lo, a); hi = max(hi, a);
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {                          // wave64 butterfly
+        lo = min(lo, (unsigned)__shfl_xor((int)lo, o, 64));
+        hi = max(hi, (unsigned)__shfl_xor((int)hi, o, 64));
+    }
+    if ((threadIdx.x & 63) == 0) {
+        atomicMin(&mnmx[0], lo);
+        atomicMax(&mnmx[1], hi);
+    }
+}
+
+hipError_t launch_minmax_u16(const uint16_t *raw, size_t n, unsigned *mnmx, hipStream_t s)
+{
+    if (n == 0 || (reinterpret_cast<uintptr_t>(raw) & 15)) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(minmax_init_kernel, dim3(1), dim3(256), 0, s, mnmx);
+    size_t blocks = (n / 8 + 255) / 256;
+    if (blocks > 2048) blocks = 2048;
+    if (blocks == 0) blocks = 1;
+    hipLaunchKernelGGL(minmax_u16_kernel, dim3((unsigned)blocks), dim3(256), 0, s, raw, n, mnmx);
+    return hipGetLastError();
+}
+
+__global__ __launch_bounds__(256) void resample_u8_kernel(const uint16_t *__restrict__ raw, int w, int h,
+                                                          const unsigned *__restrict__ mnmx, uint8_t *__restrict__ dst,
+                                                          int outW, int outH)
+{
+#pragma clang fp contract(off)
+    const int x = blockIdx.x * 64 + (threadIdx.x & 63);
+    const int y = blockIdx.y * 4 + (threadIdx.x >> 6);
+    if (x >= outW || y >= outH) return;
+    const unsigned short mn = (unsigned short)mnmx[0];
+    unsigned short mx = (unsigned short)mnmx[1];
+    if (mn == mx) mx = (unsigned short)(mn + 1);                // evaluated in uint16_t: wraps to 0 at 65535 (src/preprocess.cpp:92)
+    const double scale8 = 255.0 / (double)((int)mx - (int)mn);
+    const double stepX = (double)w / (double)outW, stepY = (double)h / (double)outH;
+    const double fx = __dmul_rn((double)x, stepX), fy = __dmul_rn((double)y, stepY);
+    const int ix = (int)fx, iy = (int)fy;
+    const int ix1 = ix + 1 < w - 1 ? ix + 1 : w - 1;
+    const int iy1 = iy + 1 < h - 1 ? iy + 1 : h - 1;
+    const double dx = __dsub_rn(fx, (double)ix), dy = __dsub_rn(fy, (double)iy);
+    const double v00 = raw[(size_t)iy * w + ix], v01 = raw[(size_t)iy * w + ix1];
+    const double v10 = raw[(size_t)iy1 * w + ix], v11 = raw[(size_t)iy1 * w + ix1];
+    const double omdx = __dsub_rn(1.0, dx), omdy = __dsub_rn(1.0, dy);
+    // (1-dx)*(1-dy)*v00 + dx*(1-dy)*v01 + (1-dx)*dy*v10 + dx*dy*v11, left to right, one rounding per operation
+    double v = __dmul_rn(__dmul_rn(omdx, omdy), v00);
+    v = __dadd_rn(v, __dmul_rn(__dmul_rn(dx, omdy), v01));
+    v = __dadd_rn(v, __dmul_rn(__dmul_rn(omdx, dy), v10));
+    v = __dadd_rn(v, __dmul_rn(__dmul_rn(dx, dy), v11));
+    const double q = __dadd_rn(__dmul_rn(__dsub_rn(v, (double)mn), scale8), 0.5);
+    dst[(size_t)y * outW + x] = (uint8_t)(int)q;
+}
+
+hipError_t launch_resample_u8(const uint16_t *raw, int w, int h, const unsigned *mnmx, uint8_t *dst, int outW, int outH,
+                              hipStream_t s)
+{
+    if (w <= 0 || h <= 0 || outW <= 0 || outH <= 0) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(resample_u8_kernel, dim3((outW + 63) / 64, (outH + 3) / 4), dim3(256), 0, s, raw, w, h, mnmx, dst, outW, outH);
+    return hipGetLastError();
+}
+
 }  // namespace miunet

@@ -42,6 +42,11 @@ int medseg_process_single_image(const char *raw_path, int width, int height, con
 {
     return MedicalSeg::process_single_image(raw_path, width, height, output_dir) ? 0 : 1;
 }
+int medseg_process_image_batch(const char *const *raw_paths, const int *widths, const int *heights, int n, const char *output_dir)
+{
+    std::vector<std::string> p(raw_paths, raw_paths + n);
+    return MedicalSeg::process_image_batch(p, std::vector<int>(widths, widths + n), std::vector<int>(heights, heights + n), output_dir);
+}
 void medseg_cleanup_resources(void) { MedicalSeg::cleanup_resources(); }
 const char *medseg_get_log_path(void)
 {

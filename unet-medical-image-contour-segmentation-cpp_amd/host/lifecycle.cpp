@@ -3,6 +3,7 @@
 // Same log file name, banner lines, message prefixes and bool/void error conventions; the TensorRT engine, the
 // thread-local execution context and the CUDA graph are replaced by one mi_unet handle.
 #include <chrono>
+#include <cstdlib>
 #include <filesystem>
 #include <iostream>
 #include <mutex>
@@ -115,6 +116,91 @@ Image8 mask_to_image(const Image8 &mask)
     return vis;
 }
 
+namespace {
+
+// One image after the device work is done: write the reference's artefacts and run the CPU tail of the pipeline.
+void finish_image(const std::string &raw_path, int width, int height, const std::string &output_dir, const Image8 &tile,
+                  Image8 pred_mask)
+{
+    const std::string base_name = fs::path(raw_path).stem().string();
+    const std::string preprocessed_png_path = output_dir + "/" + base_name + "_normalized.png";
+    const std::string size_json_path = output_dir + "/" + base_name + "_original_sizes.json";
+    const std::string pred_mask_path = output_dir + "/" + base_name + "_mask.png";
+    if (!Preprocess::write_preprocess_outputs(tile, raw_path, preprocessed_png_path, size_json_path, width, height))
+        throw std::runtime_error("Preprocessing failed");
+    pred_mask = postprocess_mask(pred_mask);
+    if (!medseg::write_png(pred_mask_path, mask_to_image(pred_mask), /*level0=*/true))
+        throw std::runtime_error("Failed to save mask");
+    Mask2Polygon::process_single_mask(pred_mask_path, output_dir, size_json_path, preprocessed_png_path, base_name);
+}
+
+bool host_preprocess_requested()
+{
+    const char *e = std::getenv("MEDSEG_HOST_PREPROCESS");
+    return e && e[0] == '1';
+}
+
+}  // namespace
+
+// Device-first form of the pipeline for N images at once (the reference loops files one by one, src/main.cpp:148-164):
+// RAW16 -> [device: min/max, bilinear resample, quantise, UNet, argmax] -> per image on the host: PNG/JSON artefacts,
+// postprocess_mask, contours.  Returns the number of images that succeeded.
+int process_image_batch(const std::vector<std::string> &raw_paths, const std::vector<int> &widths,
+                        const std::vector<int> &heights, const std::string &output_dir)
+{
+    auto &log_file = get_log_file();
+    int ok = 0;
+    try {
+        if (!g_engine) throw std::runtime_error("Engine not initialized");
+        const size_t n = raw_paths.size();
+        if (widths.size() != n || heights.size() != n) throw std::runtime_error("widths/heights do not match raw_paths");
+        std::vector<std::vector<uint16_t>> raws(n);
+        std::vector<const uint16_t *> ptrs;
+        std::vector<int> ws, hs;
+        std::vector<size_t> idx;                           // images that could be read
+        for (size_t i = 0; i < n; ++i) {
+            try {
+                raws[i] = Preprocess::read_raw16(raw_paths[i], widths[i], heights[i]);
+                ptrs.push_back(raws[i].data()); ws.push_back(widths[i]); hs.push_back(heights[i]); idx.push_back(i);
+            } catch (const std::exception &e) {
+                std::cerr << "Processing error: " << e.what() << " (" << raw_paths[i] << ")" << std::endl;
+                if (log_file.is_open()) log_file << "Processing error: " << e.what() << " (" << raw_paths[i] << ")" << std::endl;
+            }
+        }
+        const size_t hw = (size_t)g_cfg.height * g_cfg.width;
+        std::vector<uint8_t> tiles(hw * idx.size()), labels(hw * idx.size());
+        const auto t0 = std::chrono::high_resolution_clock::now();
+        {
+            std::lock_guard<std::mutex> lk(g_infer_mutex);
+            if (!idx.empty() && mi_unet_infer_raw16(g_engine, ptrs.data(), ws.data(), hs.data(), (int)idx.size(), tiles.data(),
+                                                    labels.data(), nullptr) != MI_UNET_OK)
+                throw std::runtime_error(std::string("Inference failed: ") + mi_unet_last_error());
+        }
+        const auto ms = std::chrono::duration_cast<std::chrono::milliseconds>(std::chrono::high_resolution_clock::now() - t0).count();
+        if (log_file.is_open()) log_file << "Batch inference time: " << ms << " ms for " << idx.size() << " images" << std::endl;
+        for (size_t k = 0; k < idx.size(); ++k) {
+            const size_t i = idx[k];
+            try {
+                if (log_file.is_open())
+                    log_file << "\n=== Processing Image: " << fs::path(raw_paths[i]).filename().string() << " ===" << std::endl;
+                Image8 tile(g_cfg.height, g_cfg.width, 1), mask(g_cfg.height, g_cfg.width, 1);
+                std::copy(tiles.begin() + k * hw, tiles.begin() + (k + 1) * hw, tile.data.begin());
+                std::copy(labels.begin() + k * hw, labels.begin() + (k + 1) * hw, mask.data.begin());
+                finish_image(raw_paths[i], widths[i], heights[i], output_dir, tile, std::move(mask));
+                if (log_file.is_open()) log_file << "Processing completed for: " << fs::path(raw_paths[i]).stem().string() << std::endl;
+                ++ok;
+            } catch (const std::exception &e) {
+                std::cerr << "Processing error: " << e.what() << std::endl;
+                if (log_file.is_open()) log_file << "Processing error: " << e.what() << std::endl;
+            }
+        }
+    } catch (const std::exception &e) {
+        std::cerr << "Processing error: " << e.what() << std::endl;
+        if (log_file.is_open()) log_file << "Processing error: " << e.what() << std::endl;
+    }
+    return ok;
+}
+
 bool process_single_image(const std::string &raw_path, int width, int height, const std::string &output_dir)
 {
     try {
@@ -124,25 +210,43 @@ bool process_single_image(const std::string &raw_path, int width, int height, co
         const std::string base_name = fs::path(raw_path).stem().string();
         const auto total_start = std::chrono::high_resolution_clock::now();
 
-        const std::string preprocessed_png_path = output_dir + "/" + base_name + "_normalized.png";
-        const std::string size_json_path = output_dir + "/" + base_name + "_original_sizes.json";
-        const std::string pred_mask_path = output_dir + "/" + base_name + "_mask.png";
-
-        if (!Preprocess::preprocess_raw(raw_path, preprocessed_png_path, size_json_path, width, height))
-            throw std::runtime_error("Preprocessing failed");
-        const Image8 gray_img = medseg::read_png(preprocessed_png_path, /*as_color=*/false);
-        if (gray_img.empty()) throw std::runtime_error("Failed to read preprocessed image");
-
-        const auto infer_start = std::chrono::high_resolution_clock::now();
-        Image8 pred_mask = execute_inference(gray_img);
-        const auto infer_ms = std::chrono::duration_cast<std::chrono::milliseconds>(
-                                  std::chrono::high_resolution_clock::now() - infer_start).count();
-        log_file << "Inference time: " << infer_ms << " ms" << std::endl;
-
-        pred_mask = postprocess_mask(pred_mask);
-        if (!medseg::write_png(pred_mask_path, mask_to_image(pred_mask), /*level0=*/true))
-            throw std::runtime_error("Failed to save mask");
-        Mask2Polygon::process_single_mask(pred_mask_path, output_dir, size_json_path, preprocessed_png_path, base_name);
+        if (host_preprocess_requested()) {
+            // the reference's own order: CPU preprocess -> PNG on disk -> read back -> inference (src/process.cpp:211-224)
+            const std::string preprocessed_png_path = output_dir + "/" + base_name + "_normalized.png";
+            const std::string size_json_path = output_dir + "/" + base_name + "_original_sizes.json";
+            if (!Preprocess::preprocess_raw(raw_path, preprocessed_png_path, size_json_path, width, height))
+                throw std::runtime_error("Preprocessing failed");
+            const Image8 gray_img = medseg::read_png(preprocessed_png_path, /*as_color=*/false);
+            if (gray_img.empty()) throw std::runtime_error("Failed to read preprocessed image");
+            const auto infer_start = std::chrono::high_resolution_clock::now();
+            Image8 pred_mask = execute_inference(gray_img);
+            const auto infer_ms = std::chrono::duration_cast<std::chrono::milliseconds>(
+                                      std::chrono::high_resolution_clock::now() - infer_start).count();
+            log_file << "Inference time: " << infer_ms << " ms" << std::endl;
+            finish_image(raw_path, width, height, output_dir, gray_img, std::move(pred_mask));
+        } else {
+            // device-first: min/max + resample + quantise run on the GPU in front of the network; the tile
+            // comes back once, for the _normalized.png artefact
+            std::vector<uint16_t> raw;
+            try {
+                raw = Preprocess::read_raw16(raw_path, width, height);
+            } catch (const std::exception &e) {
+                std::cerr << "preprocess_raw error: " << e.what() << '\n';
+                throw std::runtime_error("Preprocessing failed");
+            }
+            const uint16_t *rp = raw.data();
+            Image8 tile(g_cfg.height, g_cfg.width, 1), pred_mask(g_cfg.height, g_cfg.width, 1);
+            const auto infer_start = std::chrono::high_resolution_clock::now();
+            {
+                std::lock_guard<std::mutex> lk(g_infer_mutex);
+                if (mi_unet_infer_raw16(g_engine, &rp, &width, &height, 1, tile.data.data(), pred_mask.data.data(), nullptr) != MI_UNET_OK)
+                    throw std::runtime_error(std::string("Inference failed: ") + mi_unet_last_error());
+            }
+            const auto infer_ms = std::chrono::duration_cast<std::chrono::milliseconds>(
+                                      std::chrono::high_resolution_clock::now() - infer_start).count();
+            log_file << "Inference time: " << infer_ms << " ms" << std::endl;
+            finish_image(raw_path, width, height, output_dir, tile, std::move(pred_mask));
+        }
 
         const auto total_ms = std::chrono::duration_cast<std::chrono::milliseconds>(
                                   std::chrono::high_resolution_clock::now() - total_start).count();

@@ -90,6 +90,30 @@ medseg::Image8 resample_normalize(const uint16_t *src, int w, int h, int outW, i
     return dst;
 }
 
+std::vector<uint16_t> read_raw16(const std::string &raw_path, int w, int h)
+{
+    if (w <= 0 || h <= 0) throw std::runtime_error("width and height must be positive");
+    MappedFile file(raw_path, (size_t)w * h * 2);
+    return std::vector<uint16_t>(file.data(), file.data() + (size_t)w * h);
+}
+
+bool write_preprocess_outputs(const medseg::Image8 &tile, const std::string &raw_path, const std::string &png_path,
+                              const std::string &json_path, int w, int h)
+{
+    try {
+        const fs::path parent = fs::path(png_path).parent_path();
+        if (!parent.empty()) fs::create_directories(parent);
+        if (!medseg::write_png(png_path, tile, /*level0=*/true)) throw std::runtime_error("imwrite failed");
+        std::ofstream jf(json_path);
+        jf << medseg::size_json_text(fs::path(raw_path).filename().string(), w, h, tile.cols, tile.rows);
+        jf.flush();
+        return jf.good();
+    } catch (const std::exception &e) {
+        std::cerr << "preprocess_raw error: " << e.what() << '\n';
+        return false;
+    }
+}
+
 bool preprocess_raw(const std::string &raw_path, const std::string &png_path, const std::string &json_path, int w, int h)
 {
     try {
@@ -97,15 +121,7 @@ bool preprocess_raw(const std::string &raw_path, const std::string &png_path, co
         const int outW = 512, outH = 512;                        // src/preprocess.cpp:81
         MappedFile file(raw_path, (size_t)w * h * 2);
         const medseg::Image8 dst8 = resample_normalize(file.data(), w, h, outW, outH);
-
-        const fs::path parent = fs::path(png_path).parent_path();
-        if (!parent.empty()) fs::create_directories(parent);
-        if (!medseg::write_png(png_path, dst8, /*level0=*/true)) throw std::runtime_error("imwrite failed");
-
-        std::ofstream jf(json_path);
-        jf << medseg::size_json_text(fs::path(raw_path).filename().string(), w, h, outW, outH);
-        jf.flush();
-        return true;
+        return write_preprocess_outputs(dst8, raw_path, png_path, json_path, w, h);
     } catch (const std::exception &e) {
         std::cerr << "preprocess_raw error: " << e.what() << '\n';
         return false;

@@ -15,7 +15,7 @@ LIB_PATH = os.path.join(PKG_DIR, "libmiunet.so")
 
 EXPORTS = [
     "mi_unet_default_config", "mi_unet_create", "mi_unet_load_weights", "mi_unet_load_weights_from_memory",
-    "mi_unet_infer_u8", "mi_unet_infer_u8_device", "mi_unet_set_stream", "mi_unet_sync", "mi_unet_timer_begin",
+    "mi_unet_infer_u8", "mi_unet_infer_u8_device", "mi_unet_infer_raw16", "mi_unet_set_stream", "mi_unet_sync", "mi_unet_timer_begin",
     "mi_unet_timer_end", "mi_unet_set_profiling", "mi_unet_get_kernel_stats", "mi_unet_layer_debug", "mi_unet_destroy",
     "mi_unet_last_error", "mi_unet_device_count",
 ]
@@ -53,6 +53,8 @@ def lib():
         L.mi_unet_load_weights_from_memory.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t]
         L.mi_unet_infer_u8.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]
         L.mi_unet_infer_u8_device.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]
+        L.mi_unet_infer_raw16.argtypes = [C.c_void_p, C.POINTER(C.c_void_p), C.POINTER(C.c_int), C.POINTER(C.c_int), C.c_int,
+                                          C.c_void_p, C.c_void_p, C.c_void_p]
         L.mi_unet_set_stream.argtypes = [C.c_void_p, C.c_void_p]
         L.mi_unet_sync.argtypes = [C.c_void_p]
         L.mi_unet_timer_begin.argtypes = [C.c_void_p]
@@ -134,6 +136,19 @@ class Engine:
         logits = np.empty((b, c.classes, c.height, c.width), np.float32) if want_logits else None
         _check(lib().mi_unet_infer_u8(self._h, _ptr(imgs), b, _ptr(labels), _ptr(logits)))
         return labels, logits
+
+    def infer_raw16(self, raws, want_tiles=True, want_logits=False):
+        """raws: list of u16 [h_i][w_i] arrays -> (tiles u8 [B,H,W] or None, labels u8 [B,H,W], logits or None)"""
+        raws = [np.ascontiguousarray(r, dtype=np.uint16) for r in raws]
+        b, c = len(raws), self.cfg
+        ptrs = (C.c_void_p * b)(*[r.ctypes.data for r in raws])
+        ws = (C.c_int * b)(*[r.shape[1] for r in raws])
+        hs = (C.c_int * b)(*[r.shape[0] for r in raws])
+        tiles = np.empty((b, c.height, c.width), np.uint8) if want_tiles else None
+        labels = np.empty((b, c.height, c.width), np.uint8)
+        logits = np.empty((b, c.classes, c.height, c.width), np.float32) if want_logits else None
+        _check(lib().mi_unet_infer_raw16(self._h, ptrs, ws, hs, b, _ptr(tiles), _ptr(labels), _ptr(logits)))
+        return tiles, labels, logits
 
     def infer_device(self, d_imgs_ptr: int, b: int, d_labels_ptr: int, d_logits_ptr: int = 0):
         _check(lib().mi_unet_infer_u8_device(self._h, C.c_void_p(d_imgs_ptr), b, C.c_void_p(d_labels_ptr),

@@ -14,7 +14,7 @@ _u8 = np.ctypeslib.ndpointer(np.uint8, flags="C_CONTIGUOUS")
 _u16 = np.ctypeslib.ndpointer(np.uint16, flags="C_CONTIGUOUS")
 _i32 = np.ctypeslib.ndpointer(np.int32, flags="C_CONTIGUOUS")
 
-EXPORTS = ["medseg_initialize_engine", "medseg_process_single_image", "medseg_cleanup_resources", "medseg_get_log_path",
+EXPORTS = ["medseg_initialize_engine", "medseg_process_single_image", "medseg_process_image_batch", "medseg_cleanup_resources", "medseg_get_log_path",
            "medseg_preprocess_raw", "medseg_resample_normalize", "medseg_postprocess_mask", "medseg_mask_to_image",
            "medseg_extract_contours", "medseg_map_points", "medseg_generate_json", "medseg_process_single_mask",
            "medseg_write_png", "medseg_read_png"]
@@ -28,6 +28,7 @@ def lib():
         L = C.CDLL(LIB_PATH)
         L.medseg_initialize_engine.argtypes = [C.c_char_p, C.c_char_p]
         L.medseg_process_single_image.argtypes = [C.c_char_p, C.c_int, C.c_int, C.c_char_p]
+        L.medseg_process_image_batch.argtypes = [C.POINTER(C.c_char_p), C.POINTER(C.c_int), C.POINTER(C.c_int), C.c_int, C.c_char_p]
         L.medseg_cleanup_resources.restype = None
         L.medseg_get_log_path.restype = C.c_char_p
         L.medseg_preprocess_raw.argtypes = [C.c_char_p, C.c_char_p, C.c_char_p, C.c_int, C.c_int]
@@ -129,6 +130,12 @@ def initialize_engine(weight_path, log_dir) -> bool:
 
 def process_single_image(raw_path, w, h, output_dir) -> bool:
     return lib().medseg_process_single_image(_b(raw_path), w, h, _b(output_dir)) == 0
+
+
+def process_image_batch(raw_paths, widths, heights, output_dir) -> int:
+    n = len(raw_paths)
+    arr = (C.c_char_p * n)(*[_b(p) for p in raw_paths])
+    return lib().medseg_process_image_batch(arr, (C.c_int * n)(*widths), (C.c_int * n)(*heights), n, _b(output_dir))
 
 
 def cleanup_resources():
