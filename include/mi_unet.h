@@ -82,6 +82,15 @@ int mi_unet_infer_u8_device(mi_unet_t *h, const uint8_t *d_imgs, int B, uint8_t 
 int mi_unet_infer_raw16(mi_unet_t *h, const uint16_t *const *raws, const int *widths, const int *heights, int B,
                         uint8_t *tiles, uint8_t *labels, float *logits);
 
+/* SURVEY §8f row f2 -- postprocess_mask (src/postprocess.cpp:47-79) on the device, integer-exact: hole fill (8-connected
+ * components of label != 2 that touch no image edge and are smaller than 6 % of the image), 3x3 open, keep components of
+ * at least 6 % of the image; output in {0, 2}.
+ *   mi_unet_set_postprocess(h, 1): every mi_unet_infer_* call returns the POSTPROCESSED masks instead of the raw label
+ *                                  maps (the label maps never leave the device in between).
+ *   mi_unet_postprocess_masks    : the stage alone on host buffers, u8 [B][H][W] in -> out (may alias). */
+int mi_unet_set_postprocess(mi_unet_t *h, int on);
+int mi_unet_postprocess_masks(mi_unet_t *h, const uint8_t *labels, int B, uint8_t *out);
+
 /* Use an external hipStream_t (e.g. the caller framework's current stream) instead of the engine's own. NULL restores it. */
 int mi_unet_set_stream(mi_unet_t *h, void *hip_stream);
 int mi_unet_sync(mi_unet_t *h);

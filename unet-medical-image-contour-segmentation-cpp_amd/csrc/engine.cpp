@@ -83,6 +83,7 @@ struct mi_unet {
     };
     std::vector<GraphEntry> graphs;
     bool use_graph = true;          // MIUNET_GRAPH=0 disables
+    bool postprocess = false;       // mi_unet_set_postprocess: label maps -> postprocess_mask output before they leave the device
     // profiling: one event pair per launch, recorded on the launch stream and only read back (synchronised) in
     // mi_unet_get_kernel_stats, so the launches themselves never wait on the host
     bool profiling = false;
@@ -428,6 +429,24 @@ int launch_plan(mi_unet *h, const uint8_t *d_imgs, int B, uint8_t *d_labels, flo
     return 0;
 }
 
+// postprocess_mask on the device, in place on `d_labels`; the network's scratch buffer s1 is free once the head has run
+int device_postprocess(mi_unet *h, const uint8_t *d_in, uint8_t *d_out, int B)
+{
+    const int H = h->cfg.height, W = h->cfg.width;
+    const size_t cap = sizeof(float) * (size_t)h->cfg.max_batch * H * W * h->ch[0];
+    if (postprocess_workspace_bytes(B, H, W) > cap) return fail(MI_UNET_EARG, "postprocess workspace does not fit the scratch buffer");
+    const int min_area = static_cast<int>(W * H * 0.06f);            // src/postprocess.cpp:9, :30, :66 (evaluated in float)
+    const hipError_t e = launch_postprocess_masks(d_in, d_out, B, H, W, min_area, h->d_s1, h->stream);
+    if (e != hipSuccess) return fail(MI_UNET_EHIP, std::string("postprocess launch: ") + hipGetErrorString(e));
+    return 0;
+}
+
+int infer_microbatch(mi_unet *h, const uint8_t *d_imgs, int B, uint8_t *d_labels, float *d_logits)
+{
+    if (int rc = run_microbatch(h, d_imgs, B, d_labels, d_logits)) return rc;
+    return h->postprocess ? device_postprocess(h, d_labels, d_labels, B) : 0;
+}
+
 int check_handle(mi_unet *h, bool need_weights)
 {
     if (!h) return fail(MI_UNET_EARG, "null engine handle");
@@ -563,8 +582,8 @@ int mi_unet_infer_u8_device(mi_unet_t *h, const uint8_t *d_imgs, int B, uint8_t 
     const size_t hw = (size_t)h->cfg.height * h->cfg.width;
     for (int b0 = 0; b0 < B; b0 += h->cfg.max_batch) {
         const int bm = (B - b0) < h->cfg.max_batch ? (B - b0) : h->cfg.max_batch;
-        if (int rc = run_microbatch(h, d_imgs + b0 * hw * h->cfg.in_ch, bm, d_labels + b0 * hw,
-                                    d_logits ? d_logits + b0 * hw * h->cfg.classes : nullptr))
+        if (int rc = infer_microbatch(h, d_imgs + b0 * hw * h->cfg.in_ch, bm, d_labels + b0 * hw,
+                                      d_logits ? d_logits + b0 * hw * h->cfg.classes : nullptr))
             return rc;
     }
     return MI_UNET_OK;
@@ -582,13 +601,39 @@ int mi_unet_infer_u8(mi_unet_t *h, const uint8_t *imgs, int B, uint8_t *labels, 
         const size_t in_bytes = bm * hw * h->cfg.in_ch;
         memcpy(h->h_img, imgs + b0 * hw * h->cfg.in_ch, in_bytes);
         HIP_TRY(hipMemcpyAsync(h->d_img, h->h_img, in_bytes, hipMemcpyHostToDevice, s));
-        if (int rc = run_microbatch(h, h->d_img, bm, h->d_labels, logits ? h->d_logits : nullptr)) return rc;
+        if (int rc = infer_microbatch(h, h->d_img, bm, h->d_labels, logits ? h->d_logits : nullptr)) return rc;
         HIP_TRY(hipMemcpyAsync(h->h_labels, h->d_labels, bm * hw, hipMemcpyDeviceToHost, s));
         if (logits)
             HIP_TRY(hipMemcpyAsync(logits + b0 * hw * h->cfg.classes, h->d_logits, sizeof(float) * bm * hw * h->cfg.classes,
                                    hipMemcpyDeviceToHost, s));
         HIP_TRY(hipStreamSynchronize(s));
         memcpy(labels + b0 * hw, h->h_labels, bm * hw);
+    }
+    return MI_UNET_OK;
+}
+
+int mi_unet_set_postprocess(mi_unet_t *h, int on)
+{
+    if (int rc = check_handle(h, false)) return rc;
+    h->postprocess = on != 0;
+    return MI_UNET_OK;
+}
+
+int mi_unet_postprocess_masks(mi_unet_t *h, const uint8_t *labels, int B, uint8_t *out)
+{
+    if (int rc = check_handle(h, false)) return rc;
+    if (!labels || !out || B < 0) return fail(MI_UNET_EARG, "mi_unet_postprocess_masks: bad argument");
+    HIP_TRY(hipSetDevice(h->cfg.device));
+    const size_t hw = (size_t)h->cfg.height * h->cfg.width;
+    hipStream_t s = h->stream;
+    for (int b0 = 0; b0 < B; b0 += h->cfg.max_batch) {
+        const int bm = (B - b0) < h->cfg.max_batch ? (B - b0) : h->cfg.max_batch;
+        memcpy(h->h_labels, labels + b0 * hw, bm * hw);
+        HIP_TRY(hipMemcpyAsync(h->d_labels, h->h_labels, bm * hw, hipMemcpyHostToDevice, s));
+        if (int rc = device_postprocess(h, h->d_labels, h->d_labels, bm)) return rc;
+        HIP_TRY(hipMemcpyAsync(h->h_labels, h->d_labels, bm * hw, hipMemcpyDeviceToHost, s));
+        HIP_TRY(hipStreamSynchronize(s));
+        memcpy(out + b0 * hw, h->h_labels, bm * hw);
     }
     return MI_UNET_OK;
 }
@@ -626,7 +671,7 @@ int mi_unet_infer_raw16(mi_unet_t *h, const uint16_t *const *raws, const int *wi
             if (e == hipSuccess) e = launch_resample_u8(h->d_raw, w, ht, h->d_mnmx + 2 * i, h->d_img + i * hw, h->cfg.width, h->cfg.height, s);
             if (e != hipSuccess) return fail(MI_UNET_EHIP, std::string("preprocess launch: ") + hipGetErrorString(e));
         }
-        if (int rc = run_microbatch(h, h->d_img, bm, h->d_labels, logits ? h->d_logits : nullptr)) return rc;
+        if (int rc = infer_microbatch(h, h->d_img, bm, h->d_labels, logits ? h->d_logits : nullptr)) return rc;
         if (tiles) HIP_TRY(hipMemcpyAsync(tiles + b0 * hw, h->d_img, bm * hw, hipMemcpyDeviceToHost, s));
         HIP_TRY(hipMemcpyAsync(h->h_labels, h->d_labels, bm * hw, hipMemcpyDeviceToHost, s));
         if (logits)

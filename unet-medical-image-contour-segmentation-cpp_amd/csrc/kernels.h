@@ -61,4 +61,14 @@ hipError_t launch_minmax_u16(const uint16_t *raw, size_t n, unsigned *mnmx, hipS
 hipError_t launch_resample_u8(const uint16_t *raw, int w, int h, const unsigned *mnmx, uint8_t *dst, int outW, int outH,
                               hipStream_t s);
 
+// Device form of postprocess_mask (reference: src/postprocess.cpp:13-79), integer-exact.  Workspace `ws` must hold
+// postprocess_workspace_bytes(B, H, W) bytes; labels_in/out are u8 [B][H][W] (in-place allowed).
+//   hole fill : 8-connected components of (label != 2) by lock-free union-find, per-root area + bbox by atomics; a
+//               component is filled iff its bbox touches no image edge and area < min_area
+//   open      : 3x3 erode then dilate, windows clipped to the image
+//   filter    : 8-connected components of the opened mask, kept iff area >= min_area;  output in {0, 2}
+size_t postprocess_workspace_bytes(int B, int H, int W);
+hipError_t launch_postprocess_masks(const uint8_t *labels_in, uint8_t *labels_out, int B, int H, int W, int min_area,
+                                    void *ws, hipStream_t s);
+
 }  // namespace miunet

@@ -1047,4 +1047,152 @@ hipError_t launch_resample_u8(const uint16_t *raw, int w, int h, const unsigned 
     return hipGetLastError();
 }
 
+// --------------------------------------------------------------------------------------------------------------------
+// postprocess_mask on the device.  Byte/integer work, HBM/L2-bound and tiny next to the network:
+// the point is to keep the label maps on the device and to replace the reference's O(components x H x W) loops
+// (src/postprocess.cpp:41, :71) by one union-find labelling.
+namespace pp {
+
+__device__ __forceinline__ int ld(const int *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+
+__device__ __forceinline__ int find_root(const int *parent, int x)
+{
+    int p = ld(parent + x);
+    while (p != x) { x = p; p = ld(parent + x); }
+    return x;
+}
+
+// parents only ever decrease, roots satisfy parent[r] == r; atomicMin at L2 makes concurrent unions safe
+__device__ __forceinline__ void unite(int *parent, int a, int b)
+{
+    for (;;) {
+        a = find_root(parent, a);
+        b = find_root(parent, b);
+        if (a == b) return;
+        if (a < b) { const int t = a; a = b; b = t; }          // a > b: hang a under b
+        const int old = atomicMin(parent + a, b);
+        if (old == a) return;
+        a = old;                                                // somebody re-parented a meanwhile: retry from there
+    }
+}
+
+// fg[i] != 0 marks foreground.  parent = own index for fg, -1 for bg; stats cleared.
+__global__ __launch_bounds__(256) void cc_init(const uint8_t *__restrict__ fg, int *parent, int *area, int *minx, int *miny,
+                                               int *maxx, int *maxy, long long n)
+{
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    parent[i] = fg[i] ? (int)i : -1;
+    area[i] = 0; minx[i] = 0x7FFFFFFF; miny[i] = 0x7FFFFFFF; maxx[i] = -1; maxy[i] = -1;
+}
+
+__global__ __launch_bounds__(256) void cc_merge(const uint8_t *__restrict__ fg, int *parent, int H, int W, long long n)
+{
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n || !fg[i]) return;
+    const int hw = H * W;
+    const int p = (int)(i % hw), y = p / W, x = p - y * W;
+    if (x > 0 && fg[i - 1]) unite(parent, (int)i, (int)i - 1);
+    if (y > 0) {
+        if (fg[i - W]) unite(parent, (int)i, (int)i - W);
+        if (x > 0 && fg[i - W - 1]) unite(parent, (int)i, (int)i - W - 1);
+        if (x + 1 < W && fg[i - W + 1]) unite(parent, (int)i, (int)i - W + 1);
+    }
+}
+
+__global__ __launch_bounds__(256) void cc_stats(int *parent, int *area, int *minx, int *miny, int *maxx, int *maxy, int H, int W,
+                                                long long n)
+{
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n || parent[i] < 0) return;
+    const int r = find_root(parent, (int)i);
+    parent[i] = r;                                              // flatten (only this thread writes parent[i] in this kernel...
+    const int hw = H * W;                                       // ... and a non-root's value is never used as a union target)
+    const int p = (int)(i % hw), y = p / W, x = p - y * W;
+    atomicAdd(area + r, 1);
+    atomicMin(minx + r, x); atomicMax(maxx + r, x);
+    atomicMin(miny + r, y); atomicMax(maxy + r, y);
+}
+
+__global__ __launch_bounds__(256) void k_inv(const uint8_t *__restrict__ labels, uint8_t *inv, long long n)
+{
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (i < n) inv[i] = labels[i] == 2 ? 0 : 255;               // src/postprocess.cpp:18-22
+}
+
+// bin = 255 where the pixel is foreground after hole filling (src/postprocess.cpp:30-43, :57)
+__global__ __launch_bounds__(256) void k_fill_bin(const uint8_t *__restrict__ labels, const int *__restrict__ parent,
+                                                  const int *__restrict__ area, const int *__restrict__ minx,
+                                                  const int *__restrict__ miny, const int *__restrict__ maxx,
+                                                  const int *__restrict__ maxy, uint8_t *bin, int H, int W, int min_area, long long n)
+{
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    bool fgd = labels[i] == 2;
+    const int r = parent[i];
+    if (!fgd && r >= 0)
+        fgd = minx[r] > 0 && miny[r] > 0 && maxx[r] < W - 1 && maxy[r] < H - 1 && area[r] < min_area;
+    bin[i] = fgd ? 255 : 0;
+}
+
+template <bool DILATE>
+__global__ __launch_bounds__(256) void k_morph3(const uint8_t *__restrict__ src, uint8_t *dst, int H, int W, long long n)
+{
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const int hw = H * W;
+    const int p = (int)(i % hw), y = p / W, x = p - y * W;
+    unsigned v = DILATE ? 0u : 255u;
+#pragma unroll
+    for (int dy = -1; dy <= 1; ++dy)
+#pragma unroll
+        for (int dx = -1; dx <= 1; ++dx) {
+            const int yy = y + dy, xx = x + dx;
+            if (yy < 0 || yy >= H || xx < 0 || xx >= W) continue;          // the border never constrains / never seeds
+            const unsigned sv = src[i + dy * W + dx];
+            v = DILATE ? max(v, sv) : min(v, sv);
+        }
+    dst[i] = (uint8_t)v;
+}
+
+__global__ __launch_bounds__(256) void k_filter(const int *__restrict__ parent, const int *__restrict__ area, uint8_t *out,
+                                                int min_area, long long n)
+{
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const int r = parent[i];
+    out[i] = (r >= 0 && area[r] >= min_area) ? 2 : 0;          // src/postprocess.cpp:70, :75-76
+}
+
+}  // namespace pp
+
+size_t postprocess_workspace_bytes(int B, int H, int W)
+{
+    const size_t n = (size_t)B * H * W;
+    return n * (6 * sizeof(int) + 3);                           // parent, area, 4 x bbox, three u8 planes
+}
+
+hipError_t launch_postprocess_masks(const uint8_t *labels_in, uint8_t *labels_out, int B, int H, int W, int min_area, void *ws,
+                                    hipStream_t s)
+{
+    const long long n = (long long)B * H * W;
+    if (n <= 0 || n > 0x7FFFFFFFLL) return hipErrorInvalidValue;
+    int *parent = static_cast<int *>(ws), *area = parent + n, *minx = area + n, *miny = minx + n, *maxx = miny + n, *maxy = maxx + n;
+    uint8_t *u0 = reinterpret_cast<uint8_t *>(maxy + n), *u1 = u0 + n, *u2 = u1 + n;
+    const dim3 g((unsigned)((n + 255) / 256)), b(256);
+    auto label = [&](const uint8_t *fg) {
+        hipLaunchKernelGGL(pp::cc_init, g, b, 0, s, fg, parent, area, minx, miny, maxx, maxy, n);
+        hipLaunchKernelGGL(pp::cc_merge, g, b, 0, s, fg, parent, H, W, n);
+        hipLaunchKernelGGL(pp::cc_stats, g, b, 0, s, parent, area, minx, miny, maxx, maxy, H, W, n);
+    };
+    hipLaunchKernelGGL(pp::k_inv, g, b, 0, s, labels_in, u0, n);
+    label(u0);
+    hipLaunchKernelGGL(pp::k_fill_bin, g, b, 0, s, labels_in, parent, area, minx, miny, maxx, maxy, u1, H, W, min_area, n);
+    hipLaunchKernelGGL(pp::k_morph3<false>, g, b, 0, s, u1, u2, H, W, n);
+    hipLaunchKernelGGL(pp::k_morph3<true>, g, b, 0, s, u2, u1, H, W, n);
+    label(u1);
+    hipLaunchKernelGGL(pp::k_filter, g, b, 0, s, parent, area, labels_out, min_area, n);
+    return hipGetLastError();
+}
+
 }  // namespace miunet

@@ -120,7 +120,7 @@ namespace {
 
 // One image after the device work is done: write the reference's artefacts and run the CPU tail of the pipeline.
 void finish_image(const std::string &raw_path, int width, int height, const std::string &output_dir, const Image8 &tile,
-                  Image8 pred_mask)
+                  Image8 pred_mask, bool already_postprocessed)
 {
     const std::string base_name = fs::path(raw_path).stem().string();
     const std::string preprocessed_png_path = output_dir + "/" + base_name + "_normalized.png";
@@ -128,7 +128,7 @@ void finish_image(const std::string &raw_path, int width, int height, const std:
     const std::string pred_mask_path = output_dir + "/" + base_name + "_mask.png";
     if (!Preprocess::write_preprocess_outputs(tile, raw_path, preprocessed_png_path, size_json_path, width, height))
         throw std::runtime_error("Preprocessing failed");
-    pred_mask = postprocess_mask(pred_mask);
+    if (!already_postprocessed) pred_mask = postprocess_mask(pred_mask);
     if (!medseg::write_png(pred_mask_path, mask_to_image(pred_mask), /*level0=*/true))
         throw std::runtime_error("Failed to save mask");
     Mask2Polygon::process_single_mask(pred_mask_path, output_dir, size_json_path, preprocessed_png_path, base_name);
@@ -138,6 +138,13 @@ bool host_preprocess_requested()
 {
     const char *e = std::getenv("MEDSEG_HOST_PREPROCESS");
     return e && e[0] == '1';
+}
+
+// postprocess_mask runs on the device right behind the argmax unless MEDSEG_HOST_POSTPROCESS=1
+bool device_postprocess_requested()
+{
+    const char *e = std::getenv("MEDSEG_HOST_POSTPROCESS");
+    return !(e && e[0] == '1');
 }
 
 }  // namespace
@@ -170,11 +177,14 @@ int process_image_batch(const std::vector<std::string> &raw_paths, const std::ve
         const size_t hw = (size_t)g_cfg.height * g_cfg.width;
         std::vector<uint8_t> tiles(hw * idx.size()), labels(hw * idx.size());
         const auto t0 = std::chrono::high_resolution_clock::now();
+        const bool dev_post = device_postprocess_requested();
         {
             std::lock_guard<std::mutex> lk(g_infer_mutex);
-            if (!idx.empty() && mi_unet_infer_raw16(g_engine, ptrs.data(), ws.data(), hs.data(), (int)idx.size(), tiles.data(),
-                                                    labels.data(), nullptr) != MI_UNET_OK)
-                throw std::runtime_error(std::string("Inference failed: ") + mi_unet_last_error());
+            mi_unet_set_postprocess(g_engine, dev_post ? 1 : 0);
+            const int rc = idx.empty() ? MI_UNET_OK : mi_unet_infer_raw16(g_engine, ptrs.data(), ws.data(), hs.data(), (int)idx.size(),
+                                                                          tiles.data(), labels.data(), nullptr);
+            mi_unet_set_postprocess(g_engine, 0);
+            if (rc != MI_UNET_OK) throw std::runtime_error(std::string("Inference failed: ") + mi_unet_last_error());
         }
         const auto ms = std::chrono::duration_cast<std::chrono::milliseconds>(std::chrono::high_resolution_clock::now() - t0).count();
         if (log_file.is_open()) log_file << "Batch inference time: " << ms << " ms for " << idx.size() << " images" << std::endl;
@@ -186,7 +196,7 @@ int process_image_batch(const std::vector<std::string> &raw_paths, const std::ve
                 Image8 tile(g_cfg.height, g_cfg.width, 1), mask(g_cfg.height, g_cfg.width, 1);
                 std::copy(tiles.begin() + k * hw, tiles.begin() + (k + 1) * hw, tile.data.begin());
                 std::copy(labels.begin() + k * hw, labels.begin() + (k + 1) * hw, mask.data.begin());
-                finish_image(raw_paths[i], widths[i], heights[i], output_dir, tile, std::move(mask));
+                finish_image(raw_paths[i], widths[i], heights[i], output_dir, tile, std::move(mask), dev_post);
                 if (log_file.is_open()) log_file << "Processing completed for: " << fs::path(raw_paths[i]).stem().string() << std::endl;
                 ++ok;
             } catch (const std::exception &e) {
@@ -223,7 +233,7 @@ bool process_single_image(const std::string &raw_path, int width, int height, co
             const auto infer_ms = std::chrono::duration_cast<std::chrono::milliseconds>(
                                       std::chrono::high_resolution_clock::now() - infer_start).count();
             log_file << "Inference time: " << infer_ms << " ms" << std::endl;
-            finish_image(raw_path, width, height, output_dir, gray_img, std::move(pred_mask));
+            finish_image(raw_path, width, height, output_dir, gray_img, std::move(pred_mask), false);
         } else {
             // device-first: min/max + resample + quantise run on the GPU in front of the network; the tile
             // comes back once, for the _normalized.png artefact
@@ -237,15 +247,18 @@ bool process_single_image(const std::string &raw_path, int width, int height, co
             const uint16_t *rp = raw.data();
             Image8 tile(g_cfg.height, g_cfg.width, 1), pred_mask(g_cfg.height, g_cfg.width, 1);
             const auto infer_start = std::chrono::high_resolution_clock::now();
+            const bool dev_post = device_postprocess_requested();
             {
                 std::lock_guard<std::mutex> lk(g_infer_mutex);
-                if (mi_unet_infer_raw16(g_engine, &rp, &width, &height, 1, tile.data.data(), pred_mask.data.data(), nullptr) != MI_UNET_OK)
-                    throw std::runtime_error(std::string("Inference failed: ") + mi_unet_last_error());
+                mi_unet_set_postprocess(g_engine, dev_post ? 1 : 0);
+                const int rc = mi_unet_infer_raw16(g_engine, &rp, &width, &height, 1, tile.data.data(), pred_mask.data.data(), nullptr);
+                mi_unet_set_postprocess(g_engine, 0);
+                if (rc != MI_UNET_OK) throw std::runtime_error(std::string("Inference failed: ") + mi_unet_last_error());
             }
             const auto infer_ms = std::chrono::duration_cast<std::chrono::milliseconds>(
                                       std::chrono::high_resolution_clock::now() - infer_start).count();
             log_file << "Inference time: " << infer_ms << " ms" << std::endl;
-            finish_image(raw_path, width, height, output_dir, tile, std::move(pred_mask));
+            finish_image(raw_path, width, height, output_dir, tile, std::move(pred_mask), dev_post);
         }
 
         const auto total_ms = std::chrono::duration_cast<std::chrono::milliseconds>(

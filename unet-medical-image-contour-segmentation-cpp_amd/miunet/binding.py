@@ -15,7 +15,7 @@ LIB_PATH = os.path.join(PKG_DIR, "libmiunet.so")
 
 EXPORTS = [
     "mi_unet_default_config", "mi_unet_create", "mi_unet_load_weights", "mi_unet_load_weights_from_memory",
-    "mi_unet_infer_u8", "mi_unet_infer_u8_device", "mi_unet_infer_raw16", "mi_unet_set_stream", "mi_unet_sync", "mi_unet_timer_begin",
+    "mi_unet_infer_u8", "mi_unet_infer_u8_device", "mi_unet_infer_raw16", "mi_unet_set_postprocess", "mi_unet_postprocess_masks", "mi_unet_set_stream", "mi_unet_sync", "mi_unet_timer_begin",
     "mi_unet_timer_end", "mi_unet_set_profiling", "mi_unet_get_kernel_stats", "mi_unet_layer_debug", "mi_unet_destroy",
     "mi_unet_last_error", "mi_unet_device_count",
 ]
@@ -55,6 +55,8 @@ def lib():
         L.mi_unet_infer_u8_device.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]
         L.mi_unet_infer_raw16.argtypes = [C.c_void_p, C.POINTER(C.c_void_p), C.POINTER(C.c_int), C.POINTER(C.c_int), C.c_int,
                                           C.c_void_p, C.c_void_p, C.c_void_p]
+        L.mi_unet_set_postprocess.argtypes = [C.c_void_p, C.c_int]
+        L.mi_unet_postprocess_masks.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]
         L.mi_unet_set_stream.argtypes = [C.c_void_p, C.c_void_p]
         L.mi_unet_sync.argtypes = [C.c_void_p]
         L.mi_unet_timer_begin.argtypes = [C.c_void_p]
@@ -149,6 +151,15 @@ class Engine:
         logits = np.empty((b, c.classes, c.height, c.width), np.float32) if want_logits else None
         _check(lib().mi_unet_infer_raw16(self._h, ptrs, ws, hs, b, _ptr(tiles), _ptr(labels), _ptr(logits)))
         return tiles, labels, logits
+
+    def set_postprocess(self, on: bool):
+        _check(lib().mi_unet_set_postprocess(self._h, int(on)))
+
+    def postprocess_masks(self, labels: np.ndarray):
+        labels = np.ascontiguousarray(labels, np.uint8)
+        out = np.empty_like(labels)
+        _check(lib().mi_unet_postprocess_masks(self._h, _ptr(labels), labels.shape[0], _ptr(out)))
+        return out
 
     def infer_device(self, d_imgs_ptr: int, b: int, d_labels_ptr: int, d_logits_ptr: int = 0):
         _check(lib().mi_unet_infer_u8_device(self._h, C.c_void_p(d_imgs_ptr), b, C.c_void_p(d_labels_ptr),
