@@ -14,8 +14,9 @@ from miunet.spec import UNetSpec, pack_weights
 pytestmark = pytest.mark.gpu
 
 
-@pytest.mark.parametrize("host_pre", ["0", "1"])
-def test_process_single_image_end_to_end(tmp_path, capfd, monkeypatch, host_pre):
+@pytest.mark.parametrize("host_pre,host_post", [("0", "0"), ("1", "1"), ("0", "1")])
+def test_process_single_image_end_to_end(tmp_path, capfd, monkeypatch, host_pre, host_post):
+    monkeypatch.setenv("MEDSEG_HOST_POSTPROCESS", host_post)     # "0": postprocess_mask on the device behind the argmax
     # "0": device-first (min/max + resample + quantise on the GPU in front of the network); "1": the reference's own order
     # (CPU preprocess -> PNG on disk -> read back -> inference).  Both must produce the same files.
     monkeypatch.setenv("MEDSEG_HOST_PREPROCESS", host_pre)
