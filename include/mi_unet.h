@@ -91,6 +91,15 @@ int mi_unet_infer_raw16(mi_unet_t *h, const uint16_t *const *raws, const int *wi
 int mi_unet_set_postprocess(mi_unet_t *h, int on);
 int mi_unet_postprocess_masks(mi_unet_t *h, const uint8_t *labels, int B, uint8_t *out);
 
+/* SURVEY §8f row f3 -- Mask2Polygon::extract_contours (src/mask2polygon.cpp:29-36: threshold 127 +
+ * findContours(RETR_EXTERNAL, CHAIN_APPROX_SIMPLE)) on the device, same point sequences and contour order.
+ *   masks  u8 [B][H][W] host (e.g. the 0/128/255 visualisation of mask_to_image; > 127 = foreground)
+ *   xy     int32 [B][cap_points][2] out: x,y pairs of image b's contours, contour after contour (newest first)
+ *   start  int32 [B][cap_contours + 1] out: first point of contour c; entry [counts[b]] = total points of image b
+ *   counts int32 [B] out: number of contours of image b, or -1 if one of the two capacities was too small for it */
+int mi_unet_extract_contours(mi_unet_t *h, const uint8_t *masks, int B, int32_t *xy, int cap_points, int32_t *start,
+                             int cap_contours, int32_t *counts);
+
 /* Use an external hipStream_t (e.g. the caller framework's current stream) instead of the engine's own. NULL restores it. */
 int mi_unet_set_stream(mi_unet_t *h, void *hip_stream);
 int mi_unet_sync(mi_unet_t *h);

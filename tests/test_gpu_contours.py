@@ -1,0 +1,61 @@
+"""extract_contours (threshold 127 + external contours, CHAIN_APPROX_SIMPLE, newest first) on the
+device, exact against the oracle's sequential Suzuki-Abe restatement (oracle/imgproc_oracle.c)."""
+import numpy as np
+import pytest
+
+import oracle_lib as orc
+from miunet import binding
+
+pytestmark = pytest.mark.gpu
+
+
+def _blob_mask(seed, h, w, smooth=2, q=0.55):
+    rng = np.random.default_rng(seed)
+    f = rng.random((h, w))
+    for _ in range(smooth):
+        f = (f + np.roll(f, 1, 0) + np.roll(f, -1, 0) + np.roll(f, 1, 1) + np.roll(f, -1, 1)) / 5
+    m = (f > np.quantile(f, q)).astype(np.uint8) * 255
+    m[rng.random((h, w)) < 0.02] = 255
+    m[rng.random((h, w)) < 0.02] = 0
+    return m
+
+
+def test_known_answers_and_nesting():
+    masks = np.zeros((7, 64, 64), np.uint8)
+    masks[0, 2:6, 3:9] = 255                                            # rectangle: TL, BL, BR, TR
+    masks[1, 2:6, 3:9] = 255; masks[1, 8, 1] = 200; masks[1, 10, 5:9] = 128   # + isolated pixel + 1-px line, newest first
+    masks[2, 1:30, 1:30] = 255; masks[2, 5:25, 5:25] = 0; masks[2, 8:20, 8:20] = 255; masks[2, 11:15, 11:15] = 0; masks[2, 12:14, 12:14] = 255
+    masks[3, :, :] = 255                                                 # touches every edge
+    masks[4, 0, 0] = 255; masks[4, 63, 63] = 255; masks[4, 0:3, 63] = 255
+    masks[5, 10:40, 10:40] = 255; masks[5, 20:30, 20:40] = 0; masks[5, 22:28, 25:35] = 255    # C-shape open to the right + blob in the notch
+    masks[6, 30, 30] = 127; masks[6, 31, 31] = 128                      # threshold is strict (> 127)
+    with binding.Engine(64, 64, max_batch=4) as eng:
+        got = eng.extract_contours(masks, cap_points=2048, cap_contours=64)
+    assert got[0] == [[(3, 2), (3, 5), (8, 5), (8, 2)]]
+    assert got[1] == [[(5, 10), (8, 10)], [(1, 8)], [(3, 2), (3, 5), (8, 5), (8, 2)]]
+    assert got[2] == [[(1, 1), (1, 29), (29, 29), (29, 1)]]             # everything nested inside the hole is not external
+    assert got[3] == [[(0, 0), (0, 63), (63, 63), (63, 0)]]
+    assert got[6] == [[(31, 31)]]
+    for i in range(7):
+        assert got[i] == orc.find_contours(masks[i]), i
+
+
+@pytest.mark.parametrize("h,w,smooth,q", [(64, 64, 2, 0.55), (96, 160, 1, 0.5), (48, 80, 3, 0.6), (128, 128, 0, 0.5)])
+def test_random_masks_vs_oracle(h, w, smooth, q):
+    masks = np.stack([_blob_mask(1000 * smooth + s, h, w, smooth, q) for s in range(6)])
+    with binding.Engine(h, w, max_batch=4) as eng:
+        got = eng.extract_contours(masks, cap_points=h * w, cap_contours=h * w // 2)
+    for i in range(masks.shape[0]):
+        assert got[i] == orc.find_contours(masks[i]), i
+
+
+def test_full_size_and_capacity_overflow():
+    masks = np.stack([_blob_mask(7 + s, 512, 512, 4, 0.5) for s in range(3)])
+    with binding.Engine(512, 512, max_batch=2) as eng:
+        got = eng.extract_contours(masks, cap_points=200000, cap_contours=20000)
+        small = eng.extract_contours(masks, cap_points=16, cap_contours=20000)
+        few = eng.extract_contours(masks, cap_points=200000, cap_contours=2)
+    for i in range(3):
+        want = orc.find_contours(masks[i])
+        assert got[i] == want and len(want) > 10
+        assert small[i] is None and few[i] is None

@@ -71,6 +71,8 @@ struct mi_unet {
     size_t raw_cap = 0;             // samples
     uint16_t *h_raw = nullptr;      // pinned
     unsigned *d_mnmx = nullptr;     // [max_batch][2]
+    int *d_cont = nullptr;          // contour outputs of mi_unet_extract_contours (grown on demand)
+    size_t cont_cap = 0;            // ints
     // pinned host staging (the reference used pageable std::vector, src/process.cpp:138,152)
     uint8_t *h_img = nullptr;
     uint8_t *h_labels = nullptr;
@@ -638,6 +640,42 @@ int mi_unet_postprocess_masks(mi_unet_t *h, const uint8_t *labels, int B, uint8_
     return MI_UNET_OK;
 }
 
+int mi_unet_extract_contours(mi_unet_t *h, const uint8_t *masks, int B, int32_t *xy, int cap_points, int32_t *start,
+                             int cap_contours, int32_t *counts)
+{
+    if (int rc = check_handle(h, false)) return rc;
+    if (!masks || !xy || !start || !counts || B < 0 || cap_points <= 0 || cap_contours <= 0)
+        return fail(MI_UNET_EARG, "mi_unet_extract_contours: bad argument");
+    HIP_TRY(hipSetDevice(h->cfg.device));
+    const int H = h->cfg.height, W = h->cfg.width;
+    const size_t hw = (size_t)H * W;
+    const size_t scratch = sizeof(float) * (size_t)h->cfg.max_batch * hw * h->ch[0];
+    hipStream_t s = h->stream;
+    for (int b0 = 0; b0 < B; b0 += h->cfg.max_batch) {
+        const int bm = (B - b0) < h->cfg.max_batch ? (B - b0) : h->cfg.max_batch;
+        if (contour_workspace_bytes(bm, H, W, cap_contours) > scratch)
+            return fail(MI_UNET_EARG, "contour workspace does not fit the scratch buffer (cap_contours too large)");
+        const size_t need = (size_t)bm * ((size_t)cap_points * 2 + cap_contours + 1 + 1);
+        if (need > h->cont_cap) {
+            HIP_TRY(hipStreamSynchronize(s));
+            if (h->d_cont) HIP_TRY(hipFree(h->d_cont));
+            h->d_cont = nullptr; h->cont_cap = 0;
+            HIP_TRY(hipMalloc(&h->d_cont, need * sizeof(int)));
+            h->cont_cap = need;
+        }
+        int *d_xy = h->d_cont, *d_start = d_xy + (size_t)bm * cap_points * 2, *d_count = d_start + (size_t)bm * (cap_contours + 1);
+        memcpy(h->h_labels, masks + b0 * hw, bm * hw);
+        HIP_TRY(hipMemcpyAsync(h->d_labels, h->h_labels, bm * hw, hipMemcpyHostToDevice, s));
+        const hipError_t e = launch_extract_contours(h->d_labels, bm, H, W, d_xy, cap_points, d_start, cap_contours, d_count, h->d_s1, s);
+        if (e != hipSuccess) return fail(MI_UNET_EHIP, std::string("contour launch: ") + hipGetErrorString(e));
+        HIP_TRY(hipMemcpyAsync(xy + (size_t)b0 * cap_points * 2, d_xy, sizeof(int) * (size_t)bm * cap_points * 2, hipMemcpyDeviceToHost, s));
+        HIP_TRY(hipMemcpyAsync(start + (size_t)b0 * (cap_contours + 1), d_start, sizeof(int) * (size_t)bm * (cap_contours + 1), hipMemcpyDeviceToHost, s));
+        HIP_TRY(hipMemcpyAsync(counts + b0, d_count, sizeof(int) * bm, hipMemcpyDeviceToHost, s));
+        HIP_TRY(hipStreamSynchronize(s));
+    }
+    return MI_UNET_OK;
+}
+
 int mi_unet_infer_raw16(mi_unet_t *h, const uint16_t *const *raws, const int *widths, const int *heights, int B,
                         uint8_t *tiles, uint8_t *labels, float *logits)
 {
@@ -827,7 +865,7 @@ void mi_unet_destroy(mi_unet_t *h)
     if (h->own_stream) (void)hipStreamSynchronize(h->own_stream);
     for (int i = 0; i < 8; ++i)
         if (h->d_cat[i]) (void)hipFree(h->d_cat[i]);
-    void *dev[] = { h->d_weights, h->d_lut, h->d_s0, h->d_s1, h->d_img, h->d_labels, h->d_logits, h->d_raw, h->d_mnmx };
+    void *dev[] = { h->d_weights, h->d_lut, h->d_s0, h->d_s1, h->d_img, h->d_labels, h->d_logits, h->d_raw, h->d_mnmx, h->d_cont };
     for (void *p : dev)
         if (p) (void)hipFree(p);
     if (h->h_img) (void)hipHostFree(h->h_img);

@@ -71,4 +71,15 @@ size_t postprocess_workspace_bytes(int B, int H, int W);
 hipError_t launch_postprocess_masks(const uint8_t *labels_in, uint8_t *labels_out, int B, int H, int W, int min_area,
                                     void *ws, hipStream_t s);
 
+// Device form of Mask2Polygon::extract_contours (reference: src/mask2polygon.cpp:29-36 = threshold 127 +
+// findContours(RETR_EXTERNAL, CHAIN_APPROX_SIMPLE)), exact point sequences and contour order.
+//   masks u8 [B][H][W] (any values; > 127 = foreground).  Per image: at most cap_contours contours and cap_points points.
+//   out_xy     int32 [B][cap_points][2]   points of all contours of the image, contour after contour (newest first)
+//   out_start  int32 [B][cap_contours+1]  first point of contour c; entry n_contours = total points
+//   out_count  int32 [B]                  number of contours, or -1 when a capacity was too small
+// Workspace: contour_workspace_bytes(B, H, W, cap_contours).
+size_t contour_workspace_bytes(int B, int H, int W, int cap_contours);
+hipError_t launch_extract_contours(const uint8_t *masks, int B, int H, int W, int *out_xy, int cap_points, int *out_start,
+                                   int cap_contours, int *out_count, void *ws, hipStream_t s);
+
 }  // namespace miunet

@@ -1195,4 +1195,187 @@ hipError_t launch_postprocess_masks(const uint8_t *labels_in, uint8_t *labels_ou
     return hipGetLastError();
 }
 
+// --------------------------------------------------------------------------------------------------------------------
+// extract_contours on the device.
+// OpenCV's sequential Suzuki-Abe scan interleaves "find the next start pixel" with "follow that border".  For
+// RETR_EXTERNAL both halves separate cleanly:
+//   * the start pixel of a component's outer border is its first pixel in raster order = the ROOT of the union-find
+//     labelling above (parents always point to smaller indices);
+//   * the border is external iff the background region just above that pixel reaches the image frame (OpenCV's
+//     `img0[lnbd] > 0` test says the same thing through the sign of the last border label on the row): the pixel above
+//     the root is background by construction, and a 4-connected background component reaches the frame iff its
+//     bounding box touches the image edge;
+//   * the trace itself (first neighbour clockwise from west, then counter-clockwise from the arrival direction, a point
+//     wherever the step direction changes) is inherently serial per contour, so every external contour gets its own
+//     lane: contours and images run in parallel, the mask is L2-resident (256 KB per image);
+//   * OpenCV returns contours newest-first = descending raster order of the start pixels: a 64-bit-free trick -- the
+//     per-image list of external roots is sorted by one thread per image (a handful of entries after postprocess_mask).
+namespace ct {
+
+__global__ __launch_bounds__(256) void k_threshold(const uint8_t *__restrict__ mask, uint8_t *fg, uint8_t *bg, long long n)
+{
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const bool f = mask[i] > 127;                               // cv::threshold(127, 255, THRESH_BINARY)
+    fg[i] = f ? 255 : 0;
+    bg[i] = f ? 0 : 255;
+}
+
+// 4-connected union (background regions)
+__global__ __launch_bounds__(256) void cc_merge4(const uint8_t *__restrict__ fg, int *parent, int H, int W, long long n)
+{
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n || !fg[i]) return;
+    const int hw = H * W;
+    const int p = (int)(i % hw), y = p / W, x = p - y * W;
+    if (x > 0 && fg[i - 1]) pp::unite(parent, (int)i, (int)i - 1);
+    if (y > 0 && fg[i - W]) pp::unite(parent, (int)i, (int)i - W);
+}
+
+__global__ __launch_bounds__(256) void k_zero_counts(int *counts, int B)
+{
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i < B) counts[i] = 0;
+}
+
+// one entry per external component: its root (= start pixel).  fparent: flattened fg labelling; bparent + bbox: background.
+__global__ __launch_bounds__(256) void k_collect(const int *__restrict__ fparent, const int *__restrict__ bparent,
+                                                 const int *__restrict__ bminx, const int *__restrict__ bminy,
+                                                 const int *__restrict__ bmaxx, const int *__restrict__ bmaxy, int *roots,
+                                                 int *counts, int cap, int H, int W, long long n)
+{
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n || fparent[i] != (int)i) return;                // roots only
+    const int hw = H * W, img = (int)(i / hw);
+    const int p = (int)(i % hw), y = p / W;
+    bool external = (y == 0);
+    if (!external) {
+        const int r = bparent[i - W];                           // the pixel above a component's first pixel is background
+        external = r >= 0 && (bminx[r] == 0 || bminy[r] == 0 || bmaxx[r] == W - 1 || bmaxy[r] == H - 1);
+    }
+    if (external) {
+        const int slot = atomicAdd(counts + img, 1);
+        if (slot < cap) roots[(size_t)img * cap + slot] = p;
+    }
+}
+
+// per image: sort the start pixels descending (newest contour first).  Few entries: insertion sort by one lane.
+__global__ __launch_bounds__(64) void k_sort_roots(int *roots, const int *counts, int cap, int B)
+{
+    const int img = blockIdx.x * 64 + threadIdx.x;
+    if (img >= B) return;
+    const int n = counts[img] < cap ? counts[img] : cap;
+    int *r = roots + (size_t)img * cap;
+    for (int a = 1; a < n; ++a) {
+        const int v = r[a];
+        int b = a - 1;
+        while (b >= 0 && r[b] < v) { r[b + 1] = r[b]; --b; }
+        r[b + 1] = v;
+    }
+}
+
+// one lane per (image, contour): follow the border from its start pixel, emit CHAIN_APPROX_SIMPLE points.
+// pass 0 counts points (npts), pass 1 writes them at the offsets computed in between.
+__global__ __launch_bounds__(64) void k_trace(const uint8_t *__restrict__ fg, const int *__restrict__ roots,
+                                              const int *__restrict__ counts, int cap, int H, int W, int B, int *npts,
+                                              const int *__restrict__ offs, int *out_xy, int cap_points, int write)
+{
+    const int t = blockIdx.x * 64 + threadIdx.x;
+    const int img = t / cap, c = t - img * cap;
+    if (img >= B || c >= counts[img] || counts[img] > cap) return;
+    const uint8_t *im = fg + (size_t)img * H * W;
+    auto at = [&](int x, int y) -> bool { return x >= 0 && x < W && y >= 0 && y < H && im[(size_t)y * W + x] != 0; };
+    const int DX[8] = { 1, 1, 0, -1, -1, -1, 0, 1 };            // 0 = E, then counter-clockwise on screen (y grows down)
+    const int DY[8] = { 0, -1, -1, -1, 0, 1, 1, 1 };
+    const int start = roots[(size_t)img * cap + c];
+    const int x0 = start % W, y0 = start / W;
+    int *dst = nullptr;
+    int room = 0;
+    if (write) {
+        const int o = offs[(size_t)img * (cap + 1) + c];
+        room = cap_points - o;
+        dst = out_xy + ((size_t)img * cap_points + o) * 2;
+    }
+    int n = 0;
+    auto emit = [&](int x, int y) {
+        if (write && n < room) { dst[2 * n] = x; dst[2 * n + 1] = y; }
+        ++n;
+    };
+    int dir = 4, first = -1;                                    // first neighbour: clockwise, starting after west
+    for (int k = 0; k < 8; ++k) {
+        dir = (dir + 7) & 7;
+        if (at(x0 + DX[dir], y0 + DY[dir])) { first = dir; break; }
+    }
+    if (first < 0) {
+        emit(x0, y0);                                           // isolated pixel
+    } else {
+        const int x1 = x0 + DX[first], y1 = y0 + DY[first];
+        int cx = x0, cy = y0, came = first, last_step = first ^ 4;
+        for (long long guard = 0; guard < 4LL * H * W + 16; ++guard) {      // a border has at most 4 visits per pixel
+            int s = came, nx, ny;
+            do { ++s; nx = cx + DX[s & 7]; ny = cy + DY[s & 7]; } while (!at(nx, ny));
+            const int step = s & 7;
+            if (step != last_step) { emit(cx, cy); last_step = step; }
+            const bool closing = (nx == x0 && ny == y0 && cx == x1 && cy == y1);
+            cx = nx; cy = ny;
+            if (closing) break;
+            came = (step + 4) & 7;
+        }
+    }
+    if (!write) npts[(size_t)img * cap + c] = n;
+}
+
+// per image: exclusive scan of the point counts -> out_start, and the verdict (count or -1 on overflow)
+__global__ __launch_bounds__(64) void k_offsets(const int *__restrict__ npts, const int *__restrict__ counts, int cap,
+                                                int cap_points, int B, int *out_start, int *out_count)
+{
+    const int img = blockIdx.x * 64 + threadIdx.x;
+    if (img >= B) return;
+    int *st = out_start + (size_t)img * (cap + 1);
+    const int nc = counts[img];
+    if (nc > cap) { out_count[img] = -1; st[0] = 0; return; }
+    int o = 0;
+    for (int c = 0; c < nc; ++c) { st[c] = o; o += npts[(size_t)img * cap + c]; }
+    st[nc] = o;
+    out_count[img] = o > cap_points ? -1 : nc;
+}
+
+}  // namespace ct
+
+size_t contour_workspace_bytes(int B, int H, int W, int cap_contours)
+{
+    const size_t n = (size_t)B * H * W;
+    return n * (7 * sizeof(int) + 2) + sizeof(int) * ((size_t)B * (2 * cap_contours + 1) + 64);
+}
+
+hipError_t launch_extract_contours(const uint8_t *masks, int B, int H, int W, int *out_xy, int cap_points, int *out_start,
+                                   int cap_contours, int *out_count, void *ws, hipStream_t s)
+{
+    const long long n = (long long)B * H * W;
+    if (n <= 0 || n > 0x7FFFFFFFLL || cap_contours <= 0 || cap_points <= 0) return hipErrorInvalidValue;
+    int *fparent = static_cast<int *>(ws), *bparent = fparent + n, *area = bparent + n, *minx = area + n, *miny = minx + n,
+        *maxx = miny + n, *maxy = maxx + n;
+    uint8_t *fg = reinterpret_cast<uint8_t *>(maxy + n), *bg = fg + n;
+    int *roots = reinterpret_cast<int *>(bg + n + ((16 - (2 * n) % 16) % 16));
+    int *npts = roots + (size_t)B * cap_contours, *counts = npts + (size_t)B * cap_contours;
+    const dim3 g((unsigned)((n + 255) / 256)), b(256);
+    hipLaunchKernelGGL(ct::k_threshold, g, b, 0, s, masks, fg, bg, n);
+    // foreground labelling (8-connected); its stats are not needed, the arrays are reused by the background pass
+    hipLaunchKernelGGL(pp::cc_init, g, b, 0, s, fg, fparent, area, minx, miny, maxx, maxy, n);
+    hipLaunchKernelGGL(pp::cc_merge, g, b, 0, s, fg, fparent, H, W, n);
+    hipLaunchKernelGGL(pp::cc_stats, g, b, 0, s, fparent, area, minx, miny, maxx, maxy, H, W, n);
+    // background labelling (4-connected) with bounding boxes
+    hipLaunchKernelGGL(pp::cc_init, g, b, 0, s, bg, bparent, area, minx, miny, maxx, maxy, n);
+    hipLaunchKernelGGL(ct::cc_merge4, g, b, 0, s, bg, bparent, H, W, n);
+    hipLaunchKernelGGL(pp::cc_stats, g, b, 0, s, bparent, area, minx, miny, maxx, maxy, H, W, n);
+    hipLaunchKernelGGL(ct::k_zero_counts, dim3((B + 255) / 256), b, 0, s, counts, B);
+    hipLaunchKernelGGL(ct::k_collect, g, b, 0, s, fparent, bparent, minx, miny, maxx, maxy, roots, counts, cap_contours, H, W, n);
+    hipLaunchKernelGGL(ct::k_sort_roots, dim3((B + 63) / 64), dim3(64), 0, s, roots, counts, cap_contours, B);
+    const dim3 gt((unsigned)(((long long)B * cap_contours + 63) / 64)), bt(64);
+    hipLaunchKernelGGL(ct::k_trace, gt, bt, 0, s, fg, roots, counts, cap_contours, H, W, B, npts, out_start, out_xy, cap_points, 0);
+    hipLaunchKernelGGL(ct::k_offsets, dim3((B + 63) / 64), dim3(64), 0, s, npts, counts, cap_contours, cap_points, B, out_start, out_count);
+    hipLaunchKernelGGL(ct::k_trace, gt, bt, 0, s, fg, roots, counts, cap_contours, H, W, B, npts, out_start, out_xy, cap_points, 1);
+    return hipGetLastError();
+}
+
 }  // namespace miunet

@@ -15,7 +15,7 @@ LIB_PATH = os.path.join(PKG_DIR, "libmiunet.so")
 
 EXPORTS = [
     "mi_unet_default_config", "mi_unet_create", "mi_unet_load_weights", "mi_unet_load_weights_from_memory",
-    "mi_unet_infer_u8", "mi_unet_infer_u8_device", "mi_unet_infer_raw16", "mi_unet_set_postprocess", "mi_unet_postprocess_masks", "mi_unet_set_stream", "mi_unet_sync", "mi_unet_timer_begin",
+    "mi_unet_infer_u8", "mi_unet_infer_u8_device", "mi_unet_infer_raw16", "mi_unet_set_postprocess", "mi_unet_postprocess_masks", "mi_unet_extract_contours", "mi_unet_set_stream", "mi_unet_sync", "mi_unet_timer_begin",
     "mi_unet_timer_end", "mi_unet_set_profiling", "mi_unet_get_kernel_stats", "mi_unet_layer_debug", "mi_unet_destroy",
     "mi_unet_last_error", "mi_unet_device_count",
 ]
@@ -57,6 +57,7 @@ def lib():
                                           C.c_void_p, C.c_void_p, C.c_void_p]
         L.mi_unet_set_postprocess.argtypes = [C.c_void_p, C.c_int]
         L.mi_unet_postprocess_masks.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]
+        L.mi_unet_extract_contours.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p]
         L.mi_unet_set_stream.argtypes = [C.c_void_p, C.c_void_p]
         L.mi_unet_sync.argtypes = [C.c_void_p]
         L.mi_unet_timer_begin.argtypes = [C.c_void_p]
@@ -159,6 +160,22 @@ class Engine:
         labels = np.ascontiguousarray(labels, np.uint8)
         out = np.empty_like(labels)
         _check(lib().mi_unet_postprocess_masks(self._h, _ptr(labels), labels.shape[0], _ptr(out)))
+        return out
+
+    def extract_contours(self, masks: np.ndarray, cap_points=8192, cap_contours=256):
+        """masks u8 [B,H,W] -> per image a list of contours [(x, y), ...] (None where a capacity overflowed)"""
+        masks = np.ascontiguousarray(masks, np.uint8)
+        b = masks.shape[0]
+        xy = np.zeros((b, cap_points, 2), np.int32)
+        start = np.zeros((b, cap_contours + 1), np.int32)
+        counts = np.zeros(b, np.int32)
+        _check(lib().mi_unet_extract_contours(self._h, _ptr(masks), b, _ptr(xy), cap_points, _ptr(start), cap_contours, _ptr(counts)))
+        out = []
+        for i in range(b):
+            if counts[i] < 0:
+                out.append(None)
+                continue
+            out.append([[tuple(p) for p in xy[i, start[i, c]:start[i, c + 1]].tolist()] for c in range(counts[i])])
         return out
 
     def infer_device(self, d_imgs_ptr: int, b: int, d_labels_ptr: int, d_logits_ptr: int = 0):
