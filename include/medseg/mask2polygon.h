@@ -24,6 +24,14 @@ void create_overlay_image(const std::vector<medseg::Contour> &contours, const st
 void process_single_mask(const std::string &mask_path, const std::string &output_dir, const std::string &json_path,
                          const std::string &original_png, const std::string &base_name);
 
+// In-memory halves of the functions above (used by the device-first pipeline, which already holds the tile and the contours):
+// the overlay picture (gray tile replicated to B,G,R, closed red polylines of thickness 1) and the steps 6-8 of
+// process_single_mask (src/mask2polygon.cpp:188-207) for contours that were extracted elsewhere.
+medseg::Image8 draw_overlay(const medseg::Image8 &gray_or_bgr, const std::vector<medseg::Contour> &contours);
+void write_polygon_outputs(const std::vector<medseg::Contour> &contours, const medseg::Image8 &normalized_tile,
+                           const std::string &output_dir, const std::string &base_name, int original_width,
+                           int original_height);
+
 // The document generate_json writes, as a string (4-space indent, sorted keys, trailing newline).
 std::string polygon_json_text(const std::vector<medseg::Contour> &contours, const std::string &base_name, int original_width,
                               int original_height);

@@ -100,6 +100,14 @@ int mi_unet_postprocess_masks(mi_unet_t *h, const uint8_t *labels, int B, uint8_
 int mi_unet_extract_contours(mi_unet_t *h, const uint8_t *masks, int B, int32_t *xy, int cap_points, int32_t *start,
                              int cap_contours, int32_t *counts);
 
+/* The whole device half of process_single_image (src/process.cpp:188-242) for B images in one call, nothing leaving the
+ * device in between: RAW16 -> min/max + bilinear + quantise (f1) -> UNet + argmax -> postprocess_mask (f2) ->
+ * mask_to_image -> extract_contours (f3).  Outputs (host): tiles u8 [B][H][W] (the _normalized.png pixels, may be NULL),
+ * masks u8 [B][H][W] (the _mask.png pixels: 0 / 255), and the contours in the layout of mi_unet_extract_contours. */
+int mi_unet_segment_raw16(mi_unet_t *h, const uint16_t *const *raws, const int *widths, const int *heights, int B,
+                          uint8_t *tiles, uint8_t *masks, int32_t *xy, int cap_points, int32_t *start, int cap_contours,
+                          int32_t *counts);
+
 /* Use an external hipStream_t (e.g. the caller framework's current stream) instead of the engine's own. NULL restores it. */
 int mi_unet_set_stream(mi_unet_t *h, void *hip_stream);
 int mi_unet_sync(mi_unet_t *h);

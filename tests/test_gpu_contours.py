@@ -59,3 +59,26 @@ def test_full_size_and_capacity_overflow():
         want = orc.find_contours(masks[i])
         assert got[i] == want and len(want) > 10
         assert small[i] is None and few[i] is None
+
+
+def test_segment_raw16_whole_device_half_of_the_pipeline():
+    """RAW16 -> tile -> UNet -> argmax -> postprocess_mask -> mask_to_image -> contours, all on the device in one call;
+    every output equals the oracle chain run stage by stage."""
+    from miunet import synth
+    from miunet.spec import UNetSpec, pack_weights
+
+    spec = UNetSpec()
+    blob = pack_weights(spec, synth.make_threshold_weights(spec))
+    raws = [synth.make_raw16(1536, 2048, seed=21), synth.make_raw16(600, 800, seed=41), np.full((64, 64), 7, np.uint16)]
+    with binding.Engine(512, 512, max_batch=2) as eng:
+        eng.load_weights(blob)
+        tiles, masks, cont = eng.segment_raw16(raws)
+    n_with_contours = 0
+    for i, raw in enumerate(raws):
+        tile = orc.preprocess_raw(raw)
+        _, labels = orc.unet_forward(blob, tile[None, :, :, None], want_logits=False)
+        vis = orc.mask_to_image(orc.postprocess_mask(labels[0]))
+        assert np.array_equal(tiles[i], tile) and np.array_equal(masks[i], vis)
+        assert cont[i] == orc.find_contours(vis)
+        n_with_contours += bool(cont[i])
+    assert n_with_contours >= 1

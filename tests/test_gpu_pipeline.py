@@ -82,7 +82,9 @@ def test_process_single_image_end_to_end(tmp_path, capfd, monkeypatch, host_pre,
     assert not hostlib.process_single_image(str(rp), 2048, 1536, str(out_dir))       # engine is gone again
 
 
-def test_process_image_batch(tmp_path):
+@pytest.mark.parametrize("host_contours", ["0", "1"])
+def test_process_image_batch(tmp_path, monkeypatch, host_contours):
+    monkeypatch.setenv("MEDSEG_HOST_CONTOURS", host_contours)     # "0": contours are extracted on the device as well
     """Directory mode as ONE device call: N RAW files of different sizes -> the reference's five artefacts per image."""
     spec = UNetSpec()
     blob = pack_weights(spec, synth.make_threshold_weights(spec))
@@ -112,4 +114,9 @@ def test_process_image_batch(tmp_path):
             h, w = raw.shape
             doc = json.load(open(out_dir / f"b{k}.json"))
             assert [[tuple(p) for p in s["points"]] for s in doc["shapes"]] == [orc.map_points(c, w / 512.0, h / 512.0) for c in contours]
+            ov = np.array(Image.open(out_dir / f"b{k}_contour_overlay.png"))
+            red = (ov[..., 0] == 255) & (ov[..., 1] == 0) & (ov[..., 2] == 0)
+            assert red.any() and np.array_equal(ov[~red][:, 0], tile[~red])
+        else:
+            assert not (out_dir / f"b{k}.json").exists()
     hostlib.cleanup_resources()

@@ -676,6 +676,41 @@ int mi_unet_extract_contours(mi_unet_t *h, const uint8_t *masks, int B, int32_t 
     return MI_UNET_OK;
 }
 
+}  // extern "C"
+
+namespace {
+// upload + min/max + resample `bm` RAW images into h->d_img (one staging buffer: serialised per image)
+int stage_raw16(mi_unet *h, const uint16_t *const *raws, const int *widths, const int *heights, int bm)
+{
+    const size_t hw = (size_t)h->cfg.height * h->cfg.width;
+    hipStream_t s = h->stream;
+    if (!h->d_mnmx) HIP_TRY(hipMalloc(&h->d_mnmx, sizeof(unsigned) * 2 * h->cfg.max_batch));
+    for (int i = 0; i < bm; ++i) {
+        const int w = widths[i], ht = heights[i];
+        if (!raws[i] || w <= 0 || ht <= 0) return fail(MI_UNET_EARG, "RAW16 input: bad image description");
+        const size_t n = (size_t)w * ht;
+        if (n > h->raw_cap) {                    // grow the staging pair (outside any captured region)
+            HIP_TRY(hipStreamSynchronize(s));
+            if (h->d_raw) HIP_TRY(hipFree(h->d_raw));
+            if (h->h_raw) HIP_TRY(hipHostFree(h->h_raw));
+            h->d_raw = nullptr; h->h_raw = nullptr; h->raw_cap = 0;
+            HIP_TRY(hipMalloc(&h->d_raw, n * sizeof(uint16_t)));
+            HIP_TRY(hipHostMalloc(&h->h_raw, n * sizeof(uint16_t), hipHostMallocDefault));
+            h->raw_cap = n;
+        }
+        HIP_TRY(hipStreamSynchronize(s));        // the previous image's kernels must have consumed the staging buffer
+        memcpy(h->h_raw, raws[i], n * sizeof(uint16_t));
+        HIP_TRY(hipMemcpyAsync(h->d_raw, h->h_raw, n * sizeof(uint16_t), hipMemcpyHostToDevice, s));
+        hipError_t e = launch_minmax_u16(h->d_raw, n, h->d_mnmx + 2 * i, s);
+        if (e == hipSuccess) e = launch_resample_u8(h->d_raw, w, ht, h->d_mnmx + 2 * i, h->d_img + i * hw, h->cfg.width, h->cfg.height, s);
+        if (e != hipSuccess) return fail(MI_UNET_EHIP, std::string("preprocess launch: ") + hipGetErrorString(e));
+    }
+    return 0;
+}
+}  // namespace
+
+extern "C" {
+
 int mi_unet_infer_raw16(mi_unet_t *h, const uint16_t *const *raws, const int *widths, const int *heights, int B,
                         uint8_t *tiles, uint8_t *labels, float *logits)
 {
@@ -685,30 +720,9 @@ int mi_unet_infer_raw16(mi_unet_t *h, const uint16_t *const *raws, const int *wi
     HIP_TRY(hipSetDevice(h->cfg.device));
     const size_t hw = (size_t)h->cfg.height * h->cfg.width;
     hipStream_t s = h->stream;
-    if (!h->d_mnmx) HIP_TRY(hipMalloc(&h->d_mnmx, sizeof(unsigned) * 2 * h->cfg.max_batch));
     for (int b0 = 0; b0 < B; b0 += h->cfg.max_batch) {
         const int bm = (B - b0) < h->cfg.max_batch ? (B - b0) : h->cfg.max_batch;
-        for (int i = 0; i < bm; ++i) {
-            const int w = widths[b0 + i], ht = heights[b0 + i];
-            if (!raws[b0 + i] || w <= 0 || ht <= 0) return fail(MI_UNET_EARG, "mi_unet_infer_raw16: bad image description");
-            const size_t n = (size_t)w * ht;
-            if (n > h->raw_cap) {                    // grow the staging pair (outside any captured region)
-                HIP_TRY(hipStreamSynchronize(s));
-                if (h->d_raw) HIP_TRY(hipFree(h->d_raw));
-                if (h->h_raw) HIP_TRY(hipHostFree(h->h_raw));
-                h->d_raw = nullptr; h->h_raw = nullptr; h->raw_cap = 0;
-                HIP_TRY(hipMalloc(&h->d_raw, n * sizeof(uint16_t)));
-                HIP_TRY(hipHostMalloc(&h->h_raw, n * sizeof(uint16_t), hipHostMallocDefault));
-                h->raw_cap = n;
-            }
-            // one staging buffer: the previous image's kernels must have consumed it before it is overwritten
-            HIP_TRY(hipStreamSynchronize(s));
-            memcpy(h->h_raw, raws[b0 + i], n * sizeof(uint16_t));
-            HIP_TRY(hipMemcpyAsync(h->d_raw, h->h_raw, n * sizeof(uint16_t), hipMemcpyHostToDevice, s));
-            hipError_t e = launch_minmax_u16(h->d_raw, n, h->d_mnmx + 2 * i, s);
-            if (e == hipSuccess) e = launch_resample_u8(h->d_raw, w, ht, h->d_mnmx + 2 * i, h->d_img + i * hw, h->cfg.width, h->cfg.height, s);
-            if (e != hipSuccess) return fail(MI_UNET_EHIP, std::string("preprocess launch: ") + hipGetErrorString(e));
-        }
+        if (int rc = stage_raw16(h, raws + b0, widths + b0, heights + b0, bm)) return rc;
         if (int rc = infer_microbatch(h, h->d_img, bm, h->d_labels, logits ? h->d_logits : nullptr)) return rc;
         if (tiles) HIP_TRY(hipMemcpyAsync(tiles + b0 * hw, h->d_img, bm * hw, hipMemcpyDeviceToHost, s));
         HIP_TRY(hipMemcpyAsync(h->h_labels, h->d_labels, bm * hw, hipMemcpyDeviceToHost, s));
@@ -717,6 +731,51 @@ int mi_unet_infer_raw16(mi_unet_t *h, const uint16_t *const *raws, const int *wi
                                    hipMemcpyDeviceToHost, s));
         HIP_TRY(hipStreamSynchronize(s));
         memcpy(labels + b0 * hw, h->h_labels, bm * hw);
+    }
+    return MI_UNET_OK;
+}
+
+int mi_unet_segment_raw16(mi_unet_t *h, const uint16_t *const *raws, const int *widths, const int *heights, int B,
+                          uint8_t *tiles, uint8_t *masks, int32_t *xy, int cap_points, int32_t *start, int cap_contours,
+                          int32_t *counts)
+{
+    if (int rc = check_handle(h, true)) return rc;
+    if (!raws || !widths || !heights || !masks || !xy || !start || !counts || B < 0 || cap_points <= 0 || cap_contours <= 0)
+        return fail(MI_UNET_EARG, "mi_unet_segment_raw16: bad argument");
+    if (h->cfg.in_ch != 1) return fail(MI_UNET_EARG, "mi_unet_segment_raw16 needs a single-channel engine");
+    HIP_TRY(hipSetDevice(h->cfg.device));
+    const int H = h->cfg.height, W = h->cfg.width;
+    const size_t hw = (size_t)H * W;
+    const size_t scratch = sizeof(float) * (size_t)h->cfg.max_batch * hw * h->ch[0];
+    hipStream_t s = h->stream;
+    for (int b0 = 0; b0 < B; b0 += h->cfg.max_batch) {
+        const int bm = (B - b0) < h->cfg.max_batch ? (B - b0) : h->cfg.max_batch;
+        if (contour_workspace_bytes(bm, H, W, cap_contours) > scratch)
+            return fail(MI_UNET_EARG, "contour workspace does not fit the scratch buffer (cap_contours too large)");
+        const size_t need = (size_t)bm * ((size_t)cap_points * 2 + cap_contours + 1 + 1);
+        if (need > h->cont_cap) {
+            HIP_TRY(hipStreamSynchronize(s));
+            if (h->d_cont) HIP_TRY(hipFree(h->d_cont));
+            h->d_cont = nullptr; h->cont_cap = 0;
+            HIP_TRY(hipMalloc(&h->d_cont, need * sizeof(int)));
+            h->cont_cap = need;
+        }
+        int *d_xy = h->d_cont, *d_start = d_xy + (size_t)bm * cap_points * 2, *d_count = d_start + (size_t)bm * (cap_contours + 1);
+        if (int rc = stage_raw16(h, raws + b0, widths + b0, heights + b0, bm)) return rc;
+        if (int rc = run_microbatch(h, h->d_img, bm, h->d_labels, nullptr)) return rc;          // UNet + argmax
+        if (int rc = device_postprocess(h, h->d_labels, h->d_labels, bm)) return rc;             // {0, 2}
+        uint8_t *d_vis = reinterpret_cast<uint8_t *>(h->d_s0);                                   // s0 is free after the head
+        hipError_t e = launch_mask_to_image(h->d_labels, d_vis, bm * hw, s);
+        if (e == hipSuccess)
+            e = launch_extract_contours(d_vis, bm, H, W, d_xy, cap_points, d_start, cap_contours, d_count, h->d_s1, s);
+        if (e != hipSuccess) return fail(MI_UNET_EHIP, std::string("segment launch: ") + hipGetErrorString(e));
+        if (tiles) HIP_TRY(hipMemcpyAsync(tiles + b0 * hw, h->d_img, bm * hw, hipMemcpyDeviceToHost, s));
+        HIP_TRY(hipMemcpyAsync(h->h_labels, d_vis, bm * hw, hipMemcpyDeviceToHost, s));
+        HIP_TRY(hipMemcpyAsync(xy + (size_t)b0 * cap_points * 2, d_xy, sizeof(int) * (size_t)bm * cap_points * 2, hipMemcpyDeviceToHost, s));
+        HIP_TRY(hipMemcpyAsync(start + (size_t)b0 * (cap_contours + 1), d_start, sizeof(int) * (size_t)bm * (cap_contours + 1), hipMemcpyDeviceToHost, s));
+        HIP_TRY(hipMemcpyAsync(counts + b0, d_count, sizeof(int) * bm, hipMemcpyDeviceToHost, s));
+        HIP_TRY(hipStreamSynchronize(s));
+        memcpy(masks + b0 * hw, h->h_labels, bm * hw);
     }
     return MI_UNET_OK;
 }

@@ -78,6 +78,8 @@ hipError_t launch_postprocess_masks(const uint8_t *labels_in, uint8_t *labels_ou
 //   out_start  int32 [B][cap_contours+1]  first point of contour c; entry n_contours = total points
 //   out_count  int32 [B]                  number of contours, or -1 when a capacity was too small
 // Workspace: contour_workspace_bytes(B, H, W, cap_contours).
+// mask_to_image (src/process.cpp:178-185): 0 -> 0, 1 -> 128, 2 -> 255, anything else -> 0
+hipError_t launch_mask_to_image(const uint8_t *labels, uint8_t *vis, size_t n, hipStream_t s);
 size_t contour_workspace_bytes(int B, int H, int W, int cap_contours);
 hipError_t launch_extract_contours(const uint8_t *masks, int B, int H, int W, int *out_xy, int cap_points, int *out_start,
                                    int cap_contours, int *out_count, void *ws, hipStream_t s);

@@ -1342,6 +1342,20 @@ __global__ __launch_bounds__(64) void k_offsets(const int *__restrict__ npts, co
 
 }  // namespace ct
 
+__global__ __launch_bounds__(256) void mask_to_image_kernel(const uint8_t *__restrict__ labels, uint8_t *vis, size_t n)
+{
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const unsigned v = labels[i];
+    vis[i] = v == 1 ? 128 : v == 2 ? 255 : 0;
+}
+
+hipError_t launch_mask_to_image(const uint8_t *labels, uint8_t *vis, size_t n, hipStream_t s)
+{
+    hipLaunchKernelGGL(mask_to_image_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, labels, vis, n);
+    return hipGetLastError();
+}
+
 size_t contour_workspace_bytes(int B, int H, int W, int cap_contours)
 {
     const size_t n = (size_t)B * H * W;

@@ -140,6 +140,13 @@ bool host_preprocess_requested()
     return e && e[0] == '1';
 }
 
+// extract_contours runs on the device behind postprocess_mask unless MEDSEG_HOST_CONTOURS=1
+bool device_contours_requested()
+{
+    const char *e = std::getenv("MEDSEG_HOST_CONTOURS");
+    return !(e && e[0] == '1');
+}
+
 // postprocess_mask runs on the device right behind the argmax unless MEDSEG_HOST_POSTPROCESS=1
 bool device_postprocess_requested()
 {
@@ -178,6 +185,53 @@ int process_image_batch(const std::vector<std::string> &raw_paths, const std::ve
         std::vector<uint8_t> tiles(hw * idx.size()), labels(hw * idx.size());
         const auto t0 = std::chrono::high_resolution_clock::now();
         const bool dev_post = device_postprocess_requested();
+        if (dev_post && device_contours_requested() && !idx.empty()) {
+            // every device-capable stage in ONE call: preprocess, UNet, argmax, postprocess_mask, mask_to_image, contours
+            const int cap_points = 1 << 15, cap_contours = 64;     // postprocess keeps components >= 6 % of the tile: <= 16
+            std::vector<int32_t> xy((size_t)idx.size() * cap_points * 2), start((size_t)idx.size() * (cap_contours + 1)), cnt(idx.size());
+            {
+                std::lock_guard<std::mutex> lk(g_infer_mutex);
+                if (mi_unet_segment_raw16(g_engine, ptrs.data(), ws.data(), hs.data(), (int)idx.size(), tiles.data(), labels.data(),
+                                          xy.data(), cap_points, start.data(), cap_contours, cnt.data()) != MI_UNET_OK)
+                    throw std::runtime_error(std::string("Inference failed: ") + mi_unet_last_error());
+            }
+            const auto ms = std::chrono::duration_cast<std::chrono::milliseconds>(std::chrono::high_resolution_clock::now() - t0).count();
+            if (log_file.is_open()) log_file << "Batch device time: " << ms << " ms for " << idx.size() << " images" << std::endl;
+            for (size_t k = 0; k < idx.size(); ++k) {
+                const size_t i = idx[k];
+                try {
+                    const std::string base_name = fs::path(raw_paths[i]).stem().string();
+                    if (log_file.is_open())
+                        log_file << "\n=== Processing Image: " << fs::path(raw_paths[i]).filename().string() << " ===" << std::endl;
+                    Image8 tile(g_cfg.height, g_cfg.width, 1), vis(g_cfg.height, g_cfg.width, 1);
+                    std::copy(tiles.begin() + k * hw, tiles.begin() + (k + 1) * hw, tile.data.begin());
+                    std::copy(labels.begin() + k * hw, labels.begin() + (k + 1) * hw, vis.data.begin());
+                    if (!Preprocess::write_preprocess_outputs(tile, raw_paths[i], output_dir + "/" + base_name + "_normalized.png",
+                                                              output_dir + "/" + base_name + "_original_sizes.json", widths[i], heights[i]))
+                        throw std::runtime_error("Preprocessing failed");
+                    if (!medseg::write_png(output_dir + "/" + base_name + "_mask.png", vis, /*level0=*/true))
+                        throw std::runtime_error("Failed to save mask");
+                    std::vector<medseg::Contour> contours;
+                    if (cnt[k] < 0) {                      // capacity overflow on the device: fall back to the host tracer
+                        contours = Mask2Polygon::extract_contours(vis);
+                    } else {
+                        const int32_t *st = &start[k * (cap_contours + 1)], *pts = &xy[k * (size_t)cap_points * 2];
+                        for (int c = 0; c < cnt[k]; ++c) {
+                            medseg::Contour cc;
+                            for (int q = st[c]; q < st[c + 1]; ++q) cc.emplace_back(pts[2 * q], pts[2 * q + 1]);
+                            contours.push_back(std::move(cc));
+                        }
+                    }
+                    Mask2Polygon::write_polygon_outputs(contours, tile, output_dir, base_name, widths[i], heights[i]);
+                    if (log_file.is_open()) log_file << "Processing completed for: " << base_name << std::endl;
+                    ++ok;
+                } catch (const std::exception &e) {
+                    std::cerr << "Processing error: " << e.what() << std::endl;
+                    if (log_file.is_open()) log_file << "Processing error: " << e.what() << std::endl;
+                }
+            }
+            return ok;
+        }
         {
             std::lock_guard<std::mutex> lk(g_infer_mutex);
             mi_unet_set_postprocess(g_engine, dev_post ? 1 : 0);

@@ -175,15 +175,51 @@ void generate_json(const std::vector<Contour> &contours, const std::string &json
     f.flush();
 }
 
-void create_overlay_image(const std::vector<Contour> &contours, const std::string &original_png_path,
-                          const std::string &overlay_path)
+Image8 draw_overlay(const Image8 &src, const std::vector<Contour> &contours)
 {
-    Image8 img = medseg::read_png(original_png_path, /*as_color=*/true);
-    if (img.empty()) throw std::runtime_error("Fail to Read Original Image: " + original_png_path);
+    Image8 img(src.rows, src.cols, 3);
+    for (int y = 0; y < src.rows; ++y)
+        for (int x = 0; x < src.cols; ++x)
+            for (int c = 0; c < 3; ++c) img.at(y, x, c) = src.at(y, x, src.channels == 3 ? c : 0);
     const uint8_t red_bgr[3] = { 0, 0, 255 };                         // cv::Scalar(0, 0, 255), src/mask2polygon.cpp:10
     for (const Contour &c : contours)                                 // drawContours(-1, thickness 1): closed polylines
         for (size_t k = 0; k < c.size(); ++k) draw_segment(img, c[k], c[(k + 1) % c.size()], red_bgr);
-    if (!medseg::write_png(overlay_path, img, /*level0=*/false)) throw std::runtime_error("Fail to Save Overlay PNG: " + overlay_path);
+    return img;
+}
+
+void create_overlay_image(const std::vector<Contour> &contours, const std::string &original_png_path,
+                          const std::string &overlay_path)
+{
+    const Image8 img = medseg::read_png(original_png_path, /*as_color=*/true);
+    if (img.empty()) throw std::runtime_error("Fail to Read Original Image: " + original_png_path);
+    if (!medseg::write_png(overlay_path, draw_overlay(img, contours), /*level0=*/false))
+        throw std::runtime_error("Fail to Save Overlay PNG: " + overlay_path);
+}
+
+void write_polygon_outputs(const std::vector<Contour> &contours, const Image8 &normalized_tile, const std::string &output_dir,
+                           const std::string &base_name, int original_width, int original_height)
+{
+    try {
+        std::cout << "Processing Mask: " << base_name + ".png" << std::endl;
+        std::cout << "Original Size: " << original_width << "x" << original_height << std::endl;
+        std::cout << "Scaled Size: " << normalized_tile.cols << "x" << normalized_tile.rows << std::endl;
+        if (contours.empty()) {
+            std::cout << "Warning: No Contours Detected" << std::endl;
+            return;
+        }
+        std::cout << "Extracted " << contours.size() << " Contours" << std::endl;
+        const std::string overlay_path = output_dir + "/" + base_name + "_contour_overlay.png";
+        if (!medseg::write_png(overlay_path, draw_overlay(normalized_tile, contours), /*level0=*/false))
+            throw std::runtime_error("Fail to Save Overlay PNG: " + overlay_path);
+        std::cout << "Overlay Image Saved to: " << overlay_path << std::endl;
+        const double scale_x = static_cast<double>(original_width) / normalized_tile.cols;
+        const double scale_y = static_cast<double>(original_height) / normalized_tile.rows;
+        const std::string output_json_path = output_dir + "/" + base_name + ".json";
+        generate_json(map_contour_points(contours, scale_x, scale_y), output_json_path, base_name, original_width, original_height);
+        std::cout << "JSON Saved to: " << output_json_path << std::endl;
+    } catch (const std::exception &e) {
+        std::cerr << "Processing Failure: " << e.what() << std::endl;
+    }
 }
 
 void process_single_mask(const std::string &mask_path, const std::string &output_dir, const std::string &json_path,

@@ -15,7 +15,7 @@ LIB_PATH = os.path.join(PKG_DIR, "libmiunet.so")
 
 EXPORTS = [
     "mi_unet_default_config", "mi_unet_create", "mi_unet_load_weights", "mi_unet_load_weights_from_memory",
-    "mi_unet_infer_u8", "mi_unet_infer_u8_device", "mi_unet_infer_raw16", "mi_unet_set_postprocess", "mi_unet_postprocess_masks", "mi_unet_extract_contours", "mi_unet_set_stream", "mi_unet_sync", "mi_unet_timer_begin",
+    "mi_unet_infer_u8", "mi_unet_infer_u8_device", "mi_unet_infer_raw16", "mi_unet_set_postprocess", "mi_unet_postprocess_masks", "mi_unet_extract_contours", "mi_unet_segment_raw16", "mi_unet_set_stream", "mi_unet_sync", "mi_unet_timer_begin",
     "mi_unet_timer_end", "mi_unet_set_profiling", "mi_unet_get_kernel_stats", "mi_unet_layer_debug", "mi_unet_destroy",
     "mi_unet_last_error", "mi_unet_device_count",
 ]
@@ -58,6 +58,8 @@ def lib():
         L.mi_unet_set_postprocess.argtypes = [C.c_void_p, C.c_int]
         L.mi_unet_postprocess_masks.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]
         L.mi_unet_extract_contours.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p]
+        L.mi_unet_segment_raw16.argtypes = [C.c_void_p, C.POINTER(C.c_void_p), C.POINTER(C.c_int), C.POINTER(C.c_int), C.c_int,
+                                            C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p]
         L.mi_unet_set_stream.argtypes = [C.c_void_p, C.c_void_p]
         L.mi_unet_sync.argtypes = [C.c_void_p]
         L.mi_unet_timer_begin.argtypes = [C.c_void_p]
@@ -177,6 +179,26 @@ class Engine:
                 continue
             out.append([[tuple(p) for p in xy[i, start[i, c]:start[i, c + 1]].tolist()] for c in range(counts[i])])
         return out
+
+    def segment_raw16(self, raws, cap_points=8192, cap_contours=64):
+        """RAW16 images -> (tiles, mask images 0/255, contours per image) with every stage on the device"""
+        raws = [np.ascontiguousarray(r, dtype=np.uint16) for r in raws]
+        b, c = len(raws), self.cfg
+        ptrs = (C.c_void_p * b)(*[r.ctypes.data for r in raws])
+        ws = (C.c_int * b)(*[r.shape[1] for r in raws])
+        hs = (C.c_int * b)(*[r.shape[0] for r in raws])
+        tiles = np.empty((b, c.height, c.width), np.uint8)
+        masks = np.empty((b, c.height, c.width), np.uint8)
+        xy = np.zeros((b, cap_points, 2), np.int32)
+        start = np.zeros((b, cap_contours + 1), np.int32)
+        counts = np.zeros(b, np.int32)
+        _check(lib().mi_unet_segment_raw16(self._h, ptrs, ws, hs, b, _ptr(tiles), _ptr(masks), _ptr(xy), cap_points, _ptr(start),
+                                           cap_contours, _ptr(counts)))
+        cont = []
+        for i in range(b):
+            cont.append(None if counts[i] < 0 else
+                        [[tuple(p) for p in xy[i, start[i, k]:start[i, k + 1]].tolist()] for k in range(counts[i])])
+        return tiles, masks, cont
 
     def infer_device(self, d_imgs_ptr: int, b: int, d_labels_ptr: int, d_logits_ptr: int = 0):
         _check(lib().mi_unet_infer_u8_device(self._h, C.c_void_p(d_imgs_ptr), b, C.c_void_p(d_labels_ptr),
