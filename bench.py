@@ -28,6 +28,7 @@ from miunet import binding, shard, synth  # noqa: E402
 from miunet.spec import UNetSpec, pack_weights  # noqa: E402
 
 FP32_PEAK_TFLOPS = 157.3      # MI355X_MICROARCH.md: fp32 matrix peak (v_mfma_f32_32x32x2_f32)
+BF16_PEAK_TFLOPS = 2500.0     # dense bf16 MFMA peak (v_mfma_f32_32x32x16_bf16)
 HBM_PEAK_GBS = 8000.0
 
 
@@ -76,7 +77,7 @@ def main():
     ap.add_argument("--size", type=int, default=512)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--per-layer", action="store_true", help="also print a per-layer table to stderr")
-    ap.add_argument("--conv-algo", choices=["auto", "direct", "winograd", "winograd16"], default="auto")
+    ap.add_argument("--conv-algo", choices=["auto", "direct", "winograd", "winograd16", "bf16"], default="auto")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -151,14 +152,16 @@ def main():
         images = B * world * args.steps
         ips = images / dt
         # dominant kernel: the fp32 MFMA implicit-GEMM conv (17 launches per step, 97 % of the FLOPs)
-        dom = [s for s in stats if s["kernel"] in ("conv3x3_mfma", "conv3x3_wino", "conv3x3_wino16")]
+        dom = [s for s in stats if s["kernel"] in ("conv3x3_mfma", "conv3x3_wino", "conv3x3_wino16", "conv3x3_bf16")]
         dom_kernel = dom[0]["kernel"] if dom else "conv3x3_mfma"
         dom_flops = sum(s["flops"] for s in dom)
         dom_ms = sum(s["ms"] for s in dom)
         all_ms = sum(s["ms"] for s in stats)
         achieved = dom_flops / (dom_ms * 1e-3) / 1e12
+        is_bf16 = dom_kernel == "conv3x3_bf16"
+        peak = BF16_PEAK_TFLOPS if is_bf16 else FP32_PEAK_TFLOPS
         out = {
-            "metric": "images/sec, 512x512 UNet fp32 inference (u8 tile -> u8 label map)",
+            "metric": "images/sec, 512x512 UNet %s inference (u8 tile -> u8 label map)" % ("bf16-operand / fp32-accumulate" if is_bf16 else "fp32"),
             "value": ips,
             "unit": "images/s",
             "n_gpus": world,
@@ -169,16 +172,16 @@ def main():
             "higher_is_better": True,
             "scaling": "weak",
             "vs_baseline": None,
-            "dtype": "fp32",
+            "dtype": "bf16" if is_bf16 else "fp32",
             "data": "synthetic",
-            "config": {"workload": f"BASELINE.json configs[1]: batch {B} x {H}x{W}x1 u8 per GPU, 4-level UNet base 64, fp32, "
+            "config": {"workload": f"BASELINE.json configs[{2 if is_bf16 else 1}]: batch {B} x {H}x{W}x1 u8 per GPU, 4-level UNet base 64, {'bf16 operands / fp32 accumulate' if is_bf16 else 'fp32'}, "
                                    "argmax label maps", "images_per_gpu_per_step": B, "global_batch": B * world,
                        "parallelism": f"dp{world}" + (" (RCCL weight broadcast + per-step label-map gather)" if world > 1 else "")},
             "roofline": {
-                "bound": "mfma", "kernel": dom_kernel + " (v_mfma_f32_32x32x2_f32)",
+                "bound": "mfma", "kernel": dom_kernel + (" (v_mfma_f32_32x32x16_bf16)" if is_bf16 else " (v_mfma_f32_32x32x2_f32)"),
                 "algorithm": "winograd F(2x2,3x3): achieved counts ALGORITHMIC (direct-convolution) FLOPs, the MFMA pipe "
                              "executes 1/2.25 of them" if dom_kernel.startswith("conv3x3_wino") else "direct implicit GEMM",
-                "achieved": achieved, "peak": FP32_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": achieved / FP32_PEAK_TFLOPS,
+                "achieved": achieved, "peak": peak, "unit": "TFLOP/s", "frac": achieved / peak,
                 "traffic": pmc_traffic({"conv3x3_wino": "miunet::conv3x3_wino_f32<*>", "conv3x3_wino16": "miunet::conv3x3_wino16_f32"}.get(
                     dom_kernel, "miunet::conv_mfma_f32<9, 8, 64, 16, false>")),
                 "launches": len(dom), "avg_launch_ms": dom_ms / max(1, len(dom)),

@@ -249,6 +249,24 @@ static const float *take(cursor *c, size_t n)
     return r;
 }
 
+/* round-to-nearest-even to bfloat16, returned as float (what v_cvt_pk_bf16_f32 / a plain (__bf16) cast produce) */
+static float bf16_round(float x)
+{
+    uint32_t u;
+    memcpy(&u, &x, 4);
+    if ((u & 0x7F800000u) == 0x7F800000u && (u & 0x007FFFFFu)) return x;      /* NaN stays NaN */
+    u = (u + 0x7FFFu + ((u >> 16) & 1u)) & 0xFFFF0000u;
+    memcpy(&x, &u, 4);
+    return x;
+}
+
+/* MODE 0 (default): conv -> BatchNorm -> ReLU exactly as written.
+ * MODE 1 (BASELINE config 3 emulation): BatchNorm folded into the conv the way the engine folds it (scale in double ->
+ *   float weights, shift added after the conv), and -- except for the first layer of the network, which the engine
+ *   computes on the fp32 VALU -- BOTH conv operands rounded to bf16, products and sums in fp32. */
+static int g_mode = 0;
+static int g_first_conv = 0;
+
 /* one [conv3x3 -> BN -> ReLU] x2 block; returns 0 or error; out must hold B*H*W*Cout floats */
 static int double_conv(cursor *cur, const float *in, int B, int H, int W, int Cin, int Cout, float eps, float *tmp,
                        float *out)
@@ -260,8 +278,33 @@ static int double_conv(cursor *cur, const float *in, int B, int H, int W, int Ci
         const float *w = take(cur, (size_t)Cout * ci * 9);
         const float *g = take(cur, Cout), *be = take(cur, Cout), *mu = take(cur, Cout), *va = take(cur, Cout);
         if (!w || !g || !be || !mu || !va) return ORC_EBADFILE;
-        orc_conv3x3(src, B, H, W, ci, w, Cout, dsts[k]);
-        orc_bn_relu(dsts[k], (size_t)B * H * W, Cout, g, be, mu, va, eps, 1);
+        if (g_mode == 0) {
+            orc_conv3x3(src, B, H, W, ci, w, Cout, dsts[k]);
+            orc_bn_relu(dsts[k], (size_t)B * H * W, Cout, g, be, mu, va, eps, 1);
+        } else {
+            const int low = !g_first_conv;                 /* first conv of the network stays fp32 */
+            g_first_conv = 0;
+            const size_t nw = (size_t)Cout * ci * 9, nx = (size_t)B * H * W * ci, npix = (size_t)B * H * W;
+            float *wf = (float *)malloc(sizeof(float) * nw), *shift = (float *)malloc(sizeof(float) * Cout);
+            float *xr = low ? (float *)malloc(sizeof(float) * nx) : NULL;
+            for (int co = 0; co < Cout; ++co) {
+                const double sc = (double)g[co] / sqrt((double)va[co] + (double)eps);
+                shift[co] = (float)((double)be[co] - (double)mu[co] * sc);
+                for (size_t q = 0; q < (size_t)ci * 9; ++q) {
+                    const float f = (float)((double)w[(size_t)co * ci * 9 + q] * sc);
+                    wf[(size_t)co * ci * 9 + q] = low ? bf16_round(f) : f;
+                }
+            }
+            if (low)
+                for (size_t q = 0; q < nx; ++q) xr[q] = bf16_round(src[q]);
+            orc_conv3x3(low ? xr : src, B, H, W, ci, wf, Cout, dsts[k]);
+            for (size_t p = 0; p < npix; ++p)
+                for (int co = 0; co < Cout; ++co) {
+                    float v = dsts[k][p * Cout + co] + shift[co];
+                    dsts[k][p * Cout + co] = v > 0.0f ? v : 0.0f;
+                }
+            free(wf); free(shift); free(xr);
+        }
         src = dsts[k];
         ci = Cout;
     }
@@ -319,7 +362,16 @@ int orc_unet_forward(const void *blob, size_t blob_len, const uint8_t *imgs, int
         const int cin = ch[L - i + 1], cout = cin / 2, lvl = L - i;
         const float *tw = take(&cur, (size_t)cin * cout * 4), *tb = take(&cur, cout);
         if (!tw || !tb) return ORC_EBADFILE;
-        orc_convT2x2(feat, B, h, w, cin, tw, tb, cout, cat[lvl], 2 * cout, cout);
+        if (g_mode == 0) {
+            orc_convT2x2(feat, B, h, w, cin, tw, tb, cout, cat[lvl], 2 * cout, cout);
+        } else {                                            /* bf16 operands, fp32 accumulate, fp32 bias */
+            const size_t nw = (size_t)cin * cout * 4, nx = (size_t)B * h * w * cin;
+            float *wr = (float *)malloc(sizeof(float) * nw), *xr = (float *)malloc(sizeof(float) * nx);
+            for (size_t q = 0; q < nw; ++q) wr[q] = bf16_round(tw[q]);
+            for (size_t q = 0; q < nx; ++q) xr[q] = bf16_round(feat[q]);
+            orc_convT2x2(xr, B, h, w, cin, wr, tb, cout, cat[lvl], 2 * cout, cout);
+            free(wr); free(xr);
+        }
         h *= 2; w *= 2;
         rc = double_conv(&cur, cat[lvl], B, h, w, cin, cout, wf.eps, t1, t2);
         if (rc) return rc;
@@ -339,6 +391,19 @@ int orc_unet_forward(const void *blob, size_t blob_len, const uint8_t *imgs, int
     free(x); free(t1); free(t2);
     return ORC_OK;
 }
+
+/* Same network with bf16 conv operands (see MODE 1 above): the checker for BASELINE config 3. */
+int orc_unet_forward_bf16(const void *blob, size_t blob_len, const uint8_t *imgs, int B, int H, int W, float *logits,
+                          uint8_t *labels, int nthreads)
+{
+    g_mode = 1;
+    g_first_conv = 1;
+    const int rc = orc_unet_forward(blob, blob_len, imgs, B, H, W, logits, labels, nthreads);
+    g_mode = 0;
+    return rc;
+}
+
+float orc_bf16_round(float x) { return bf16_round(x); }
 
 int orc_num_threads(void)
 {

@@ -27,6 +27,10 @@ def lib():
         L = C.CDLL(so)
         L.orc_unet_forward.argtypes = [C.c_void_p, C.c_size_t, _u8p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_int]
         L.orc_unet_forward.restype = C.c_int
+        L.orc_unet_forward_bf16.argtypes = L.orc_unet_forward.argtypes
+        L.orc_unet_forward_bf16.restype = C.c_int
+        L.orc_bf16_round.argtypes = [C.c_float]
+        L.orc_bf16_round.restype = C.c_float
         L.orc_num_threads.restype = C.c_int
         L.orc_normalize_u8.argtypes = [_u8p, C.c_size_t, _f32p]
         L.orc_argmax_planar.argtypes = [_f32p, C.c_int, C.c_size_t, _u8p]
@@ -47,8 +51,16 @@ def lib():
     return _LIB
 
 
-def unet_forward(blob: bytes, imgs: np.ndarray, want_logits=True, nthreads=0):
-    """imgs u8 [B,H,W,C] -> (logits f32 [B,classes,H,W] or None, labels u8 [B,H,W])"""
+def bf16_round(a):
+    """round-to-nearest-even to bfloat16, kept in float32 (numpy mirror of the oracle's bf16_round)"""
+    u = np.ascontiguousarray(a, np.float32).view(np.uint32)
+    r = ((u + np.uint32(0x7FFF) + ((u >> np.uint32(16)) & np.uint32(1))) & np.uint32(0xFFFF0000)).view(np.float32)
+    return r.reshape(np.shape(a))
+
+
+def unet_forward(blob: bytes, imgs: np.ndarray, want_logits=True, nthreads=0, bf16=False):
+    """imgs u8 [B,H,W,C] -> (logits f32 [B,classes,H,W] or None, labels u8 [B,H,W]); bf16=True emulates BASELINE
+    config 3 (bf16 conv operands, fp32 accumulate)"""
     L = lib()
     imgs = np.ascontiguousarray(imgs, dtype=np.uint8)
     b, h, w, _ = imgs.shape
@@ -56,8 +68,9 @@ def unet_forward(blob: bytes, imgs: np.ndarray, want_logits=True, nthreads=0):
     logits = np.empty((b, classes, h, w), np.float32) if want_logits else None
     labels = np.empty((b, h, w), np.uint8)
     buf = C.create_string_buffer(blob, len(blob)) if not isinstance(blob, C.Array) else blob
-    rc = L.orc_unet_forward(C.cast(buf, C.c_void_p), len(blob), imgs, b, h, w,
-                            logits.ctypes.data if want_logits else None, labels.ctypes.data, nthreads)
+    fn = L.orc_unet_forward_bf16 if bf16 else L.orc_unet_forward
+    rc = fn(C.cast(buf, C.c_void_p), len(blob), imgs, b, h, w,
+            logits.ctypes.data if want_logits else None, labels.ctypes.data, nthreads)
     if rc != 0:
         raise RuntimeError(f"orc_unet_forward failed rc={rc}")
     return logits, labels

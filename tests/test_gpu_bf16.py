@@ -1,0 +1,69 @@
+"""BASELINE config 3: bf16 conv operands, fp32 accumulate (MI_UNET_CONV_BF16).  The checker is the oracle's bf16-operand
+mode (same rounding points: weights after BN folding, activations at every MFMA conv input), so the tolerance stays
+tight; the distance to the fp32 network is reported separately."""
+import numpy as np
+import pytest
+
+import oracle_lib as orc
+from miunet import binding, synth
+from miunet.spec import UNetSpec, pack_weights
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("B,H,W,Cin,Cout", [(1, 8, 32, 32, 64), (2, 16, 64, 64, 64), (1, 5, 7, 40, 64), (1, 12, 40, 96, 128),
+                                            (1, 9, 33, 24, 32), (3, 4, 4, 128, 256), (1, 2, 2, 1024, 64)])
+def test_conv3x3_bf16(B, H, W, Cin, Cout):
+    r = np.random.default_rng(B * 1000 + H * 100 + W + Cin + Cout)
+    x = r.standard_normal((B, H, W, Cin), dtype=np.float32)
+    w = (r.standard_normal((Cout, Cin, 3, 3), dtype=np.float32) * np.sqrt(2.0 / (9 * Cin))).astype(np.float32)
+    scale = (1.0 + 0.1 * r.standard_normal(Cout)).astype(np.float32)
+    shift = (0.1 * r.standard_normal(Cout)).astype(np.float32)
+    got = binding.layer_debug("conv3x3_bf16", x, w, scale, shift, relu=True)
+    wf = (w.astype(np.float64) * scale.astype(np.float64)[:, None, None, None]).astype(np.float32)
+    ref = np.maximum(orc.conv3x3(orc.bf16_round(x), orc.bf16_round(wf)) + shift, 0.0)
+    assert not np.isnan(got).any()
+    assert np.max(np.abs(got - ref)) < 1e-4 * max(1.0, float(np.abs(ref).max()))
+
+
+def test_conv3x3_bf16_exact_on_small_integers():
+    r = np.random.default_rng(11)                       # small integers are exact in bf16 and in fp32 sums
+    x = r.integers(-4, 5, (1, 10, 36, 32)).astype(np.float32)
+    w = r.integers(-3, 4, (64, 32, 3, 3)).astype(np.float32)
+    assert np.array_equal(binding.layer_debug("conv3x3_bf16", x, w), orc.conv3x3(x, w))
+
+
+@pytest.mark.parametrize("B,H,W,Cin,Cout", [(1, 8, 32, 64, 32), (2, 4, 4, 128, 64), (1, 3, 5, 1024, 512)])
+def test_convT2x2_bf16(B, H, W, Cin, Cout):
+    r = np.random.default_rng(H * 7 + W + Cin)
+    x = r.standard_normal((B, H, W, Cin), dtype=np.float32)
+    w = (r.standard_normal((Cin, Cout, 2, 2), dtype=np.float32) / np.sqrt(Cin)).astype(np.float32)
+    bias = (0.1 * r.standard_normal(Cout)).astype(np.float32)
+    got = binding.layer_debug("convT2x2_bf16", x, w, None, bias)
+    ref = orc.convT2x2(orc.bf16_round(x), orc.bf16_round(w), bias)
+    assert np.max(np.abs(got - ref)) < 1e-4 * max(1.0, float(np.abs(ref).max()))
+
+
+def test_end_to_end_tolerances():
+    """End to end the bf16-operand network is NOT reproducible to fp32 tolerance by any second implementation: an
+    upstream difference of 1e-7 (summation order, fma contraction) flips some bf16 roundings of the activations and moves
+    the logits by ~6e-3 (measured with the oracle against itself, weights perturbed by 1e-7).  So: each kernel is pinned
+    tightly above on identical inputs, and the whole network is held to the size of the bf16 quantisation noise itself --
+    within 3e-2 of the bf16-operand oracle AND no further from the fp32 oracle than that oracle's own bf16 mode is
+    (x1.5), labels equal wherever the fp32 top-2 margin exceeds 0.1."""
+    spec = UNetSpec()
+    blob = pack_weights(spec, synth.make_weights(spec, 4321))
+    imgs = synth.make_images(3, 128, 128, 1, 0xBEEF, "blobs")
+    ref16, _ = orc.unet_forward(blob, imgs, bf16=True)
+    ref32, lab32 = orc.unet_forward(blob, imgs)
+    with binding.Engine(128, 128, max_batch=2, conv_algo="bf16") as eng:
+        eng.load_weights(blob)
+        labels, logits = eng.infer(imgs, want_logits=True)
+    noise = float(np.max(np.abs(ref16 - ref32)))             # what bf16 operands cost in this network
+    assert 1e-3 < noise < 0.1
+    assert float(np.max(np.abs(logits - ref16))) < 3e-2
+    assert float(np.max(np.abs(logits - ref32))) < 1.5 * noise
+    srt = np.sort(ref32, axis=1)
+    safe = (srt[:, -1] - srt[:, -2]) > 0.1
+    assert safe.mean() > 0.5 and np.array_equal(labels[safe], lab32[safe])
+    assert np.array_equal(labels, np.stack([orc.argmax_planar(l) for l in logits]))    # argmax rule is exact on its own logits

@@ -42,6 +42,12 @@ hipError_t launch_conv3x3_wino(const ConvArgs &a, hipStream_t s);
 hipError_t launch_conv3x3_wino16(const ConvArgs &a, hipStream_t s);
 hipError_t launch_convT2x2_mfma(const ConvArgs &a, hipStream_t s);
 
+// BASELINE config 3: bf16 operands, fp32 accumulate on v_mfma_f32_32x32x16_bf16.  Activations stay fp32 in HBM and are
+// rounded to bf16 (RNE) while they are staged into LDS; a.wpk holds bf16 weights packed [Cin/32][taps][CoutPad][32].
+constexpr int KC_BF16 = 32;
+hipError_t launch_conv3x3_bf16(const ConvArgs &a, hipStream_t s);
+hipError_t launch_convT2x2_bf16(const ConvArgs &a, hipStream_t s);
+
 // First layer: u8 image -> (LUT /255) -> conv3x3 (Cin = 1..4) + shift + ReLU.  w is [9][Cin][Cout] (BN scale folded).
 hipError_t launch_conv3x3_first(const uint8_t *img, const float *lut256, const float *w, const float *shift, float *out,
                                 int B, int H, int W, int Cin, int Cout, int ldo, hipStream_t s);
