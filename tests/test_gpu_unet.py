@@ -143,3 +143,19 @@ def test_graph_replay_matches_eager(monkeypatch):
             assert np.array_equal(lg, runs[0][1])
             res[flag] = runs[0]
     assert np.array_equal(res["0"][1], res["1"][1]) and np.array_equal(res["0"][0], res["1"][0])
+
+
+def test_config5_shape_1024_three_channels_five_levels():
+    """BASELINE config 5's topology (1024x1024x3 input, 5 levels, base 32) through the fp32 engine: one image against the
+    oracle in full, a second one in the batch for independence.  (Its fp16 arithmetic is not built yet: DESIGN.md §9.)"""
+    spec = UNetSpec(3, 32, 5, 3)
+    blob = pack_weights(spec, synth.make_weights(spec, 555))
+    imgs = synth.make_images(2, 1024, 1024, 3, 0xC5, "blobs")
+    with binding.Engine(1024, 1024, 3, 32, 5, 3, max_batch=2) as eng:
+        eng.load_weights(blob)
+        labels, logits = eng.infer(imgs, want_logits=True)
+        l1, g1 = eng.infer(imgs[1:2], want_logits=True)
+    assert np.array_equal(l1[0], labels[1]) and np.array_equal(g1[0], logits[1])
+    ref_logits, ref_labels = orc.unet_forward(blob, imgs[0:1])
+    flips = check_parity(labels[0:1], logits[0:1], ref_logits, ref_labels)
+    assert flips <= 16
