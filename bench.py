@@ -32,24 +32,24 @@ BF16_PEAK_TFLOPS = 2500.0     # dense bf16 MFMA peak (v_mfma_f32_32x32x16_bf16)
 HBM_PEAK_GBS = 8000.0
 
 
-def cpu_baseline(blob, h, w):
+def cpu_baseline(blob, h, w, in_ch=1):
     """Oracle (oracle/liboracle.so: the CPU restatement, kind "port") timed on this host's cores on a bounded sample:
     ONE 512x512 image end to end (normalise + UNet forward + argmax)."""
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import oracle_lib as orc
 
     cores = int(orc.lib().orc_num_threads())
-    probe = synth.make_images(1, h, w, 1, 0x5EED, "bytes")
+    probe = synth.make_images(1, h, w, in_ch, 0x5EED, "bytes")
     t0 = time.perf_counter()
     orc.unet_forward(blob, probe, want_logits=False)                # also pages in the library and the thread pool
     t1 = time.perf_counter() - t0
     n = int(min(32, max(1, np.ceil(20.0 / t1))))                    # bounded sample: about 10-30 s of CPU work
-    imgs = synth.make_images(n, h, w, 1, 0x5EED, "bytes")
+    imgs = synth.make_images(n, h, w, in_ch, 0x5EED, "bytes")
     t0 = time.perf_counter()
     orc.unet_forward(blob, imgs, want_logits=False)
     dt = time.perf_counter() - t0
     return {"value": n / dt, "unit": "images/s", "cores": cores, "kind": "port",
-            "sample": f"{n} image(s) {h}x{w}x1 of the same synthetic workload through oracle/unet_oracle.c "
+            "sample": f"{n} image(s) {h}x{w}x{in_ch} of the same synthetic workload through oracle/unet_oracle.c "
                       f"(normalise + UNet forward + argmax; OpenMP, {cores} threads), {dt:.2f} s",
             "ms_per_image": dt / n * 1e3}
 
@@ -75,9 +75,12 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--batch", type=int, default=16, help="images per GPU per step")
     ap.add_argument("--size", type=int, default=512)
+    ap.add_argument("--in-ch", type=int, default=1)
+    ap.add_argument("--base", type=int, default=64)
+    ap.add_argument("--levels", type=int, default=4)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--per-layer", action="store_true", help="also print a per-layer table to stderr")
-    ap.add_argument("--conv-algo", choices=["auto", "direct", "winograd", "winograd16", "bf16"], default="auto")
+    ap.add_argument("--conv-algo", choices=["auto", "direct", "winograd", "winograd16", "bf16", "fp16"], default="auto")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -101,7 +104,7 @@ def main():
         os.environ.setdefault("MASTER_PORT", "29531")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
-    spec = UNetSpec()
+    spec = UNetSpec(args.in_ch, args.base, args.levels, 3)
     H = W = args.size
     B = args.batch
 
@@ -117,7 +120,7 @@ def main():
     eng.set_stream(stream.cuda_stream)
 
     # ---- this rank's shard of the synthetic batch, resident in HBM before the timed region
-    imgs = torch.from_numpy(synth.make_images(B, H, W, 1, 0x5EED + 1000 * rank, "bytes")).to(dev)
+    imgs = torch.from_numpy(synth.make_images(B, H, W, spec.in_ch, 0x5EED + 1000 * rank, "bytes")).to(dev)
     labels = torch.empty((B, H, W), dtype=torch.uint8, device=dev)
     gathered = [torch.empty_like(labels) for _ in range(world)] if (use_dist and rank == 0) else None
 
@@ -152,16 +155,18 @@ def main():
         images = B * world * args.steps
         ips = images / dt
         # dominant kernel: the fp32 MFMA implicit-GEMM conv (17 launches per step, 97 % of the FLOPs)
-        dom = [s for s in stats if s["kernel"] in ("conv3x3_mfma", "conv3x3_wino", "conv3x3_wino16", "conv3x3_bf16")]
+        dom = [s for s in stats if s["kernel"] in ("conv3x3_mfma", "conv3x3_wino", "conv3x3_wino16", "conv3x3_bf16", "conv3x3_fp16")]
         dom_kernel = dom[0]["kernel"] if dom else "conv3x3_mfma"
         dom_flops = sum(s["flops"] for s in dom)
         dom_ms = sum(s["ms"] for s in dom)
         all_ms = sum(s["ms"] for s in stats)
         achieved = dom_flops / (dom_ms * 1e-3) / 1e12
-        is_bf16 = dom_kernel == "conv3x3_bf16"
+        is_bf16 = dom_kernel in ("conv3x3_bf16", "conv3x3_fp16")
+        lp_name = "fp16" if dom_kernel == "conv3x3_fp16" else "bf16"
+        is_cfg1 = (spec.in_ch, spec.base, spec.levels, H) == (1, 64, 4, 512)
         peak = BF16_PEAK_TFLOPS if is_bf16 else FP32_PEAK_TFLOPS
         out = {
-            "metric": "images/sec, 512x512 UNet %s inference (u8 tile -> u8 label map)" % ("bf16-operand / fp32-accumulate" if is_bf16 else "fp32"),
+            "metric": "images/sec, %s UNet %s inference (u8 tile -> u8 label map)" % (f"{H}x{W}", (lp_name + "-operand / fp32-accumulate") if is_bf16 else "fp32"),
             "value": ips,
             "unit": "images/s",
             "n_gpus": world,
@@ -172,13 +177,14 @@ def main():
             "higher_is_better": True,
             "scaling": "weak",
             "vs_baseline": None,
-            "dtype": "bf16" if is_bf16 else "fp32",
+            "dtype": lp_name if is_bf16 else "fp32",
             "data": "synthetic",
-            "config": {"workload": f"BASELINE.json configs[{2 if is_bf16 else 1}]: batch {B} x {H}x{W}x1 u8 per GPU, 4-level UNet base 64, {'bf16 operands / fp32 accumulate' if is_bf16 else 'fp32'}, "
+            "config": {"workload": (f"BASELINE.json configs[{(2 if is_bf16 else 1) if is_cfg1 else 4}]: " if (is_cfg1 or (spec.in_ch, spec.base, spec.levels, H) == (3, 32, 5, 1024)) else "") +
+                                   f"batch {B} x {H}x{W}x{spec.in_ch} u8 per GPU, {spec.levels}-level UNet base {spec.base}, {(lp_name + ' operands / fp32 accumulate') if is_bf16 else 'fp32'}, "
                                    "argmax label maps", "images_per_gpu_per_step": B, "global_batch": B * world,
                        "parallelism": f"dp{world}" + (" (RCCL weight broadcast + per-step label-map gather)" if world > 1 else "")},
             "roofline": {
-                "bound": "mfma", "kernel": dom_kernel + (" (v_mfma_f32_32x32x16_bf16)" if is_bf16 else " (v_mfma_f32_32x32x2_f32)"),
+                "bound": "mfma", "kernel": dom_kernel + ((" (v_mfma_f32_32x32x16_%s)" % ("f16" if lp_name == "fp16" else "bf16")) if is_bf16 else " (v_mfma_f32_32x32x2_f32)"),
                 "algorithm": "winograd F(2x2,3x3): achieved counts ALGORITHMIC (direct-convolution) FLOPs, the MFMA pipe "
                              "executes 1/2.25 of them" if dom_kernel.startswith("conv3x3_wino") else "direct implicit GEMM",
                 "achieved": achieved, "peak": peak, "unit": "TFLOP/s", "frac": achieved / peak,
@@ -200,7 +206,7 @@ def main():
                 print(f"{name:14s} {k:16s} {ms / n:10.3f} {fl / ms / 1e9:9.1f} {by / ms / 1e6:10.0f}", file=sys.stderr)
             print(f"sum of kernel time per step: {all_ms / args.steps:.3f} ms; wall per step: {dt / args.steps * 1e3:.3f} ms", file=sys.stderr)
         if not args.no_cpu_baseline and world == 1:
-            out["cpu_baseline"] = cpu_baseline(blob, H, W)
+            out["cpu_baseline"] = cpu_baseline(blob, H, W, spec.in_ch)
         else:
             out["cpu_baseline"] = None
         print(json.dumps(out))

@@ -42,7 +42,7 @@ typedef struct mi_unet_config {
     int max_batch;   /* images processed per micro-batch; device buffers are sized for this */
     int device;      /* HIP device ordinal (the reference uses implicit device 0) */
     int conv_algo;   /* 3x3 convolution algorithm, both exact fp32 arithmetic on v_mfma_f32_32x32x2_f32:
-                        MI_UNET_CONV_AUTO (environment MIUNET_CONV_ALGO=direct|winograd|winograd16|bf16, else the default),
+                        MI_UNET_CONV_AUTO (environment MIUNET_CONV_ALGO=direct|winograd|winograd16|bf16|fp16, else the default),
                         MI_UNET_CONV_DIRECT (implicit GEMM, 9 taps), MI_UNET_CONV_WINOGRAD (F(2x2,3x3), 2.25x fewer MACs) */
 } mi_unet_config;
 
@@ -53,6 +53,8 @@ typedef struct mi_unet_config {
 #define MI_UNET_CONV_BF16 4         /* BASELINE config 3: bf16 conv operands (weights packed bf16, activations rounded to
                                        bf16 as they are staged), fp32 accumulate on v_mfma_f32_32x32x16_bf16; activations
                                        stay fp32 in HBM.  NOT the fp32 metric: logits follow the bf16-operand oracle. */
+#define MI_UNET_CONV_FP16 5         /* BASELINE config 5's arithmetic: the same kernels with IEEE half operands
+                                       (v_mfma_f32_32x32x16_f16), fp32 accumulate */
 #define MI_UNET_CONV_DEFAULT MI_UNET_CONV_WINOGRAD
 
 /* Fills *cfg with the reference's constants: 512x512x1, base 64, 4 levels, 3 classes, max_batch 16, device 0. */
@@ -137,7 +139,7 @@ int mi_unet_get_kernel_stats(mi_unet_t *h, mi_unet_kernel_stat *stats, int cap, 
 /* Parity hook: run ONE layer kernel on host NHWC fp32 buffers (uploaded, run, downloaded).
  *   op = "conv3x3"  : in [B][H][W][Cin], w [Cout][Cin][3][3], scale/shift [Cout] (folded BN; NULL = 1/0), relu flag
  *   op = "conv3x3_wino" / "conv3x3_wino16" : the same layer through the Winograd F(2x2,3x3) kernels
- *   op = "conv3x3_bf16" / "convT2x2_bf16"  : the bf16-operand kernels of MI_UNET_CONV_BF16
+ *   op = "conv3x3_bf16" / "convT2x2_bf16" / "conv3x3_fp16" / "convT2x2_fp16" : the 16-bit-operand kernels
  *   op = "convT2x2" : in [B][H][W][Cin], w [Cin][Cout][2][2], shift = bias [Cout]  -> out [B][2H][2W][Cout]
  *   op = "maxpool"  : in [B][H][W][Cin]                                          -> out [B][H/2][W/2][Cin]
  * Weights are given in PyTorch layout exactly as in the weight file. */

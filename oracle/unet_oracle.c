@@ -260,11 +260,43 @@ static float bf16_round(float x)
     return x;
 }
 
+/* round-to-nearest-even to IEEE binary16 (with subnormals, overflow to infinity), returned as float */
+static float fp16_round(float x)
+{
+    uint32_t u;
+    memcpy(&u, &x, 4);
+    const uint32_t sign = u & 0x80000000u;
+    const int e = (int)((u >> 23) & 0xFF) - 127;
+    if (e == 128) return x;                                       /* inf / NaN */
+    if (e > 15) { u = sign | 0x7F800000u; memcpy(&x, &u, 4); return x; }
+    if (e >= -14) {                                               /* keep 10 fraction bits */
+        const uint32_t rem = u & 0x1FFFu;
+        u &= ~0x1FFFu;
+        if (rem > 0x1000u || (rem == 0x1000u && (u & 0x2000u))) u += 0x2000u;
+        if (((u >> 23) & 0xFF) > 127 + 15) u = sign | 0x7F800000u;   /* rounded past 65504: infinity */
+        memcpy(&x, &u, 4);
+        return x;
+    }
+    if (e < -25) { u = sign; memcpy(&x, &u, 4); return x; }
+    {                                                             /* subnormal half: multiples of 2^-24 */
+        const float q = 5.9604644775390625e-08f;                  /* 2^-24 */
+        float a = x < 0 ? -x : x;
+        float n = a / q;                                          /* exact: a is a multiple of 2^-149 well below 2^-14 */
+        float fl = (float)(long long)n;
+        float r = n - fl;
+        if (r > 0.5f || (r == 0.5f && ((long long)fl & 1))) fl += 1.0f;
+        a = fl * q;
+        return x < 0 ? -a : a;
+    }
+}
+
 /* MODE 0 (default): conv -> BatchNorm -> ReLU exactly as written.
  * MODE 1 (BASELINE config 3 emulation): BatchNorm folded into the conv the way the engine folds it (scale in double ->
  *   float weights, shift added after the conv), and -- except for the first layer of the network, which the engine
- *   computes on the fp32 VALU -- BOTH conv operands rounded to bf16, products and sums in fp32. */
+ *   computes on the fp32 VALU -- BOTH conv operands rounded to bf16, products and sums in fp32.
+ * MODE 2: the same with IEEE half operands (BASELINE config 5's arithmetic). */
 static int g_mode = 0;
+static float lp_round(float x) { return g_mode == 2 ? fp16_round(x) : bf16_round(x); }
 static int g_first_conv = 0;
 
 /* one [conv3x3 -> BN -> ReLU] x2 block; returns 0 or error; out must hold B*H*W*Cout floats */
@@ -292,11 +324,11 @@ static int double_conv(cursor *cur, const float *in, int B, int H, int W, int Ci
                 shift[co] = (float)((double)be[co] - (double)mu[co] * sc);
                 for (size_t q = 0; q < (size_t)ci * 9; ++q) {
                     const float f = (float)((double)w[(size_t)co * ci * 9 + q] * sc);
-                    wf[(size_t)co * ci * 9 + q] = low ? bf16_round(f) : f;
+                    wf[(size_t)co * ci * 9 + q] = low ? lp_round(f) : f;
                 }
             }
             if (low)
-                for (size_t q = 0; q < nx; ++q) xr[q] = bf16_round(src[q]);
+                for (size_t q = 0; q < nx; ++q) xr[q] = lp_round(src[q]);
             orc_conv3x3(low ? xr : src, B, H, W, ci, wf, Cout, dsts[k]);
             for (size_t p = 0; p < npix; ++p)
                 for (int co = 0; co < Cout; ++co) {
@@ -367,8 +399,8 @@ int orc_unet_forward(const void *blob, size_t blob_len, const uint8_t *imgs, int
         } else {                                            /* bf16 operands, fp32 accumulate, fp32 bias */
             const size_t nw = (size_t)cin * cout * 4, nx = (size_t)B * h * w * cin;
             float *wr = (float *)malloc(sizeof(float) * nw), *xr = (float *)malloc(sizeof(float) * nx);
-            for (size_t q = 0; q < nw; ++q) wr[q] = bf16_round(tw[q]);
-            for (size_t q = 0; q < nx; ++q) xr[q] = bf16_round(feat[q]);
+            for (size_t q = 0; q < nw; ++q) wr[q] = lp_round(tw[q]);
+            for (size_t q = 0; q < nx; ++q) xr[q] = lp_round(feat[q]);
             orc_convT2x2(xr, B, h, w, cin, wr, tb, cout, cat[lvl], 2 * cout, cout);
             free(wr); free(xr);
         }
@@ -403,7 +435,18 @@ int orc_unet_forward_bf16(const void *blob, size_t blob_len, const uint8_t *imgs
     return rc;
 }
 
+int orc_unet_forward_fp16(const void *blob, size_t blob_len, const uint8_t *imgs, int B, int H, int W, float *logits,
+                          uint8_t *labels, int nthreads)
+{
+    g_mode = 2;
+    g_first_conv = 1;
+    const int rc = orc_unet_forward(blob, blob_len, imgs, B, H, W, logits, labels, nthreads);
+    g_mode = 0;
+    return rc;
+}
+
 float orc_bf16_round(float x) { return bf16_round(x); }
+float orc_fp16_round(float x) { return fp16_round(x); }
 
 int orc_num_threads(void)
 {

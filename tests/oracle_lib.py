@@ -29,6 +29,10 @@ def lib():
         L.orc_unet_forward.restype = C.c_int
         L.orc_unet_forward_bf16.argtypes = L.orc_unet_forward.argtypes
         L.orc_unet_forward_bf16.restype = C.c_int
+        L.orc_unet_forward_fp16.argtypes = L.orc_unet_forward.argtypes
+        L.orc_unet_forward_fp16.restype = C.c_int
+        L.orc_fp16_round.argtypes = [C.c_float]
+        L.orc_fp16_round.restype = C.c_float
         L.orc_bf16_round.argtypes = [C.c_float]
         L.orc_bf16_round.restype = C.c_float
         L.orc_num_threads.restype = C.c_int
@@ -58,7 +62,12 @@ def bf16_round(a):
     return r.reshape(np.shape(a))
 
 
-def unet_forward(blob: bytes, imgs: np.ndarray, want_logits=True, nthreads=0, bf16=False):
+def fp16_round(a):
+    """round-to-nearest-even to IEEE binary16, kept in float32 (numpy's own conversion)"""
+    return np.asarray(a, np.float32).astype(np.float16).astype(np.float32)
+
+
+def unet_forward(blob: bytes, imgs: np.ndarray, want_logits=True, nthreads=0, bf16=False, fp16=False):
     """imgs u8 [B,H,W,C] -> (logits f32 [B,classes,H,W] or None, labels u8 [B,H,W]); bf16=True emulates BASELINE
     config 3 (bf16 conv operands, fp32 accumulate)"""
     L = lib()
@@ -68,7 +77,7 @@ def unet_forward(blob: bytes, imgs: np.ndarray, want_logits=True, nthreads=0, bf
     logits = np.empty((b, classes, h, w), np.float32) if want_logits else None
     labels = np.empty((b, h, w), np.uint8)
     buf = C.create_string_buffer(blob, len(blob)) if not isinstance(blob, C.Array) else blob
-    fn = L.orc_unet_forward_bf16 if bf16 else L.orc_unet_forward
+    fn = L.orc_unet_forward_bf16 if bf16 else L.orc_unet_forward_fp16 if fp16 else L.orc_unet_forward
     rc = fn(C.cast(buf, C.c_void_p), len(blob), imgs, b, h, w,
             logits.ctypes.data if want_logits else None, labels.ctypes.data, nthreads)
     if rc != 0:

@@ -67,3 +67,48 @@ def test_end_to_end_tolerances():
     safe = (srt[:, -1] - srt[:, -2]) > 0.1
     assert safe.mean() > 0.5 and np.array_equal(labels[safe], lab32[safe])
     assert np.array_equal(labels, np.stack([orc.argmax_planar(l) for l in logits]))    # argmax rule is exact on its own logits
+
+
+# ---------------------------------------------------------------- fp16 operands (BASELINE config 5's arithmetic)
+@pytest.mark.parametrize("B,H,W,Cin,Cout", [(1, 8, 32, 32, 64), (1, 5, 7, 40, 32), (2, 4, 4, 128, 256)])
+def test_conv3x3_fp16(B, H, W, Cin, Cout):
+    r = np.random.default_rng(B + H + W + Cin + Cout)
+    x = r.standard_normal((B, H, W, Cin), dtype=np.float32)
+    w = (r.standard_normal((Cout, Cin, 3, 3), dtype=np.float32) * np.sqrt(2.0 / (9 * Cin))).astype(np.float32)
+    scale = (1.0 + 0.1 * r.standard_normal(Cout)).astype(np.float32)
+    shift = (0.1 * r.standard_normal(Cout)).astype(np.float32)
+    got = binding.layer_debug("conv3x3_fp16", x, w, scale, shift, relu=True)
+    wf = (w.astype(np.float64) * scale.astype(np.float64)[:, None, None, None]).astype(np.float32)
+    ref = np.maximum(orc.conv3x3(orc.fp16_round(x), orc.fp16_round(wf)) + shift, 0.0)
+    assert np.max(np.abs(got - ref)) < 1e-4 * max(1.0, float(np.abs(ref).max()))
+
+
+def test_convT2x2_fp16():
+    r = np.random.default_rng(9)
+    x = r.standard_normal((1, 6, 10, 64), dtype=np.float32)
+    w = (r.standard_normal((64, 32, 2, 2), dtype=np.float32) / 8).astype(np.float32)
+    bias = (0.1 * r.standard_normal(32)).astype(np.float32)
+    got = binding.layer_debug("convT2x2_fp16", x, w, None, bias)
+    ref = orc.convT2x2(orc.fp16_round(x), orc.fp16_round(w), bias)
+    assert np.max(np.abs(got - ref)) < 1e-4 * max(1.0, float(np.abs(ref).max()))
+
+
+def test_config5_fp16_1024_three_channels_five_levels():
+    """BASELINE config 5: 1024x1024x3, 5 levels, base 32, fp16 operands / fp32 accumulate.  fp16 carries 11 significant
+    bits, so its rounding-flip noise is 8x smaller than bf16's: held to 5e-3 of the fp16-operand oracle and 1.5x that
+    oracle's own distance to the fp32 network."""
+    spec = UNetSpec(3, 32, 5, 3)
+    blob = pack_weights(spec, synth.make_weights(spec, 555))
+    imgs = synth.make_images(1, 1024, 1024, 3, 0xC5, "blobs")
+    ref16, _ = orc.unet_forward(blob, imgs, fp16=True)
+    ref32, lab32 = orc.unet_forward(blob, imgs)
+    with binding.Engine(1024, 1024, 3, 32, 5, 3, max_batch=1, conv_algo="fp16") as eng:
+        eng.load_weights(blob)
+        labels, logits = eng.infer(imgs, want_logits=True)
+    noise = float(np.max(np.abs(ref16 - ref32)))
+    assert 1e-5 < noise < 2e-2
+    assert float(np.max(np.abs(logits - ref16))) < 5e-3
+    assert float(np.max(np.abs(logits - ref32))) < 1.5 * noise + 1e-3
+    srt = np.sort(ref32, axis=1)
+    safe = (srt[:, -1] - srt[:, -2]) > 2e-2
+    assert np.array_equal(labels[safe], lab32[safe])

@@ -146,24 +146,53 @@ uint16_t bf16_bits(float x)
     return (uint16_t)((u + 0x7FFFu + ((u >> 16) & 1u)) >> 16);
 }
 
-// conv3x3 (PyTorch [Cout][Cin][3][3], per-channel scale) -> bf16 [Cin/32][9][CoutPad][32]; dst counts uint16 elements
-void pack_conv_bf16(const float *w, const double *scale, int cin, int cout, uint16_t *dst, size_t cpad)
+// float -> IEEE binary16 bits, round-to-nearest-even (v_cvt_f16_f32 semantics incl. subnormals and overflow to inf)
+uint16_t fp16_bits(float x)
 {
+    uint32_t u;
+    memcpy(&u, &x, 4);
+    const uint32_t sign = (u >> 16) & 0x8000u;
+    const int32_t e = (int32_t)((u >> 23) & 0xFF) - 127;
+    uint32_t m = u & 0x7FFFFFu;
+    if (e == 128) return (uint16_t)(sign | 0x7C00u | (m ? 0x200u : 0));                 // inf / NaN
+    if (e > 15) return (uint16_t)(sign | 0x7C00u);                                       // overflow
+    if (e >= -14) {                                                                      // normal
+        uint32_t h = ((uint32_t)(e + 15) << 10) | (m >> 13);
+        const uint32_t rem = m & 0x1FFFu;
+        if (rem > 0x1000u || (rem == 0x1000u && (h & 1))) ++h;                           // carries into the exponent correctly
+        return (uint16_t)(sign | h);
+    }
+    if (e < -25) return (uint16_t)sign;                                                  // underflow to zero
+    m |= 0x800000u;                                                                      // subnormal: shift the 24-bit significand
+    const int shift = -14 - e + 13;
+    uint32_t h = m >> shift;
+    const uint32_t rem = m & ((1u << shift) - 1), half = 1u << (shift - 1);
+    if (rem > half || (rem == half && (h & 1))) ++h;
+    return (uint16_t)(sign | h);
+}
+
+typedef uint16_t (*lp_cvt_fn)(float);
+
+// conv3x3 (PyTorch [Cout][Cin][3][3], per-channel scale) -> 16-bit [Cin/32][9][CoutPad][32]; dst counts uint16 elements
+void pack_conv_bf16(const float *w, const double *scale, int cin, int cout, uint16_t *dst, size_t cpad, lp_cvt_fn cvt = nullptr)
+{
+    if (!cvt) cvt = bf16_bits;
     for (int co = 0; co < cout; ++co)
         for (int ci = 0; ci < cin; ++ci)
             for (int t = 0; t < 9; ++t)
                 dst[(((size_t)(ci / KC_BF16) * 9 + t) * cpad + co) * KC_BF16 + ci % KC_BF16] =
-                    bf16_bits((float)((double)w[((size_t)co * cin + ci) * 9 + t] * (scale ? scale[co] : 1.0)));
+                    cvt((float)((double)w[((size_t)co * cin + ci) * 9 + t] * (scale ? scale[co] : 1.0)));
 }
 
 // convT (PyTorch [Cin][Cout][2][2]) -> bf16 [Cin/32][1][NPad][32] with n = k * Cout + co
-void pack_convT_bf16(const float *w, int cin, int cout, uint16_t *dst, size_t npad)
+void pack_convT_bf16(const float *w, int cin, int cout, uint16_t *dst, size_t npad, lp_cvt_fn cvt = nullptr)
 {
+    if (!cvt) cvt = bf16_bits;
     for (int ci = 0; ci < cin; ++ci)
         for (int co = 0; co < cout; ++co)
             for (int k = 0; k < 4; ++k)
                 dst[((size_t)(ci / KC_BF16) * npad + (size_t)k * cout + co) * KC_BF16 + ci % KC_BF16] =
-                    bf16_bits(w[((size_t)ci * cout + co) * 4 + k]);
+                    cvt(w[((size_t)ci * cout + co) * 4 + k]);
 }
 
 struct HostWeights {
@@ -221,11 +250,12 @@ int build_host_weights(const mi_unet_config &cfg, int algo, const void *blob, si
                 for (int ci = 0; ci < cin; ++ci)
                     for (int t = 0; t < 9; ++t)
                         out[off.w + ((size_t)t * cin + ci) * cout + co] = (float)((double)w[((size_t)co * cin + ci) * 9 + t] * sc[co]);
-        } else if (algo == MI_UNET_CONV_BF16) {   // bf16 [chunk32][tap][n (padded)][32], BN scale folded before rounding
+        } else if (algo == MI_UNET_CONV_BF16 || algo == MI_UNET_CONV_FP16) {   // 16-bit [chunk32][tap][n (padded)][32], BN scale folded before rounding
             const int nch = (cin + KC_BF16 - 1) / KC_BF16;
             const size_t cpad = round_up(cout, NPAD);
             off.w = alloc(((size_t)nch * 9 * cpad * KC_BF16 + 1) / 2);
-            pack_conv_bf16(w, sc.data(), cin, cout, reinterpret_cast<uint16_t *>(&out[off.w]), cpad);
+            pack_conv_bf16(w, sc.data(), cin, cout, reinterpret_cast<uint16_t *>(&out[off.w]), cpad,
+                           algo == MI_UNET_CONV_FP16 ? fp16_bits : bf16_bits);
         } else if (algo != MI_UNET_CONV_DIRECT) {  // Winograd layouts (same size): U = G g G^T
             const int nch = (cin + WINO_KC - 1) / WINO_KC;
             const size_t cpad = round_up(cout, NPAD);
@@ -259,10 +289,11 @@ int build_host_weights(const mi_unet_config &cfg, int algo, const void *blob, si
         off.shift = alloc(cout);
         for (int co = 0; co < cout; ++co) out[off.shift + co] = b[co];
         const size_t npad = round_up((size_t)4 * cout, NPAD);
-        if (algo == MI_UNET_CONV_BF16) {
+        if (algo == MI_UNET_CONV_BF16 || algo == MI_UNET_CONV_FP16) {
             const int nch = (cin + KC_BF16 - 1) / KC_BF16;
             off.w = alloc(((size_t)nch * npad * KC_BF16 + 1) / 2);
-            pack_convT_bf16(w, cin, cout, reinterpret_cast<uint16_t *>(&out[off.w]), npad);
+            pack_convT_bf16(w, cin, cout, reinterpret_cast<uint16_t *>(&out[off.w]), npad,
+                            algo == MI_UNET_CONV_FP16 ? fp16_bits : bf16_bits);
         } else {
             const int nch = (cin + KC - 1) / KC;
             off.w = alloc((size_t)nch * npad * KC);
@@ -437,6 +468,7 @@ int launch_plan(mi_unet *h, const uint8_t *d_imgs, int B, uint8_t *d_labels, flo
         case Step::CONV: {
             ConvArgs a = st.a; a.B = B;
             if (h->algo == MI_UNET_CONV_BF16) { kname = "conv3x3_bf16"; e = launch_conv3x3_bf16(a, s); }
+            else if (h->algo == MI_UNET_CONV_FP16) { kname = "conv3x3_fp16"; e = launch_conv3x3_fp16(a, s); }
             else if (h->algo == MI_UNET_CONV_WINOGRAD16) { kname = "conv3x3_wino16"; e = launch_conv3x3_wino16(a, s); }
             else if (h->algo == MI_UNET_CONV_WINOGRAD) { kname = "conv3x3_wino"; e = launch_conv3x3_wino(a, s); }
             else { kname = "conv3x3_mfma"; e = launch_conv3x3_mfma(a, s); }
@@ -445,6 +477,7 @@ int launch_plan(mi_unet *h, const uint8_t *d_imgs, int B, uint8_t *d_labels, flo
         case Step::CONVT: {
             ConvArgs a = st.a; a.B = B;
             if (h->algo == MI_UNET_CONV_BF16) { kname = "convT2x2_bf16"; e = launch_convT2x2_bf16(a, s); }
+            else if (h->algo == MI_UNET_CONV_FP16) { kname = "convT2x2_fp16"; e = launch_convT2x2_fp16(a, s); }
             else { kname = "convT2x2_mfma"; e = launch_convT2x2_mfma(a, s); }
             break;
         }
@@ -530,8 +563,8 @@ int mi_unet_create(const mi_unet_config *cfg, mi_unet_t **out)
         return fail(MI_UNET_EARG, "base must be a power of two in 16..256");
     if (cfg->classes < 2 || cfg->classes > 6) return fail(MI_UNET_EARG, "classes must be in 2..6");
     if (cfg->max_batch < 1) return fail(MI_UNET_EARG, "max_batch must be >= 1");
-    if (cfg->conv_algo < 0 || cfg->conv_algo > 4)
-        return fail(MI_UNET_EARG, "conv_algo must be 0 (auto), 1 (direct), 2 (winograd), 3 (winograd16) or 4 (bf16)");
+    if (cfg->conv_algo < 0 || cfg->conv_algo > 5)
+        return fail(MI_UNET_EARG, "conv_algo must be 0 (auto), 1 (direct), 2 (winograd), 3 (winograd16), 4 (bf16) or 5 (fp16)");
     int ndev = mi_unet_device_count();
     if (ndev <= 0) return fail(MI_UNET_ENODEVICE, "no HIP device visible: libmiunet has no CPU fallback");
     if (cfg->device < 0 || cfg->device >= ndev) return fail(MI_UNET_EARG, "device ordinal out of range");
@@ -548,6 +581,7 @@ int mi_unet_create(const mi_unet_config *cfg, mi_unet_t **out)
             else if (env && !strcmp(env, "winograd")) algo = MI_UNET_CONV_WINOGRAD;
             else if (env && !strcmp(env, "winograd16")) algo = MI_UNET_CONV_WINOGRAD16;
             else if (env && !strcmp(env, "bf16")) algo = MI_UNET_CONV_BF16;
+            else if (env && !strcmp(env, "fp16")) algo = MI_UNET_CONV_FP16;
             else algo = MI_UNET_CONV_DEFAULT;
         }
         h->algo = algo;
@@ -899,17 +933,18 @@ int mi_unet_layer_debug(int device, const char *op, const float *in, int B, int 
         out_n = (size_t)B * H * W * Cout;
         a.B = B; a.H = H; a.W = W; a.Cin = Cin; a.ldc = Cin; a.Cout = Cout; a.CoutPad = (int)npad; a.ldo = Cout; a.co_off = 0;
         a.relu = relu;
-    } else if (o == "conv3x3_bf16" || o == "convT2x2_bf16") {
-        if (!w || Cout <= 0 || Cin % 8) return fail(MI_UNET_EARG, "layer_debug: bf16 conv needs weights and Cin % 8 == 0");
-        const bool T = (o == "convT2x2_bf16");
+    } else if (o == "conv3x3_bf16" || o == "convT2x2_bf16" || o == "conv3x3_fp16" || o == "convT2x2_fp16") {
+        if (!w || Cout <= 0 || Cin % 8) return fail(MI_UNET_EARG, "layer_debug: 16-bit conv needs weights and Cin % 8 == 0");
+        const bool T = (o == "convT2x2_bf16" || o == "convT2x2_fp16");
+        const lp_cvt_fn cvt = (o == "conv3x3_fp16" || o == "convT2x2_fp16") ? fp16_bits : bf16_bits;
         const int nch = (Cin + KC_BF16 - 1) / KC_BF16;
         const size_t npad = round_up(T ? (size_t)4 * Cout : (size_t)Cout, NPAD);
         wpk.assign(((size_t)nch * (T ? 1 : 9) * npad * KC_BF16 + 1) / 2, 0.f);
         bias.assign(Cout, 0.f);
         std::vector<double> sc(Cout, 1.0);
         for (int co = 0; co < Cout; ++co) { bias[co] = shift ? shift[co] : 0.f; if (scale) sc[co] = scale[co]; }
-        if (T) pack_convT_bf16(w, Cin, Cout, reinterpret_cast<uint16_t *>(wpk.data()), npad);
-        else pack_conv_bf16(w, sc.data(), Cin, Cout, reinterpret_cast<uint16_t *>(wpk.data()), npad);
+        if (T) pack_convT_bf16(w, Cin, Cout, reinterpret_cast<uint16_t *>(wpk.data()), npad, cvt);
+        else pack_conv_bf16(w, sc.data(), Cin, Cout, reinterpret_cast<uint16_t *>(wpk.data()), npad, cvt);
         out_n = T ? (size_t)B * 4 * H * W * Cout : (size_t)B * H * W * Cout;
         a.B = B; a.H = H; a.W = W; a.Cin = Cin; a.ldc = Cin; a.Cout = Cout; a.CoutPad = (int)npad; a.ldo = Cout; a.co_off = 0;
         a.relu = relu;
@@ -960,7 +995,9 @@ int mi_unet_layer_debug(int device, const char *op, const float *in, int B, int 
                 : o == "conv3x3_wino" ? launch_conv3x3_wino(a, nullptr)
                 : o == "conv3x3_wino16" ? launch_conv3x3_wino16(a, nullptr)
                 : o == "conv3x3_bf16" ? launch_conv3x3_bf16(a, nullptr)
-                : o == "convT2x2_bf16" ? launch_convT2x2_bf16(a, nullptr) : launch_convT2x2_mfma(a, nullptr));
+                : o == "convT2x2_bf16" ? launch_convT2x2_bf16(a, nullptr)
+                : o == "conv3x3_fp16" ? launch_conv3x3_fp16(a, nullptr)
+                : o == "convT2x2_fp16" ? launch_convT2x2_fp16(a, nullptr) : launch_convT2x2_mfma(a, nullptr));
     } else {
         DBG_TRY(launch_maxpool2x2(d_in, Cin, d_out, B, H, W, Cin, nullptr));
     }

@@ -47,6 +47,9 @@ hipError_t launch_convT2x2_mfma(const ConvArgs &a, hipStream_t s);
 constexpr int KC_BF16 = 32;
 hipError_t launch_conv3x3_bf16(const ConvArgs &a, hipStream_t s);
 hipError_t launch_convT2x2_bf16(const ConvArgs &a, hipStream_t s);
+// the same kernels on v_mfma_f32_32x32x16_f16 (BASELINE config 5's arithmetic); a.wpk holds IEEE half weights, same packing
+hipError_t launch_conv3x3_fp16(const ConvArgs &a, hipStream_t s);
+hipError_t launch_convT2x2_fp16(const ConvArgs &a, hipStream_t s);
 
 // First layer: u8 image -> (LUT /255) -> conv3x3 (Cin = 1..4) + shift + ReLU.  w is [9][Cin][Cout] (BN scale folded).
 hipError_t launch_conv3x3_first(const uint8_t *img, const float *lut256, const float *w, const float *shift, float *out,

@@ -298,20 +298,32 @@ hipError_t launch_convT2x2_mfma(const ConvArgs &a, hipStream_t s)
 //   * v_mfma_f32_32x32x16_bf16 takes A[i][8h + j], j = 0..7 from lane (i, h): exactly one ds_read_b128 per operand per
 //     MFMA, natural k order, 32 cycles per instruction (16x the fp32 rate) -- the kernel is bound by its staging and LDS
 //     traffic and by HBM, not by the matrix pipe.
-typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+// The same kernel serves fp16 operands (BASELINE config 5's arithmetic): T = __bf16 or _Float16, 16 bits either way.
+template <typename T> struct LpVec { typedef T x8 __attribute__((ext_vector_type(8))); };
 
-__device__ __forceinline__ bf16x8 pack_bf16x8(const f32x4 lo, const f32x4 hi)
+template <typename T>
+__device__ __forceinline__ typename LpVec<T>::x8 pack_lp8(const f32x4 lo, const f32x4 hi)
 {
-    bf16x8 r;
-    r[0] = (__bf16)lo[0]; r[1] = (__bf16)lo[1]; r[2] = (__bf16)lo[2]; r[3] = (__bf16)lo[3];
-    r[4] = (__bf16)hi[0]; r[5] = (__bf16)hi[1]; r[6] = (__bf16)hi[2]; r[7] = (__bf16)hi[3];
+    typename LpVec<T>::x8 r;
+    r[0] = (T)lo[0]; r[1] = (T)lo[1]; r[2] = (T)lo[2]; r[3] = (T)lo[3];
+    r[4] = (T)hi[0]; r[5] = (T)hi[1]; r[6] = (T)hi[2]; r[7] = (T)hi[3];
     return r;
 }
 
-template <int TAPS, int TH, int BN, bool NFAST>
+__device__ __forceinline__ f32x16 mfma_lp(LpVec<__bf16>::x8 a, LpVec<__bf16>::x8 b, f32x16 c)
+{
+    return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
+}
+__device__ __forceinline__ f32x16 mfma_lp(LpVec<_Float16>::x8 a, LpVec<_Float16>::x8 b, f32x16 c)
+{
+    return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0);
+}
+
+template <typename T, int TAPS, int TH, int BN, bool NFAST>
 __global__ __launch_bounds__(256, 2) void conv_mfma_bf16(const ConvArgs a, const int tiles_x, const int tiles_y,
                                                          const int m_tiles, const int nwg)
 {
+    typedef typename LpVec<T>::x8 bf16x8;
     constexpr int ROW = KC_BF16 + 8;                     // bf16 elements per LDS row (80 bytes)
     constexpr int HALO = (TAPS == 9) ? 1 : 0;
     constexpr int PW = 32 + 2 * HALO, PH = TH + 2 * HALO, NPIX = PW * PH;
@@ -321,8 +333,8 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_bf16(const ConvArgs a, const
     constexpr int B_PARTS = BN / 64;                     // 64 rows x 64 bytes = 4 KB = 256 threads x 16 bytes
     constexpr int B_ITERS = TAPS * B_PARTS;
     extern __shared__ __attribute__((aligned(16))) float lds[];
-    __bf16 *const As = reinterpret_cast<__bf16 *>(lds);
-    __bf16 *const Bs = As + NPIX * ROW;
+    T *const As = reinterpret_cast<T *>(lds);
+    T *const Bs = As + NPIX * ROW;
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -338,7 +350,7 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_bf16(const ConvArgs a, const
     const int b = m / tiles_y;
     const int x0 = tx * 32, y0 = ty * TH, n0 = n_tile * BN;
     const float *in_img = a.in + (size_t)b * a.H * a.W * a.ldc;
-    const __bf16 *wpk = reinterpret_cast<const __bf16 *>(a.wpk);
+    const T *wpk = reinterpret_cast<const T *>(a.wpk);
 
     int a_goff[A_ITERS], a_loff[A_ITERS];
 #pragma unroll
@@ -353,7 +365,7 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_bf16(const ConvArgs a, const
         a_loff[s] = live ? pix * ROW + 8 * q : -1;
     }
     const int bq = tid & 3, bn = tid >> 2;               // 16-byte piece (8 bf16) / cout row inside a 64-cout slab
-    const __bf16 *w_base = wpk + ((size_t)n0 + bn) * KC_BF16 + 8 * bq;
+    const T *w_base = wpk + ((size_t)n0 + bn) * KC_BF16 + 8 * bq;
     const int b_loff = bn * ROW + 8 * bq;
 
     f32x4 a_lo[A_ITERS], a_hi[A_ITERS];
@@ -379,7 +391,7 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_bf16(const ConvArgs a, const
     auto store_chunk = [&]() {
 #pragma unroll
         for (int s = 0; s < A_ITERS; ++s)
-            if (a_loff[s] >= 0) *reinterpret_cast<bf16x8 *>(As + a_loff[s]) = pack_bf16x8(a_lo[s], a_hi[s]);
+            if (a_loff[s] >= 0) *reinterpret_cast<bf16x8 *>(As + a_loff[s]) = pack_lp8<T>(a_lo[s], a_hi[s]);
 #pragma unroll
         for (int it = 0; it < B_ITERS; ++it) {
             const int tap = it / B_PARTS, part = it % B_PARTS;
@@ -395,8 +407,8 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_bf16(const ConvArgs a, const
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-    const __bf16 *a_frag = As + ((wave * MT) * PW + li) * ROW + 8 * lh;
-    const __bf16 *b_frag = Bs + li * ROW + 8 * lh;
+    const T *a_frag = As + ((wave * MT) * PW + li) * ROW + 8 * lh;
+    const T *b_frag = Bs + li * ROW + 8 * lh;
     const int nchunks = (a.Cin + KC_BF16 - 1) / KC_BF16;
     load_chunk(0);
     store_chunk();
@@ -420,7 +432,7 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_bf16(const ConvArgs a, const
                 for (int i = 0; i < MT; ++i)
 #pragma unroll
                     for (int j = 0; j < NT; ++j)
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i], bf[j], acc[i][j], 0, 0, 0);
+                        acc[i][j] = mfma_lp(af[i], bf[j], acc[i][j]);
             }
         }
         __syncthreads();
@@ -476,7 +488,7 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_bf16(const ConvArgs a, const
     }
 }
 
-template <int TAPS, int TH, int BN, bool NFAST>
+template <typename T, int TAPS, int TH, int BN, bool NFAST>
 static hipError_t launch_bf16_cfg(const ConvArgs &a, hipStream_t s)
 {
     const int n_total = (TAPS == 9) ? a.Cout : 4 * a.Cout;
@@ -487,7 +499,7 @@ static hipError_t launch_bf16_cfg(const ConvArgs &a, hipStream_t s)
     constexpr int HALO = (TAPS == 9) ? 1 : 0;
     constexpr size_t lds = 2 * (size_t)(KC_BF16 + 8) * ((32 + 2 * HALO) * (TH + 2 * HALO) + TAPS * BN);
     static bool attr_set = false;
-    auto kern = conv_mfma_bf16<TAPS, TH, BN, NFAST>;
+    auto kern = conv_mfma_bf16<T, TAPS, TH, BN, NFAST>;
     if (!attr_set) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return e;
@@ -500,13 +512,25 @@ static hipError_t launch_bf16_cfg(const ConvArgs &a, hipStream_t s)
 hipError_t launch_conv3x3_bf16(const ConvArgs &a, hipStream_t s)
 {
     if (a.Cin % 8 || a.ldc % 4 || a.CoutPad % NPAD) return hipErrorInvalidValue;
-    return launch_bf16_cfg<9, 8, 64, false>(a, s);
+    return launch_bf16_cfg<__bf16, 9, 8, 64, false>(a, s);
 }
 
 hipError_t launch_convT2x2_bf16(const ConvArgs &a, hipStream_t s)
 {
     if (a.Cin % 8 || a.ldc % 4 || a.CoutPad % NPAD) return hipErrorInvalidValue;
-    return launch_bf16_cfg<1, 8, 64, true>(a, s);
+    return launch_bf16_cfg<__bf16, 1, 8, 64, true>(a, s);
+}
+
+hipError_t launch_conv3x3_fp16(const ConvArgs &a, hipStream_t s)
+{
+    if (a.Cin % 8 || a.ldc % 4 || a.CoutPad % NPAD) return hipErrorInvalidValue;
+    return launch_bf16_cfg<_Float16, 9, 8, 64, false>(a, s);
+}
+
+hipError_t launch_convT2x2_fp16(const ConvArgs &a, hipStream_t s)
+{
+    if (a.Cin % 8 || a.ldc % 4 || a.CoutPad % NPAD) return hipErrorInvalidValue;
+    return launch_bf16_cfg<_Float16, 1, 8, 64, true>(a, s);
 }
 
 // --------------------------------------------------------------------------------------------------------------------

@@ -98,7 +98,7 @@ def _ptr(a):
 class Engine:
     """One engine handle = one GPU's context (the reference's thread-local TensorRTContext, include/process.h:13-23)."""
 
-    CONV_ALGOS = {"auto": 0, "direct": 1, "winograd": 2, "winograd16": 3, "bf16": 4}
+    CONV_ALGOS = {"auto": 0, "direct": 1, "winograd": 2, "winograd16": 3, "bf16": 4, "fp16": 5}
 
     def __init__(self, height=512, width=512, in_ch=1, base=64, levels=4, classes=3, max_batch=16, device=0,
                  conv_algo="auto"):
@@ -234,11 +234,11 @@ def layer_debug(op, x, w=None, scale=None, shift=None, relu=False, device=0):
     x = np.ascontiguousarray(x, np.float32)
     b, h, ww, cin = x.shape
     cout = 0
-    if op in ("conv3x3", "conv3x3_wino", "conv3x3_wino16", "conv3x3_bf16"):
+    if op in ("conv3x3", "conv3x3_wino", "conv3x3_wino16", "conv3x3_bf16", "conv3x3_fp16"):
         w = np.ascontiguousarray(w, np.float32)
         cout = w.shape[0]
         out = np.empty((b, h, ww, cout), np.float32)
-    elif op in ("convT2x2", "convT2x2_bf16"):
+    elif op in ("convT2x2", "convT2x2_bf16", "convT2x2_fp16"):
         w = np.ascontiguousarray(w, np.float32)
         cout = w.shape[1]
         out = np.empty((b, 2 * h, 2 * ww, cout), np.float32)
