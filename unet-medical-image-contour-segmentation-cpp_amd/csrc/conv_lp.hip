@@ -1,0 +1,246 @@
+// conv_lp.hip -- the direct implicit GEMM with 16-bit operands (bf16 / fp16) and fp32 accumulation, gfx950 only.
+#include "kernel_common.h"
+
+namespace miunet {
+
+// --------------------------------------------------------------------------------------------------------------------
+// conv_mfma_bf16 -- the same implicit GEMM with bf16 operands and fp32 accumulation (BASELINE config 3).
+// Layout and schedule are those of conv_mfma_f32; what changes:
+//   * a K-chunk is 32 channels; LDS rows hold 32 bf16 + 8 pad = 80 bytes (the same conflict-free stride);
+//   * activations are fp32 in HBM: the loader fetches 2 x 16 bytes per 8 channels and rounds them to bf16
+//     (v_cvt_pk_bf16_f32, round-to-nearest-even) on the way into LDS -- one 16-byte ds_write per 8 channels;
+//   * v_mfma_f32_32x32x16_bf16 takes A[i][8h + j], j = 0..7 from lane (i, h): exactly one ds_read_b128 per operand per
+//     MFMA, natural k order, 32 cycles per instruction (16x the fp32 rate) -- the kernel is bound by its staging and LDS
+//     traffic and by HBM, not by the matrix pipe.
+// The same kernel serves fp16 operands (BASELINE config 5's arithmetic): T = __bf16 or _Float16, 16 bits either way.
+template <typename T> struct LpVec { typedef T x8 __attribute__((ext_vector_type(8))); };
+
+template <typename T>
+__device__ __forceinline__ typename LpVec<T>::x8 pack_lp8(const f32x4 lo, const f32x4 hi)
+{
+    typename LpVec<T>::x8 r;
+    r[0] = (T)lo[0]; r[1] = (T)lo[1]; r[2] = (T)lo[2]; r[3] = (T)lo[3];
+    r[4] = (T)hi[0]; r[5] = (T)hi[1]; r[6] = (T)hi[2]; r[7] = (T)hi[3];
+    return r;
+}
+
+__device__ __forceinline__ f32x16 mfma_lp(LpVec<__bf16>::x8 a, LpVec<__bf16>::x8 b, f32x16 c)
+{
+    return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
+}
+__device__ __forceinline__ f32x16 mfma_lp(LpVec<_Float16>::x8 a, LpVec<_Float16>::x8 b, f32x16 c)
+{
+    return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0);
+}
+
+template <typename T, int TAPS, int TH, int BN, bool NFAST>
+__global__ __launch_bounds__(256, 2) void conv_mfma_bf16(const ConvArgs a, const int tiles_x, const int tiles_y,
+                                                         const int m_tiles, const int nwg)
+{
+    typedef typename LpVec<T>::x8 bf16x8;
+    constexpr int ROW = KC_BF16 + 8;                     // bf16 elements per LDS row (80 bytes)
+    constexpr int HALO = (TAPS == 9) ? 1 : 0;
+    constexpr int PW = 32 + 2 * HALO, PH = TH + 2 * HALO, NPIX = PW * PH;
+    constexpr int NA8 = NPIX * (KC_BF16 / 8);            // 8-channel pieces of the A patch
+    constexpr int A_ITERS = (NA8 + 255) / 256;
+    constexpr int MT = TH / 4, NT = BN / 32;
+    constexpr int B_PARTS = BN / 64;                     // 64 rows x 64 bytes = 4 KB = 256 threads x 16 bytes
+    constexpr int B_ITERS = TAPS * B_PARTS;
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    T *const As = reinterpret_cast<T *>(lds);
+    T *const Bs = As + NPIX * ROW;
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int li = lane & 31, lh = lane >> 5;
+
+    const int L = xcd_remap(blockIdx.x, nwg);
+    const int n_tiles = nwg / m_tiles;
+    const int n_tile = NFAST ? L % n_tiles : L / m_tiles;
+    int m = NFAST ? L / n_tiles : L - n_tile * m_tiles;
+    const int tx = m % tiles_x; m /= tiles_x;
+    const int ty = m % tiles_y;
+    const int b = m / tiles_y;
+    const int x0 = tx * 32, y0 = ty * TH, n0 = n_tile * BN;
+    const float *in_img = a.in + (size_t)b * a.H * a.W * a.ldc;
+    const T *wpk = reinterpret_cast<const T *>(a.wpk);
+
+    int a_goff[A_ITERS], a_loff[A_ITERS];
+#pragma unroll
+    for (int s = 0; s < A_ITERS; ++s) {
+        const int e = tid + 256 * s;
+        const int pix = e >> 2, q = e & 3;               // 4 pieces of 8 channels per pixel
+        const int py = pix / PW, px = pix - py * PW;
+        const int gy = y0 - HALO + py, gx = x0 - HALO + px;
+        const bool live = e < NA8;
+        const bool inb = live && gy >= 0 && gy < a.H && gx >= 0 && gx < a.W;
+        a_goff[s] = inb ? (gy * a.W + gx) * a.ldc + 8 * q : -1;
+        a_loff[s] = live ? pix * ROW + 8 * q : -1;
+    }
+    const int bq = tid & 3, bn = tid >> 2;               // 16-byte piece (8 bf16) / cout row inside a 64-cout slab
+    const T *w_base = wpk + ((size_t)n0 + bn) * KC_BF16 + 8 * bq;
+    const int b_loff = bn * ROW + 8 * bq;
+
+    f32x4 a_lo[A_ITERS], a_hi[A_ITERS];
+    bf16x8 b_reg[B_ITERS];
+    auto load_chunk = [&](int chunk) {
+        const int c0 = chunk * KC_BF16;
+#pragma unroll
+        for (int s = 0; s < A_ITERS; ++s) {
+            const int q8 = 8 * ((tid + 256 * s) & 3);
+            f32x4 lo = { 0.f, 0.f, 0.f, 0.f }, hi = { 0.f, 0.f, 0.f, 0.f };
+            if (a_goff[s] >= 0) {
+                if (c0 + q8 < a.Cin) lo = *reinterpret_cast<const f32x4 *>(in_img + a_goff[s] + c0);
+                if (c0 + q8 + 4 < a.Cin) hi = *reinterpret_cast<const f32x4 *>(in_img + a_goff[s] + c0 + 4);
+            }
+            a_lo[s] = lo; a_hi[s] = hi;
+        }
+#pragma unroll
+        for (int it = 0; it < B_ITERS; ++it) {
+            const int tap = it / B_PARTS, part = it % B_PARTS;
+            b_reg[it] = *reinterpret_cast<const bf16x8 *>(w_base + (((size_t)chunk * TAPS + tap) * a.CoutPad + part * 64) * KC_BF16);
+        }
+    };
+    auto store_chunk = [&]() {
+#pragma unroll
+        for (int s = 0; s < A_ITERS; ++s)
+            if (a_loff[s] >= 0) *reinterpret_cast<bf16x8 *>(As + a_loff[s]) = pack_lp8<T>(a_lo[s], a_hi[s]);
+#pragma unroll
+        for (int it = 0; it < B_ITERS; ++it) {
+            const int tap = it / B_PARTS, part = it % B_PARTS;
+            *reinterpret_cast<bf16x8 *>(Bs + (tap * BN + part * 64) * ROW + b_loff) = b_reg[it];
+        }
+    };
+
+    f32x16 acc[MT][NT];
+#pragma unroll
+    for (int i = 0; i < MT; ++i)
+#pragma unroll
+        for (int j = 0; j < NT; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    const T *a_frag = As + ((wave * MT) * PW + li) * ROW + 8 * lh;
+    const T *b_frag = Bs + li * ROW + 8 * lh;
+    const int nchunks = (a.Cin + KC_BF16 - 1) / KC_BF16;
+    load_chunk(0);
+    store_chunk();
+    __syncthreads();
+    for (int chunk = 0; chunk < nchunks; ++chunk) {
+        const bool more = chunk + 1 < nchunks;
+        if (more) load_chunk(chunk + 1);
+#pragma unroll
+        for (int tap = 0; tap < TAPS; ++tap) {
+            const int dy = (TAPS == 9) ? tap / 3 : 0, dx = (TAPS == 9) ? tap % 3 : 0;
+#pragma unroll
+            for (int g = 0; g < KC_BF16 / 16; ++g) {
+                bf16x8 af[MT], bf[NT];
+#pragma unroll
+                for (int i = 0; i < MT; ++i)
+                    af[i] = *reinterpret_cast<const bf16x8 *>(a_frag + ((i + dy) * PW + dx) * ROW + 16 * g);
+#pragma unroll
+                for (int j = 0; j < NT; ++j)
+                    bf[j] = *reinterpret_cast<const bf16x8 *>(b_frag + (tap * BN + 32 * j) * ROW + 16 * g);
+#pragma unroll
+                for (int i = 0; i < MT; ++i)
+#pragma unroll
+                    for (int j = 0; j < NT; ++j)
+                        acc[i][j] = mfma_lp(af[i], bf[j], acc[i][j]);
+            }
+        }
+        __syncthreads();
+        if (more) {
+            store_chunk();
+            __syncthreads();
+        }
+    }
+
+    // ---- epilogue (identical to the fp32 kernel's)
+#pragma unroll
+    for (int j = 0; j < NT; ++j) {
+        const int n = n0 + 32 * j + li;
+        int co, oy_off = 0, ox_off = 0;
+        if (TAPS == 9) {
+            co = n;
+        } else {
+            const int kidx = n / a.Cout;
+            co = n - kidx * a.Cout;
+            oy_off = kidx >> 1; ox_off = kidx & 1;
+        }
+        const bool n_ok = (TAPS == 9) ? (n < a.Cout) : (n < 4 * a.Cout);
+        const float sh = n_ok ? a.bias[co] : 0.f;
+        if (TAPS == 9 && MT == 2 && a.pool_out != nullptr) {
+            const int yp = (y0 + wave * MT) >> 1;
+#pragma unroll
+            for (int r = 0; r < 16; r += 2) {
+                const int x = x0 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+                float mx = fmaxf(fmaxf(acc[0][j][r], acc[0][j][r + 1]), fmaxf(acc[MT - 1][j][r], acc[MT - 1][j][r + 1])) + sh;
+                if (a.relu) mx = mx > 0.f ? mx : 0.f;
+                if (n_ok && y0 + wave * MT + 1 < a.H && x + 1 < a.W)
+                    a.pool_out[(((size_t)b * (a.H >> 1) + yp) * (a.W >> 1) + (x >> 1)) * a.pool_ld + co] = mx;
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < MT; ++i) {
+            const int y = y0 + wave * MT + i;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int x = x0 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+                float v = acc[i][j][r] + sh;
+                if (a.relu) v = v > 0.f ? v : 0.f;
+                if (n_ok && y < a.H && x < a.W) {
+                    size_t o;
+                    if (TAPS == 9)
+                        o = (((size_t)b * a.H + y) * a.W + x) * a.ldo + a.co_off + co;
+                    else
+                        o = (((size_t)b * 2 * a.H + 2 * y + oy_off) * (2 * a.W) + 2 * x + ox_off) * a.ldo + a.co_off + co;
+                    a.out[o] = v;
+                }
+            }
+        }
+    }
+}
+
+template <typename T, int TAPS, int TH, int BN, bool NFAST>
+static hipError_t launch_bf16_cfg(const ConvArgs &a, hipStream_t s)
+{
+    const int n_total = (TAPS == 9) ? a.Cout : 4 * a.Cout;
+    const int tiles_x = (a.W + 31) / 32, tiles_y = (a.H + TH - 1) / TH;
+    const int m_tiles = tiles_x * tiles_y * a.B;
+    const int n_tiles = (n_total + BN - 1) / BN;
+    const int nwg = m_tiles * n_tiles;
+    constexpr int HALO = (TAPS == 9) ? 1 : 0;
+    constexpr size_t lds = 2 * (size_t)(KC_BF16 + 8) * ((32 + 2 * HALO) * (TH + 2 * HALO) + TAPS * BN);
+    auto kern = conv_mfma_bf16<T, TAPS, TH, BN, NFAST>;
+    if (hipError_t e = ensure_dynamic_lds(kern, lds); e != hipSuccess) return e;
+    hipLaunchKernelGGL(kern, dim3(nwg), dim3(256), lds, s, a, tiles_x, tiles_y, m_tiles, nwg);
+    return hipGetLastError();
+}
+
+hipError_t launch_conv3x3_bf16(const ConvArgs &a, hipStream_t s)
+{
+    if (a.Cin % 8 || a.ldc % 4 || a.CoutPad % NPAD) return hipErrorInvalidValue;
+    return launch_bf16_cfg<__bf16, 9, 8, 64, false>(a, s);
+}
+
+hipError_t launch_convT2x2_bf16(const ConvArgs &a, hipStream_t s)
+{
+    if (a.Cin % 8 || a.ldc % 4 || a.CoutPad % NPAD) return hipErrorInvalidValue;
+    return launch_bf16_cfg<__bf16, 1, 8, 64, true>(a, s);
+}
+
+hipError_t launch_conv3x3_fp16(const ConvArgs &a, hipStream_t s)
+{
+    if (a.Cin % 8 || a.ldc % 4 || a.CoutPad % NPAD) return hipErrorInvalidValue;
+    return launch_bf16_cfg<_Float16, 9, 8, 64, false>(a, s);
+}
+
+hipError_t launch_convT2x2_fp16(const ConvArgs &a, hipStream_t s)
+{
+    if (a.Cin % 8 || a.ldc % 4 || a.CoutPad % NPAD) return hipErrorInvalidValue;
+    return launch_bf16_cfg<_Float16, 1, 8, 64, true>(a, s);
+}
+
+
+}  // namespace miunet

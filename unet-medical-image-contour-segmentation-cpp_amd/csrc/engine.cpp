@@ -1,5 +1,5 @@
 // engine.cpp -- the C-ABI of include/mi_unet.h: handle, weight loading (BN fold + MFMA repack), device buffers,
-// the forward plan and its launches.  Host code only; every device kernel lives in kernels.hip.
+// the forward plan and its launches.  Host code only; every device kernel lives in the .hip files next to it.
 //
 // Replaces, for the reference's hot path, initialize_engine's engine deserialisation (src/initialize.cpp:49-60),
 // initialize_context's buffers/stream (src/process.cpp:45-120) and execute_inference (src/process.cpp:123-175).

@@ -1,0 +1,439 @@
+// image_stages.hip -- the reference's CPU-side image stages on the device: RAW16 preprocessing (f1), postprocess_mask
+// (f2), mask_to_image + extract_contours (f3).  Integer / byte / fp64 work, bit-exact against the oracle.  gfx950 only.
+#include "kernel_common.h"
+
+namespace miunet {
+
+// --------------------------------------------------------------------------------------------------------------------
+// RAW16 preprocessing on the device: HBM-bound integer scan + a 262144-pixel fp64 gather.
+__global__ __launch_bounds__(256) void minmax_init_kernel(unsigned *mnmx)
+{
+    if (threadIdx.x == 0) { mnmx[0] = 65535u; mnmx[1] = 0u; }
+}
+
+__global__ __launch_bounds__(256) void minmax_u16_kernel(const uint16_t *__restrict__ raw, size_t n, unsigned *mnmx)
+{
+    unsigned lo = 65535u, hi = 0u;
+    const size_t n8 = n / 8;                                   // 16 bytes = 8 samples per lane
+    const uint4 *v = reinterpret_cast<const uint4 *>(raw);
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n8; i += (size_t)gridDim.x * 256) {
+        const uint4 q = v[i];
+        const unsigned ws[4] = { q.x, q.y, q.z, q.w };
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const unsigned a = ws[k] & 0xFFFFu, b = ws[k] >> 16;
+            lo = min(lo, min(a, b));
+            hi = max(hi, max(a, b));
+        }
+    }
+    if (blockIdx.x == 0 && threadIdx.x < (n & 7)) {            // ragged tail
+        const unsigned a = raw[n8 * 8 + threadIdx.x];
+        lo = min(lo, a); hi = max(hi, a);
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {                          // wave64 butterfly
+        lo = min(lo, (unsigned)__shfl_xor((int)lo, o, 64));
+        hi = max(hi, (unsigned)__shfl_xor((int)hi, o, 64));
+    }
+    if ((threadIdx.x & 63) == 0) {
+        atomicMin(&mnmx[0], lo);
+        atomicMax(&mnmx[1], hi);
+    }
+}
+
+hipError_t launch_minmax_u16(const uint16_t *raw, size_t n, unsigned *mnmx, hipStream_t s)
+{
+    if (n == 0 || (reinterpret_cast<uintptr_t>(raw) & 15)) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(minmax_init_kernel, dim3(1), dim3(256), 0, s, mnmx);
+    size_t blocks = (n / 8 + 255) / 256;
+    if (blocks > 2048) blocks = 2048;
+    if (blocks == 0) blocks = 1;
+    hipLaunchKernelGGL(minmax_u16_kernel, dim3((unsigned)blocks), dim3(256), 0, s, raw, n, mnmx);
+    return hipGetLastError();
+}
+
+__global__ __launch_bounds__(256) void resample_u8_kernel(const uint16_t *__restrict__ raw, int w, int h,
+                                                          const unsigned *__restrict__ mnmx, uint8_t *__restrict__ dst,
+                                                          int outW, int outH)
+{
+#pragma clang fp contract(off)
+    const int x = blockIdx.x * 64 + (threadIdx.x & 63);
+    const int y = blockIdx.y * 4 + (threadIdx.x >> 6);
+    if (x >= outW || y >= outH) return;
+    const unsigned short mn = (unsigned short)mnmx[0];
+    unsigned short mx = (unsigned short)mnmx[1];
+    if (mn == mx) mx = (unsigned short)(mn + 1);                // evaluated in uint16_t: wraps to 0 at 65535 (src/preprocess.cpp:92)
+    const double scale8 = 255.0 / (double)((int)mx - (int)mn);
+    const double stepX = (double)w / (double)outW, stepY = (double)h / (double)outH;
+    const double fx = __dmul_rn((double)x, stepX), fy = __dmul_rn((double)y, stepY);
+    const int ix = (int)fx, iy = (int)fy;
+    const int ix1 = ix + 1 < w - 1 ? ix + 1 : w - 1;
+    const int iy1 = iy + 1 < h - 1 ? iy + 1 : h - 1;
+    const double dx = __dsub_rn(fx, (double)ix), dy = __dsub_rn(fy, (double)iy);
+    const double v00 = raw[(size_t)iy * w + ix], v01 = raw[(size_t)iy * w + ix1];
+    const double v10 = raw[(size_t)iy1 * w + ix], v11 = raw[(size_t)iy1 * w + ix1];
+    const double omdx = __dsub_rn(1.0, dx), omdy = __dsub_rn(1.0, dy);
+    // (1-dx)*(1-dy)*v00 + dx*(1-dy)*v01 + (1-dx)*dy*v10 + dx*dy*v11, left to right, one rounding per operation
+    double v = __dmul_rn(__dmul_rn(omdx, omdy), v00);
+    v = __dadd_rn(v, __dmul_rn(__dmul_rn(dx, omdy), v01));
+    v = __dadd_rn(v, __dmul_rn(__dmul_rn(omdx, dy), v10));
+    v = __dadd_rn(v, __dmul_rn(__dmul_rn(dx, dy), v11));
+    const double q = __dadd_rn(__dmul_rn(__dsub_rn(v, (double)mn), scale8), 0.5);
+    dst[(size_t)y * outW + x] = (uint8_t)(int)q;
+}
+
+hipError_t launch_resample_u8(const uint16_t *raw, int w, int h, const unsigned *mnmx, uint8_t *dst, int outW, int outH,
+                              hipStream_t s)
+{
+    if (w <= 0 || h <= 0 || outW <= 0 || outH <= 0) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(resample_u8_kernel, dim3((outW + 63) / 64, (outH + 3) / 4), dim3(256), 0, s, raw, w, h, mnmx, dst, outW, outH);
+    return hipGetLastError();
+}
+
+// --------------------------------------------------------------------------------------------------------------------
+// postprocess_mask on the device.  Byte/integer work, HBM/L2-bound and tiny next to the network:
+// the point is to keep the label maps on the device and to replace the reference's O(components x H x W) loops
+// (src/postprocess.cpp:41, :71) by one union-find labelling.
+namespace pp {
+
+__device__ __forceinline__ int ld(const int *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+
+__device__ __forceinline__ int find_root(const int *parent, int x)
+{
+    int p = ld(parent + x);
+    while (p != x) { x = p; p = ld(parent + x); }
+    return x;
+}
+
+// parents only ever decrease, roots satisfy parent[r] == r; atomicMin at L2 makes concurrent unions safe
+__device__ __forceinline__ void unite(int *parent, int a, int b)
+{
+    for (;;) {
+        a = find_root(parent, a);
+        b = find_root(parent, b);
+        if (a == b) return;
+        if (a < b) { const int t = a; a = b; b = t; }          // a > b: hang a under b
+        const int old = atomicMin(parent + a, b);
+        if (old == a) return;
+        a = old;                                                // somebody re-parented a meanwhile: retry from there
+    }
+}
+
+// fg[i] != 0 marks foreground.  parent = own index for fg, -1 for bg; stats cleared.
+__global__ __launch_bounds__(256) void cc_init(const uint8_t *__restrict__ fg, int *parent, int *area, int *minx, int *miny,
+                                               int *maxx, int *maxy, long long n)
+{
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    parent[i] = fg[i] ? (int)i : -1;
+    area[i] = 0; minx[i] = 0x7FFFFFFF; miny[i] = 0x7FFFFFFF; maxx[i] = -1; maxy[i] = -1;
+}
+
+__global__ __launch_bounds__(256) void cc_merge(const uint8_t *__restrict__ fg, int *parent, int H, int W, long long n)
+{
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n || !fg[i]) return;
+    const int hw = H * W;
+    const int p = (int)(i % hw), y = p / W, x = p - y * W;
+    if (x > 0 && fg[i - 1]) unite(parent, (int)i, (int)i - 1);
+    if (y > 0) {
+        if (fg[i - W]) unite(parent, (int)i, (int)i - W);
+        if (x > 0 && fg[i - W - 1]) unite(parent, (int)i, (int)i - W - 1);
+        if (x + 1 < W && fg[i - W + 1]) unite(parent, (int)i, (int)i - W + 1);
+    }
+}
+
+__global__ __launch_bounds__(256) void cc_stats(int *parent, int *area, int *minx, int *miny, int *maxx, int *maxy, int H, int W,
+                                                long long n)
+{
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n || parent[i] < 0) return;
+    const int r = find_root(parent, (int)i);
+    parent[i] = r;                                              // flatten (only this thread writes parent[i] in this kernel...
+    const int hw = H * W;                                       // ... and a non-root's value is never used as a union target)
+    const int p = (int)(i % hw), y = p / W, x = p - y * W;
+    atomicAdd(area + r, 1);
+    atomicMin(minx + r, x); atomicMax(maxx + r, x);
+    atomicMin(miny + r, y); atomicMax(maxy + r, y);
+}
+
+__global__ __launch_bounds__(256) void k_inv(const uint8_t *__restrict__ labels, uint8_t *inv, long long n)
+{
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (i < n) inv[i] = labels[i] == 2 ? 0 : 255;               // src/postprocess.cpp:18-22
+}
+
+// bin = 255 where the pixel is foreground after hole filling (src/postprocess.cpp:30-43, :57)
+__global__ __launch_bounds__(256) void k_fill_bin(const uint8_t *__restrict__ labels, const int *__restrict__ parent,
+                                                  const int *__restrict__ area, const int *__restrict__ minx,
+                                                  const int *__restrict__ miny, const int *__restrict__ maxx,
+                                                  const int *__restrict__ maxy, uint8_t *bin, int H, int W, int min_area, long long n)
+{
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    bool fgd = labels[i] == 2;
+    const int r = parent[i];
+    if (!fgd && r >= 0)
+        fgd = minx[r] > 0 && miny[r] > 0 && maxx[r] < W - 1 && maxy[r] < H - 1 && area[r] < min_area;
+    bin[i] = fgd ? 255 : 0;
+}
+
+template <bool DILATE>
+__global__ __launch_bounds__(256) void k_morph3(const uint8_t *__restrict__ src, uint8_t *dst, int H, int W, long long n)
+{
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const int hw = H * W;
+    const int p = (int)(i % hw), y = p / W, x = p - y * W;
+    unsigned v = DILATE ? 0u : 255u;
+#pragma unroll
+    for (int dy = -1; dy <= 1; ++dy)
+#pragma unroll
+        for (int dx = -1; dx <= 1; ++dx) {
+            const int yy = y + dy, xx = x + dx;
+            if (yy < 0 || yy >= H || xx < 0 || xx >= W) continue;          // the border never constrains / never seeds
+            const unsigned sv = src[i + dy * W + dx];
+            v = DILATE ? max(v, sv) : min(v, sv);
+        }
+    dst[i] = (uint8_t)v;
+}
+
+__global__ __launch_bounds__(256) void k_filter(const int *__restrict__ parent, const int *__restrict__ area, uint8_t *out,
+                                                int min_area, long long n)
+{
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const int r = parent[i];
+    out[i] = (r >= 0 && area[r] >= min_area) ? 2 : 0;          // src/postprocess.cpp:70, :75-76
+}
+
+}  // namespace pp
+
+size_t postprocess_workspace_bytes(int B, int H, int W)
+{
+    const size_t n = (size_t)B * H * W;
+    return n * (6 * sizeof(int) + 3);                           // parent, area, 4 x bbox, three u8 planes
+}
+
+hipError_t launch_postprocess_masks(const uint8_t *labels_in, uint8_t *labels_out, int B, int H, int W, int min_area, void *ws,
+                                    hipStream_t s)
+{
+    const long long n = (long long)B * H * W;
+    if (n <= 0 || n > 0x7FFFFFFFLL) return hipErrorInvalidValue;
+    int *parent = static_cast<int *>(ws), *area = parent + n, *minx = area + n, *miny = minx + n, *maxx = miny + n, *maxy = maxx + n;
+    uint8_t *u0 = reinterpret_cast<uint8_t *>(maxy + n), *u1 = u0 + n, *u2 = u1 + n;
+    const dim3 g((unsigned)((n + 255) / 256)), b(256);
+    auto label = [&](const uint8_t *fg) {
+        hipLaunchKernelGGL(pp::cc_init, g, b, 0, s, fg, parent, area, minx, miny, maxx, maxy, n);
+        hipLaunchKernelGGL(pp::cc_merge, g, b, 0, s, fg, parent, H, W, n);
+        hipLaunchKernelGGL(pp::cc_stats, g, b, 0, s, parent, area, minx, miny, maxx, maxy, H, W, n);
+    };
+    hipLaunchKernelGGL(pp::k_inv, g, b, 0, s, labels_in, u0, n);
+    label(u0);
+    hipLaunchKernelGGL(pp::k_fill_bin, g, b, 0, s, labels_in, parent, area, minx, miny, maxx, maxy, u1, H, W, min_area, n);
+    hipLaunchKernelGGL(pp::k_morph3<false>, g, b, 0, s, u1, u2, H, W, n);
+    hipLaunchKernelGGL(pp::k_morph3<true>, g, b, 0, s, u2, u1, H, W, n);
+    label(u1);
+    hipLaunchKernelGGL(pp::k_filter, g, b, 0, s, parent, area, labels_out, min_area, n);
+    return hipGetLastError();
+}
+
+// --------------------------------------------------------------------------------------------------------------------
+// extract_contours on the device.
+// OpenCV's sequential Suzuki-Abe scan interleaves "find the next start pixel" with "follow that border".  For
+// RETR_EXTERNAL both halves separate cleanly:
+//   * the start pixel of a component's outer border is its first pixel in raster order = the ROOT of the union-find
+//     labelling above (parents always point to smaller indices);
+//   * the border is external iff the background region just above that pixel reaches the image frame (OpenCV's
+//     `img0[lnbd] > 0` test says the same thing through the sign of the last border label on the row): the pixel above
+//     the root is background by construction, and a 4-connected background component reaches the frame iff its
+//     bounding box touches the image edge;
+//   * the trace itself (first neighbour clockwise from west, then counter-clockwise from the arrival direction, a point
+//     wherever the step direction changes) is inherently serial per contour, so every external contour gets its own
+//     lane: contours and images run in parallel, the mask is L2-resident (256 KB per image);
+//   * OpenCV returns contours newest-first = descending raster order of the start pixels: a 64-bit-free trick -- the
+//     per-image list of external roots is sorted by one thread per image (a handful of entries after postprocess_mask).
+namespace ct {
+
+__global__ __launch_bounds__(256) void k_threshold(const uint8_t *__restrict__ mask, uint8_t *fg, uint8_t *bg, long long n)
+{
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const bool f = mask[i] > 127;                               // cv::threshold(127, 255, THRESH_BINARY)
+    fg[i] = f ? 255 : 0;
+    bg[i] = f ? 0 : 255;
+}
+
+// 4-connected union (background regions)
+__global__ __launch_bounds__(256) void cc_merge4(const uint8_t *__restrict__ fg, int *parent, int H, int W, long long n)
+{
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n || !fg[i]) return;
+    const int hw = H * W;
+    const int p = (int)(i % hw), y = p / W, x = p - y * W;
+    if (x > 0 && fg[i - 1]) pp::unite(parent, (int)i, (int)i - 1);
+    if (y > 0 && fg[i - W]) pp::unite(parent, (int)i, (int)i - W);
+}
+
+__global__ __launch_bounds__(256) void k_zero_counts(int *counts, int B)
+{
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i < B) counts[i] = 0;
+}
+
+// one entry per external component: its root (= start pixel).  fparent: flattened fg labelling; bparent + bbox: background.
+__global__ __launch_bounds__(256) void k_collect(const int *__restrict__ fparent, const int *__restrict__ bparent,
+                                                 const int *__restrict__ bminx, const int *__restrict__ bminy,
+                                                 const int *__restrict__ bmaxx, const int *__restrict__ bmaxy, int *roots,
+                                                 int *counts, int cap, int H, int W, long long n)
+{
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n || fparent[i] != (int)i) return;                // roots only
+    const int hw = H * W, img = (int)(i / hw);
+    const int p = (int)(i % hw), y = p / W;
+    bool external = (y == 0);
+    if (!external) {
+        const int r = bparent[i - W];                           // the pixel above a component's first pixel is background
+        external = r >= 0 && (bminx[r] == 0 || bminy[r] == 0 || bmaxx[r] == W - 1 || bmaxy[r] == H - 1);
+    }
+    if (external) {
+        const int slot = atomicAdd(counts + img, 1);
+        if (slot < cap) roots[(size_t)img * cap + slot] = p;
+    }
+}
+
+// per image: sort the start pixels descending (newest contour first).  Few entries: insertion sort by one lane.
+__global__ __launch_bounds__(64) void k_sort_roots(int *roots, const int *counts, int cap, int B)
+{
+    const int img = blockIdx.x * 64 + threadIdx.x;
+    if (img >= B) return;
+    const int n = counts[img] < cap ? counts[img] : cap;
+    int *r = roots + (size_t)img * cap;
+    for (int a = 1; a < n; ++a) {
+        const int v = r[a];
+        int b = a - 1;
+        while (b >= 0 && r[b] < v) { r[b + 1] = r[b]; --b; }
+        r[b + 1] = v;
+    }
+}
+
+// one lane per (image, contour): follow the border from its start pixel, emit CHAIN_APPROX_SIMPLE points.
+// pass 0 counts points (npts), pass 1 writes them at the offsets computed in between.
+__global__ __launch_bounds__(64) void k_trace(const uint8_t *__restrict__ fg, const int *__restrict__ roots,
+                                              const int *__restrict__ counts, int cap, int H, int W, int B, int *npts,
+                                              const int *__restrict__ offs, int *out_xy, int cap_points, int write)
+{
+    const int t = blockIdx.x * 64 + threadIdx.x;
+    const int img = t / cap, c = t - img * cap;
+    if (img >= B || c >= counts[img] || counts[img] > cap) return;
+    const uint8_t *im = fg + (size_t)img * H * W;
+    auto at = [&](int x, int y) -> bool { return x >= 0 && x < W && y >= 0 && y < H && im[(size_t)y * W + x] != 0; };
+    const int DX[8] = { 1, 1, 0, -1, -1, -1, 0, 1 };            // 0 = E, then counter-clockwise on screen (y grows down)
+    const int DY[8] = { 0, -1, -1, -1, 0, 1, 1, 1 };
+    const int start = roots[(size_t)img * cap + c];
+    const int x0 = start % W, y0 = start / W;
+    int *dst = nullptr;
+    int room = 0;
+    if (write) {
+        const int o = offs[(size_t)img * (cap + 1) + c];
+        room = cap_points - o;
+        dst = out_xy + ((size_t)img * cap_points + o) * 2;
+    }
+    int n = 0;
+    auto emit = [&](int x, int y) {
+        if (write && n < room) { dst[2 * n] = x; dst[2 * n + 1] = y; }
+        ++n;
+    };
+    int dir = 4, first = -1;                                    // first neighbour: clockwise, starting after west
+    for (int k = 0; k < 8; ++k) {
+        dir = (dir + 7) & 7;
+        if (at(x0 + DX[dir], y0 + DY[dir])) { first = dir; break; }
+    }
+    if (first < 0) {
+        emit(x0, y0);                                           // isolated pixel
+    } else {
+        const int x1 = x0 + DX[first], y1 = y0 + DY[first];
+        int cx = x0, cy = y0, came = first, last_step = first ^ 4;
+        for (long long guard = 0; guard < 4LL * H * W + 16; ++guard) {      // a border has at most 4 visits per pixel
+            int s = came, nx, ny;
+            do { ++s; nx = cx + DX[s & 7]; ny = cy + DY[s & 7]; } while (!at(nx, ny));
+            const int step = s & 7;
+            if (step != last_step) { emit(cx, cy); last_step = step; }
+            const bool closing = (nx == x0 && ny == y0 && cx == x1 && cy == y1);
+            cx = nx; cy = ny;
+            if (closing) break;
+            came = (step + 4) & 7;
+        }
+    }
+    if (!write) npts[(size_t)img * cap + c] = n;
+}
+
+// per image: exclusive scan of the point counts -> out_start, and the verdict (count or -1 on overflow)
+__global__ __launch_bounds__(64) void k_offsets(const int *__restrict__ npts, const int *__restrict__ counts, int cap,
+                                                int cap_points, int B, int *out_start, int *out_count)
+{
+    const int img = blockIdx.x * 64 + threadIdx.x;
+    if (img >= B) return;
+    int *st = out_start + (size_t)img * (cap + 1);
+    const int nc = counts[img];
+    if (nc > cap) { out_count[img] = -1; st[0] = 0; return; }
+    int o = 0;
+    for (int c = 0; c < nc; ++c) { st[c] = o; o += npts[(size_t)img * cap + c]; }
+    st[nc] = o;
+    out_count[img] = o > cap_points ? -1 : nc;
+}
+
+}  // namespace ct
+
+__global__ __launch_bounds__(256) void mask_to_image_kernel(const uint8_t *__restrict__ labels, uint8_t *vis, size_t n)
+{
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const unsigned v = labels[i];
+    vis[i] = v == 1 ? 128 : v == 2 ? 255 : 0;
+}
+
+hipError_t launch_mask_to_image(const uint8_t *labels, uint8_t *vis, size_t n, hipStream_t s)
+{
+    hipLaunchKernelGGL(mask_to_image_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, labels, vis, n);
+    return hipGetLastError();
+}
+
+size_t contour_workspace_bytes(int B, int H, int W, int cap_contours)
+{
+    const size_t n = (size_t)B * H * W;
+    return n * (7 * sizeof(int) + 2) + sizeof(int) * ((size_t)B * (2 * cap_contours + 1) + 64);
+}
+
+hipError_t launch_extract_contours(const uint8_t *masks, int B, int H, int W, int *out_xy, int cap_points, int *out_start,
+                                   int cap_contours, int *out_count, void *ws, hipStream_t s)
+{
+    const long long n = (long long)B * H * W;
+    if (n <= 0 || n > 0x7FFFFFFFLL || cap_contours <= 0 || cap_points <= 0) return hipErrorInvalidValue;
+    int *fparent = static_cast<int *>(ws), *bparent = fparent + n, *area = bparent + n, *minx = area + n, *miny = minx + n,
+        *maxx = miny + n, *maxy = maxx + n;
+    uint8_t *fg = reinterpret_cast<uint8_t *>(maxy + n), *bg = fg + n;
+    int *roots = reinterpret_cast<int *>(bg + n + ((16 - (2 * n) % 16) % 16));
+    int *npts = roots + (size_t)B * cap_contours, *counts = npts + (size_t)B * cap_contours;
+    const dim3 g((unsigned)((n + 255) / 256)), b(256);
+    hipLaunchKernelGGL(ct::k_threshold, g, b, 0, s, masks, fg, bg, n);
+    // foreground labelling (8-connected); its stats are not needed, the arrays are reused by the background pass
+    hipLaunchKernelGGL(pp::cc_init, g, b, 0, s, fg, fparent, area, minx, miny, maxx, maxy, n);
+    hipLaunchKernelGGL(pp::cc_merge, g, b, 0, s, fg, fparent, H, W, n);
+    hipLaunchKernelGGL(pp::cc_stats, g, b, 0, s, fparent, area, minx, miny, maxx, maxy, H, W, n);
+    // background labelling (4-connected) with bounding boxes
+    hipLaunchKernelGGL(pp::cc_init, g, b, 0, s, bg, bparent, area, minx, miny, maxx, maxy, n);
+    hipLaunchKernelGGL(ct::cc_merge4, g, b, 0, s, bg, bparent, H, W, n);
+    hipLaunchKernelGGL(pp::cc_stats, g, b, 0, s, bparent, area, minx, miny, maxx, maxy, H, W, n);
+    hipLaunchKernelGGL(ct::k_zero_counts, dim3((B + 255) / 256), b, 0, s, counts, B);
+    hipLaunchKernelGGL(ct::k_collect, g, b, 0, s, fparent, bparent, minx, miny, maxx, maxy, roots, counts, cap_contours, H, W, n);
+    hipLaunchKernelGGL(ct::k_sort_roots, dim3((B + 63) / 64), dim3(64), 0, s, roots, counts, cap_contours, B);
+    const dim3 gt((unsigned)(((long long)B * cap_contours + 63) / 64)), bt(64);
+    hipLaunchKernelGGL(ct::k_trace, gt, bt, 0, s, fg, roots, counts, cap_contours, H, W, B, npts, out_start, out_xy, cap_points, 0);
+    hipLaunchKernelGGL(ct::k_offsets, dim3((B + 63) / 64), dim3(64), 0, s, npts, counts, cap_contours, cap_points, B, out_start, out_count);
+    hipLaunchKernelGGL(ct::k_trace, gt, bt, 0, s, fg, roots, counts, cap_contours, H, W, B, npts, out_start, out_xy, cap_points, 1);
+    return hipGetLastError();
+}
+
+
+}  // namespace miunet

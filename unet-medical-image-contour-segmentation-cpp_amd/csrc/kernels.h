@@ -1,4 +1,4 @@
-// kernels.h -- launch interface of the gfx950 kernels (kernels.hip).  Internal to libmiunet.so.
+// kernels.h -- launch interface of the gfx950 kernels (conv_direct.hip, conv_lp.hip, conv_wino.hip, layers_mem.hip, image_stages.hip).  Internal to libmiunet.so.
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stddef.h>

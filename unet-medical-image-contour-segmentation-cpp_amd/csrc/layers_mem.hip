@@ -1,0 +1,175 @@
+// layers_mem.hip -- the HBM-bound layers: first conv (K = 9), 2x2 max pooling, 1x1 head + argmax.  gfx950 only.
+#include "kernel_common.h"
+
+namespace miunet {
+
+// --------------------------------------------------------------------------------------------------------------------
+// First layer (K = 9*Cin with Cin <= 4: HBM-bound on its output).  One thread = one pixel x 4 output channels; the
+// Cout/4 threads of a pixel write one contiguous NHWC row.  u8 -> fp32 through the host-built 256-entry table so the
+// input equals float(x)/255.0f bit for bit (src/process.cpp:36-39).
+template <int CIN>
+__global__ __launch_bounds__(256) void conv3x3_first_kernel(const uint8_t *__restrict__ img, const float *__restrict__ lut,
+                                                            const float *__restrict__ w, const float *__restrict__ shift,
+                                                            float *__restrict__ out, int B, int H, int W, int Cout,
+                                                            int ldo, int quads)
+{
+    __shared__ float s_lut[256];
+    s_lut[threadIdx.x] = lut[threadIdx.x];
+    __syncthreads();
+    const int q = threadIdx.x % quads;            // which 4 couts
+    const int pl = threadIdx.x / quads;           // pixel slot in block
+    const int ppb = 256 / quads;
+    f32x4 wr[9 * CIN];
+#pragma unroll
+    for (int t = 0; t < 9 * CIN; ++t) wr[t] = *reinterpret_cast<const f32x4 *>(w + (size_t)t * Cout + 4 * q);
+    const f32x4 sh = *reinterpret_cast<const f32x4 *>(shift + 4 * q);
+    const long long npix = (long long)B * H * W;
+    for (long long p = (long long)blockIdx.x * ppb + pl; p < npix; p += (long long)gridDim.x * ppb) {
+        const int x = (int)(p % W);
+        const int y = (int)((p / W) % H);
+        const uint8_t *base = img + (size_t)(p - x - (long long)y * W) * CIN;   // image start
+        f32x4 acc = { 0.f, 0.f, 0.f, 0.f };
+#pragma unroll
+        for (int t = 0; t < 9; ++t) {
+            const int yy = y + t / 3 - 1, xx = x + t % 3 - 1;
+            const bool ok = yy >= 0 && yy < H && xx >= 0 && xx < W;
+#pragma unroll
+            for (int c = 0; c < CIN; ++c) {
+                const float v = ok ? s_lut[base[((size_t)yy * W + xx) * CIN + c]] : 0.f;
+                acc += v * wr[t * CIN + c];
+            }
+        }
+        acc += sh;
+        f32x4 r;
+        r.x = acc.x > 0.f ? acc.x : 0.f; r.y = acc.y > 0.f ? acc.y : 0.f;
+        r.z = acc.z > 0.f ? acc.z : 0.f; r.w = acc.w > 0.f ? acc.w : 0.f;
+        *reinterpret_cast<f32x4 *>(out + (size_t)p * ldo + 4 * q) = r;
+    }
+}
+
+hipError_t launch_conv3x3_first(const uint8_t *img, const float *lut256, const float *w, const float *shift, float *out,
+                                int B, int H, int W, int Cin, int Cout, int ldo, hipStream_t s)
+{
+    const int quads = Cout / 4;
+    if (Cout % 4 || quads > 256 || 256 % quads || ldo % 4) return hipErrorInvalidValue;
+    const long long npix = (long long)B * H * W;
+    const int ppb = 256 / quads;
+    long long blocks = (npix + ppb - 1) / ppb;
+    if (blocks > 256 * 32) blocks = 256 * 32;
+    switch (Cin) {
+    case 1: hipLaunchKernelGGL(conv3x3_first_kernel<1>, dim3((unsigned)blocks), dim3(256), 0, s, img, lut256, w, shift, out, B, H, W, Cout, ldo, quads); break;
+    case 3: hipLaunchKernelGGL(conv3x3_first_kernel<3>, dim3((unsigned)blocks), dim3(256), 0, s, img, lut256, w, shift, out, B, H, W, Cout, ldo, quads); break;
+    default: return hipErrorInvalidValue;
+    }
+    return hipGetLastError();
+}
+
+// --------------------------------------------------------------------------------------------------------------------
+// 2x2 max pooling, stride 2; input may be the lower half of a concat buffer (channel stride ldc).  16 B per lane.
+__global__ __launch_bounds__(256) void maxpool2x2_kernel(const float *__restrict__ in, int ldc, float *__restrict__ out,
+                                                         int Ho, int Wo, int C4, long long total)
+{
+    const int W = 2 * Wo;
+    for (long long e = (long long)blockIdx.x * 256 + threadIdx.x; e < total; e += (long long)gridDim.x * 256) {
+        const int c4 = (int)(e % C4);
+        const long long p = e / C4;                 // output pixel index over [B][Ho][Wo]
+        const int xo = (int)(p % Wo);
+        const long long by = p / Wo;                // b*Ho + yo
+        const float *src = in + ((size_t)(2 * by) * W + 2 * xo) * ldc + 4 * c4;
+        const f32x4 v00 = *reinterpret_cast<const f32x4 *>(src);
+        const f32x4 v01 = *reinterpret_cast<const f32x4 *>(src + ldc);
+        const f32x4 v10 = *reinterpret_cast<const f32x4 *>(src + (size_t)W * ldc);
+        const f32x4 v11 = *reinterpret_cast<const f32x4 *>(src + (size_t)W * ldc + ldc);
+        f32x4 m;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            float t = v00[k];
+            t = v01[k] > t ? v01[k] : t;
+            t = v10[k] > t ? v10[k] : t;
+            t = v11[k] > t ? v11[k] : t;
+            m[k] = t;
+        }
+        *reinterpret_cast<f32x4 *>(out + (size_t)p * (4 * C4) + 4 * c4) = m;
+    }
+}
+
+hipError_t launch_maxpool2x2(const float *in, int ldc, float *out, int B, int H, int W, int C, hipStream_t s)
+{
+    if (C % 4 || ldc % 4 || H % 2 || W % 2) return hipErrorInvalidValue;
+    const int Ho = H / 2, Wo = W / 2, C4 = C / 4;
+    const long long total = (long long)B * Ho * Wo * C4;
+    long long blocks = (total + 255) / 256;
+    if (blocks > 256 * 16) blocks = 256 * 16;
+    hipLaunchKernelGGL(maxpool2x2_kernel, dim3((unsigned)blocks), dim3(256), 0, s, in, ldc, out, Ho, Wo, C4, total);
+    return hipGetLastError();
+}
+
+// --------------------------------------------------------------------------------------------------------------------
+// 1x1 head + argmax.  LPP = Cin/4 lanes share a pixel (each holds 4 channels = one 16-byte load, so a wave reads
+// 64/LPP whole NHWC rows, fully coalesced); partial dot products are combined with xor-shuffles inside the lane group.
+// argmax: strict '>' against -FLT_MAX in class order (src/process.cpp:158-170): ties and NaN keep the lower index.
+template <int CLASSES>
+__global__ __launch_bounds__(256) void head_argmax_kernel(const float *__restrict__ in, int Cin, const float *__restrict__ w,
+                                                          const float *__restrict__ bias, float *__restrict__ logits,
+                                                          uint8_t *__restrict__ labels, long long npix, int HW)
+{
+    const int lpp = Cin / 4;
+    const int q = threadIdx.x % lpp;
+    const int ppb = 256 / lpp;
+    f32x4 wr[CLASSES];
+    float bs[CLASSES];
+#pragma unroll
+    for (int k = 0; k < CLASSES; ++k) {
+        wr[k] = *reinterpret_cast<const f32x4 *>(w + (size_t)k * Cin + 4 * q);
+        bs[k] = bias[k];
+    }
+    // every lane of a group iterates together (npix is padded to the group count by the loop bound on the group id)
+    for (long long p = (long long)blockIdx.x * ppb + threadIdx.x / lpp; p < npix; p += (long long)gridDim.x * ppb) {
+        const f32x4 v = *reinterpret_cast<const f32x4 *>(in + (size_t)p * Cin + 4 * q);
+        float d[CLASSES];
+#pragma unroll
+        for (int k = 0; k < CLASSES; ++k) {
+            // sequential within the lane, then a butterfly over the group: a fixed, data-independent order
+            float t = v.x * wr[k].x;
+            t += v.y * wr[k].y;
+            t += v.z * wr[k].z;
+            t += v.w * wr[k].w;
+            for (int o = 1; o < lpp; o <<= 1) t += __shfl_xor(t, o, 64);
+            d[k] = t + bs[k];
+        }
+        if (q == 0) {
+            const long long bimg = p / HW, pin = p % HW;
+            float best = -3.402823466e+38f;
+            int idx = 0;
+#pragma unroll
+            for (int k = 0; k < CLASSES; ++k) {
+                if (logits) logits[((size_t)bimg * CLASSES + k) * HW + pin] = d[k];
+                if (d[k] > best) { best = d[k]; idx = k; }
+            }
+            labels[p] = (uint8_t)idx;
+        }
+    }
+}
+
+hipError_t launch_head_argmax(const float *in, int Cin, const float *w, const float *bias, int classes, float *logits,
+                              uint8_t *labels, int B, int HW, hipStream_t s)
+{
+    const int lpp = Cin / 4;
+    if (Cin % 4 || lpp > 64 || (lpp & (lpp - 1))) return hipErrorInvalidValue;
+    const long long npix = (long long)B * HW;
+    const int ppb = 256 / lpp;
+    // the shuffle needs whole lane groups active: npix must be a multiple of the pixels per wave
+    if (npix % (64 / lpp)) return hipErrorInvalidValue;
+    long long blocks = (npix + ppb - 1) / ppb;
+    if (blocks > 256 * 16) blocks = 256 * 16;
+#define HEAD_CASE(K) case K: hipLaunchKernelGGL(head_argmax_kernel<K>, dim3((unsigned)blocks), dim3(256), 0, s, in, Cin, w, bias, logits, labels, npix, HW); break;
+    switch (classes) {
+        HEAD_CASE(2) HEAD_CASE(3) HEAD_CASE(4) HEAD_CASE(5) HEAD_CASE(6)
+    default: return hipErrorInvalidValue;
+    }
+#undef HEAD_CASE
+    return hipGetLastError();
+}
+
+
+}  // namespace miunet
