@@ -35,7 +35,9 @@ struct WinoGeom {
     static constexpr size_t LDS_BYTES = sizeof(float) * (2 * VBUF + RAW_FLOATS);
 };
 
-template <int WM, int WN>
+// SPLITK = false compiles the split-K paths out entirely (the full-K kernel's register allocation and schedule are
+// exactly those of a kernel without them: measured, a runtime ksplit == 1 path costs 4 % at batch 16).
+template <int WM, int WN, bool SPLITK>
 __global__ __launch_bounds__(256, 1) void conv3x3_wino_f32(const ConvArgs a, const int tiles_x, const int tiles_y,
                                                            const int m_tiles, const int nwg)
 {
@@ -53,7 +55,9 @@ __global__ __launch_bounds__(256, 1) void conv3x3_wino_f32(const ConvArgs a, con
     const int wm = wave / WN, wn = wave % WN;
     const int li = lane & 31, lh = lane >> 5;
 
-    const int L = xcd_remap(blockIdx.x, nwg);
+    int L = xcd_remap(blockIdx.x, nwg);
+    int ks = 0;                               // K slice of this workgroup
+    if constexpr (SPLITK) { ks = L % a.ksplit; L /= a.ksplit; }
     const int n_tile = L / m_tiles;
     int m = L - n_tile * m_tiles;
     const int tx = m % tiles_x; m /= tiles_x;
@@ -167,13 +171,20 @@ __global__ __launch_bounds__(256, 1) void conv3x3_wino_f32(const ConvArgs a, con
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[p][r] = 0.f;
 
-    const int nchunks = (a.Cin + WINO_KC - 1) / WINO_KC;
-    const int nsuper = (a.Cin + WINO_SC - 1) / WINO_SC;
+    // this workgroup's K range [c_begin, nchunks): whole super-chunks (c_begin is a multiple of 4), never empty
+    const int all_chunks = (a.Cin + WINO_KC - 1) / WINO_KC;
+    int c_begin = 0, nchunks = all_chunks;
+    if constexpr (SPLITK) {
+        const int per_slice = ((all_chunks + a.ksplit - 1) / a.ksplit + CPS - 1) / CPS * CPS;
+        c_begin = ks * per_slice;
+        nchunks = (c_begin + per_slice < all_chunks) ? c_begin + per_slice : all_chunks;
+    }
+    const int nsuper = (nchunks + CPS - 1) / CPS;
     f32x4 u[16];
 #pragma unroll
-    for (int p = 0; p < 16; ++p) u[p] = u_load(0, p);
-    // prologue: raw patch of super-chunk 0 -> LDS, V of chunk 0
-    raw_load(0);
+    for (int p = 0; p < 16; ++p) u[p] = u_load(c_begin, p);
+    // prologue: raw patch of the first super-chunk -> LDS, V of the first chunk
+    raw_load(c_begin / CPS);
     raw_store();
     __syncthreads();
 #pragma unroll
@@ -188,7 +199,7 @@ __global__ __launch_bounds__(256, 1) void conv3x3_wino_f32(const ConvArgs a, con
     //   always : 64 MFMAs; the V fragment one position ahead; the U refill one chunk ahead; during positions 4-6 the 12
     //            ds_reads of the NEXT chunk's patch, during positions 8-13 its transform, one piece after every other MFMA
     //            (a lone wave per SIMD issues in order: a filler only hides if it sits BETWEEN two MFMAs); one barrier.
-    for (int chunk = 0; chunk < nchunks; ++chunk) {
+    for (int chunk = c_begin; chunk < nchunks; ++chunk) {
         const int j = chunk & (CPS - 1), S = chunk / CPS;
         if (j == 0 && S + 1 < nsuper) raw_load(S + 1);
         if (j == CPS - 1 && S + 1 < nsuper) {
@@ -240,6 +251,15 @@ __global__ __launch_bounds__(256, 1) void conv3x3_wino_f32(const ConvArgs a, con
         float y[2][2];
         y[0][0] = s0[0] + s0[1] + s0[2]; y[0][1] = s0[1] - s0[2] - s0[3];
         y[1][0] = s1[0] + s1[1] + s1[2]; y[1][1] = s1[1] - s1[2] - s1[3];
+        if constexpr (SPLITK) {               // partial sums of this K slice: the reduce kernel finishes the layer
+#pragma unroll
+            for (int dy = 0; dy < 2; ++dy)
+#pragma unroll
+                for (int dx = 0; dx < 2; ++dx)
+                    if (n_ok && oy + dy < a.H && ox + dx < a.W)
+                        a.ksplit_ws[((((size_t)ks * a.B + b) * a.H + oy + dy) * a.W + ox + dx) * a.Cout + ncol] = y[dy][dx];
+            continue;
+        }
         float vmax = -3.402823466e+38f;
 #pragma unroll
         for (int dy = 0; dy < 2; ++dy)
@@ -474,17 +494,78 @@ hipError_t launch_conv3x3_wino16(const ConvArgs &a, hipStream_t s)
     return launch_wino16(a, s);
 }
 
-template <int WM, int WN>
-static hipError_t launch_wino_cfg(const ConvArgs &a, hipStream_t s)
+// sum the K slices in slice order, then shift, ReLU, channel-offset store and the optional 2x2 max pooling.
+// One thread = one 2x2 pixel block x 4 channels (16-byte accesses).
+__global__ __launch_bounds__(256) void wino_splitk_reduce(const ConvArgs a, long long total)
 {
+    const int C4 = a.Cout / 4, Hb = (a.H + 1) / 2, Wb = (a.W + 1) / 2;
+    for (long long e = (long long)blockIdx.x * 256 + threadIdx.x; e < total; e += (long long)gridDim.x * 256) {
+        const int c4 = (int)(e % C4);
+        long long t = e / C4;
+        const int xb = (int)(t % Wb); t /= Wb;
+        const int yb = (int)(t % Hb);
+        const int b = (int)(t / Hb);
+        const f32x4 sh = *reinterpret_cast<const f32x4 *>(a.bias + 4 * c4);
+        f32x4 vmax = { -3.402823466e+38f, -3.402823466e+38f, -3.402823466e+38f, -3.402823466e+38f };
+#pragma unroll
+        for (int dy = 0; dy < 2; ++dy)
+#pragma unroll
+            for (int dx = 0; dx < 2; ++dx) {
+                const int y = 2 * yb + dy, x = 2 * xb + dx;
+                if (y >= a.H || x >= a.W) continue;
+                const size_t px = ((size_t)b * a.H + y) * a.W + x;
+                f32x4 acc = *reinterpret_cast<const f32x4 *>(a.ksplit_ws + px * a.Cout + 4 * c4);
+                for (int k = 1; k < a.ksplit; ++k)
+                    acc += *reinterpret_cast<const f32x4 *>(a.ksplit_ws + ((size_t)k * a.B * a.H * a.W + px) * a.Cout + 4 * c4);
+                acc += sh;
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    if (a.relu) acc[q] = acc[q] > 0.f ? acc[q] : 0.f;
+                    vmax[q] = fmaxf(vmax[q], acc[q]);
+                }
+                *reinterpret_cast<f32x4 *>(a.out + px * a.ldo + a.co_off + 4 * c4) = acc;
+            }
+        if (a.pool_out != nullptr && 2 * yb + 1 < a.H && 2 * xb + 1 < a.W)
+            *reinterpret_cast<f32x4 *>(a.pool_out + (((size_t)b * (a.H >> 1) + yb) * (a.W >> 1) + xb) * a.pool_ld + 4 * c4) = vmax;
+    }
+}
+
+template <int WM, int WN>
+static hipError_t launch_wino_cfg(const ConvArgs &a0, hipStream_t s)
+{
+    ConvArgs a = a0;
     const int tiles_x = (a.W + 15) / 16, tiles_y = (a.H + 8 * WM - 1) / (8 * WM);
     const int m_tiles = tiles_x * tiles_y * a.B;
     const int n_tiles = (a.Cout + 32 * WN - 1) / (32 * WN);
-    const int nwg = m_tiles * n_tiles;
+    // split K only when the grid cannot fill half of the 256 CUs (one workgroup per CU): each slice keeps >= 2 super-chunks
+    a.ksplit = 1;
+    const int chunks = (a.Cin + WINO_KC - 1) / WINO_KC, tiles = m_tiles * n_tiles;
+    if (a.ksplit_ws != nullptr && tiles <= 128 && chunks >= 16 && a.Cout % 4 == 0 && a.ldo % 4 == 0 && a.co_off % 4 == 0) {
+        int ks = 256 / tiles;
+        if (ks > 8) ks = 8;
+        if (ks > chunks / 8) ks = chunks / 8;
+        while (ks > 1 && (size_t)ks * a.B * a.H * a.W * a.Cout * sizeof(float) > a.ksplit_ws_bytes) --ks;
+        // every slice must own at least one chunk after rounding its share up to whole super-chunks
+        while (ks > 1 && (ks - 1) * (((chunks + ks - 1) / ks + 3) / 4 * 4) >= chunks) --ks;
+        a.ksplit = ks;
+    }
+    const int nwg = tiles * a.ksplit;
     constexpr size_t lds = WinoGeom<WM, WN>::LDS_BYTES;
-    auto kern = conv3x3_wino_f32<WM, WN>;
-    if (hipError_t e = ensure_dynamic_lds(kern, lds); e != hipSuccess) return e;
-    hipLaunchKernelGGL(kern, dim3(nwg), dim3(256), lds, s, a, tiles_x, tiles_y, m_tiles, nwg);
+    if (a.ksplit > 1) {
+        auto kern = conv3x3_wino_f32<WM, WN, true>;
+        if (hipError_t e = ensure_dynamic_lds(kern, lds); e != hipSuccess) return e;
+        hipLaunchKernelGGL(kern, dim3(nwg), dim3(256), lds, s, a, tiles_x, tiles_y, m_tiles, nwg);
+    } else {
+        auto kern = conv3x3_wino_f32<WM, WN, false>;
+        if (hipError_t e = ensure_dynamic_lds(kern, lds); e != hipSuccess) return e;
+        hipLaunchKernelGGL(kern, dim3(nwg), dim3(256), lds, s, a, tiles_x, tiles_y, m_tiles, nwg);
+    }
+    if (a.ksplit > 1) {
+        const long long total = (long long)a.B * ((a.H + 1) / 2) * ((a.W + 1) / 2) * (a.Cout / 4);
+        long long blocks = (total + 255) / 256;
+        if (blocks > 2048) blocks = 2048;
+        hipLaunchKernelGGL(wino_splitk_reduce, dim3((unsigned)blocks), dim3(256), 0, s, a, total);
+    }
     return hipGetLastError();
 }
 

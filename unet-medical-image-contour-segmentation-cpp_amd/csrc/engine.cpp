@@ -71,6 +71,8 @@ struct mi_unet {
     size_t raw_cap = 0;             // samples
     uint16_t *h_raw = nullptr;      // pinned
     unsigned *d_mnmx = nullptr;     // [max_batch][2]
+    float *d_ksplit = nullptr;      // split-K slabs of the Winograd kernel (small batches / deep levels only)
+    size_t ksplit_bytes = 0;
     int *d_cont = nullptr;          // contour outputs of mi_unet_extract_contours (grown on demand)
     size_t cont_cap = 0;            // ints
     // pinned host staging (the reference used pageable std::vector, src/process.cpp:138,152)
@@ -467,6 +469,7 @@ int launch_plan(mi_unet *h, const uint8_t *d_imgs, int B, uint8_t *d_labels, flo
             break;
         case Step::CONV: {
             ConvArgs a = st.a; a.B = B;
+            a.ksplit_ws = h->d_ksplit; a.ksplit_ws_bytes = h->ksplit_bytes;
             if (h->algo == MI_UNET_CONV_BF16) { kname = "conv3x3_bf16"; e = launch_conv3x3_bf16(a, s); }
             else if (h->algo == MI_UNET_CONV_FP16) { kname = "conv3x3_fp16"; e = launch_conv3x3_fp16(a, s); }
             else if (h->algo == MI_UNET_CONV_WINOGRAD16) { kname = "conv3x3_wino16"; e = launch_conv3x3_wino16(a, s); }
@@ -611,6 +614,13 @@ int mi_unet_create(const mi_unet_config *cfg, mi_unet_t **out)
     HIP_TRY_H(hipMalloc(&h->d_logits, sizeof(float) * npix0 * cfg->classes));
     HIP_TRY_H(hipHostMalloc(&h->h_img, npix0 * cfg->in_ch, hipHostMallocDefault));
     HIP_TRY_H(hipHostMalloc(&h->h_labels, npix0, hipHostMallocDefault));
+    {
+        const char *sk = getenv("MIUNET_SPLITK");
+        if (!(sk && !strcmp(sk, "0"))) {
+            h->ksplit_bytes = (size_t)64 << 20;
+            HIP_TRY_H(hipMalloc(&h->d_ksplit, h->ksplit_bytes));
+        }
+    }
     HIP_TRY_H(hipMalloc(&h->d_lut, sizeof(float) * 256));
     float lut[256];
     for (int i = 0; i < 256; ++i) lut[i] = static_cast<float>(i) / 255.0f;   // src/process.cpp:38, true division
@@ -1019,7 +1029,7 @@ void mi_unet_destroy(mi_unet_t *h)
     if (h->own_stream) (void)hipStreamSynchronize(h->own_stream);
     for (int i = 0; i < 8; ++i)
         if (h->d_cat[i]) (void)hipFree(h->d_cat[i]);
-    void *dev[] = { h->d_weights, h->d_lut, h->d_s0, h->d_s1, h->d_img, h->d_labels, h->d_logits, h->d_raw, h->d_mnmx, h->d_cont };
+    void *dev[] = { h->d_weights, h->d_lut, h->d_s0, h->d_s1, h->d_img, h->d_labels, h->d_logits, h->d_raw, h->d_mnmx, h->d_cont, h->d_ksplit };
     for (void *p : dev)
         if (p) (void)hipFree(p);
     if (h->h_img) (void)hipHostFree(h->h_img);

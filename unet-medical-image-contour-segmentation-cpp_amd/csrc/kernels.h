@@ -28,6 +28,13 @@ struct ConvArgs {
     // channel 0.  Both conv kernels hold every 2x2 output block inside one lane, so this costs one max3 + one store.
     float *pool_out;
     int pool_ld;
+    // optional split-K workspace (Winograd kernel only): when the (tile, channel) grid alone cannot fill the chip (single
+    // images, deep levels) the launcher cuts K = Cin into up to 8 slices, each workgroup writes its partial 2x2 outputs into
+    // slab [slice][B][H][W][Cout] and a second kernel sums the slabs in a fixed order (deterministic) and applies the
+    // shift / ReLU / pooling.  nullptr or too small = never split.
+    float *ksplit_ws;
+    size_t ksplit_ws_bytes;
+    int ksplit;           // set by the launcher
 };
 
 hipError_t launch_conv3x3_mfma(const ConvArgs &a, hipStream_t s);
