@@ -1,6 +1,7 @@
 // Reference: include/mask2polygon.h:7-23, src/mask2polygon.cpp.
 #pragma once
 #include <map>
+#include <iostream>
 #include <string>
 #include <vector>
 
@@ -30,7 +31,7 @@ void process_single_mask(const std::string &mask_path, const std::string &output
 medseg::Image8 draw_overlay(const medseg::Image8 &gray_or_bgr, const std::vector<medseg::Contour> &contours);
 void write_polygon_outputs(const std::vector<medseg::Contour> &contours, const medseg::Image8 &normalized_tile,
                            const std::string &output_dir, const std::string &base_name, int original_width,
-                           int original_height);
+                           int original_height, std::ostream &console = std::cout);
 
 // The document generate_json writes, as a string (4-space indent, sorted keys, trailing newline).
 std::string polygon_json_text(const std::vector<medseg::Contour> &contours, const std::string &base_name, int original_width,

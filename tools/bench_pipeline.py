@@ -1,0 +1,67 @@
+#!/usr/bin/env python3
+"""Stage timings of the device half of the pipeline (mi_unet_segment_raw16 and its parts) and of the host facade's
+directory mode, on one GPU.  Not the headline metric (bench.py): a measurement aid for DESIGN.md §7."""
+import os
+import sys
+import tempfile
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "unet-medical-image-contour-segmentation-cpp_amd"))
+import numpy as np  # noqa: E402
+
+from miunet import binding, hostlib, synth  # noqa: E402
+from miunet.spec import UNetSpec, pack_weights  # noqa: E402
+
+
+def t(fn, n=5):
+    fn()
+    t0 = time.perf_counter()
+    for _ in range(n):
+        fn()
+    return (time.perf_counter() - t0) / n * 1e3
+
+
+def main():
+    B = int(sys.argv[1]) if len(sys.argv) > 1 else 16
+    spec = UNetSpec()
+    blob = pack_weights(spec, synth.make_threshold_weights(spec))
+    raws = [synth.make_raw16(1536, 2048, seed=100 + i) for i in range(B)]
+    with binding.Engine(512, 512, max_batch=B) as eng:
+        eng.load_weights(blob)
+        tiles, labels, _ = eng.infer_raw16(raws)
+        post = eng.postprocess_masks(labels)
+        vis = np.where(post == 2, 255, 0).astype(np.uint8)
+        print(f"B={B}  RAW 2048x1536 -> 512x512")
+        print(f"  infer_u8 (tiles on host -> labels)          {t(lambda: eng.infer(tiles[..., None])):8.2f} ms")
+        print(f"  infer_raw16 (RAW on host -> tiles, labels)  {t(lambda: eng.infer_raw16(raws)):8.2f} ms")
+        print(f"  postprocess_masks (host labels in/out)      {t(lambda: eng.postprocess_masks(labels)):8.2f} ms")
+        print(f"  extract_contours (host masks in)            {t(lambda: eng.extract_contours(vis, 1 << 15, 64)):8.2f} ms")
+        print(f"  segment_raw16 (everything, one call)        {t(lambda: eng.segment_raw16(raws, 1 << 15, 64)):8.2f} ms")
+        nc = [len(c) for c in eng.extract_contours(vis, 1 << 15, 64)]
+        print("  contours per image:", nc[:8], "points in the longest:", max((len(c) for cs in eng.extract_contours(vis, 1 << 15, 64) for c in cs), default=0))
+    # host facade: directory mode, batch vs single
+    with tempfile.TemporaryDirectory() as d:
+        eng_dir = os.path.join(d, "engine"); os.makedirs(eng_dir)
+        wp = os.path.join(eng_dir, "unet.miw"); open(wp, "wb").write(blob)
+        paths = []
+        for i, r in enumerate(raws):
+            p = os.path.join(d, f"img{i:03d}.raw"); r.tofile(p); paths.append(p)
+        out = os.path.join(d, "out"); os.makedirs(out)
+        assert hostlib.initialize_engine(wp, os.path.join(d, "log"))
+        hostlib.process_image_batch(paths, [2048] * B, [1536] * B, out)                 # warm-up at the full size (staging buffers grow once)
+        t0 = time.perf_counter(); n = hostlib.process_image_batch(paths, [2048] * B, [1536] * B, out); tb = time.perf_counter() - t0
+        t0 = time.perf_counter()
+        for p in paths:
+            hostlib.process_single_image(p, 2048, 1536, out)
+        ts = time.perf_counter() - t0
+        hostlib.cleanup_resources()
+        for root, _, files in os.walk(os.path.join(d, "log")):
+            for f in files:
+                lines = [l.strip() for l in open(os.path.join(root, f), errors="replace") if l.startswith("Batch ")]
+                print("  facade log (last batch):", "; ".join(lines[-3:]))
+        print(f"  facade process_image_batch: {tb / B * 1e3:.2f} ms/image ({n} ok); process_single_image loop: {ts / B * 1e3:.2f} ms/image")
+
+
+if __name__ == "__main__":
+    main()

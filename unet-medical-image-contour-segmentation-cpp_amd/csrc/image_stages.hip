@@ -13,6 +13,7 @@ __global__ __launch_bounds__(256) void minmax_init_kernel(unsigned *mnmx)
 
 __global__ __launch_bounds__(256) void minmax_u16_kernel(const uint16_t *__restrict__ raw, size_t n, unsigned *mnmx)
 {
+    __shared__ unsigned s_lo[4], s_hi[4];
     unsigned lo = 65535u, hi = 0u;
     const size_t n8 = n / 8;                                   // 16 bytes = 8 samples per lane
     const uint4 *v = reinterpret_cast<const uint4 *>(raw);
@@ -35,9 +36,11 @@ __global__ __launch_bounds__(256) void minmax_u16_kernel(const uint16_t *__restr
         lo = min(lo, (unsigned)__shfl_xor((int)lo, o, 64));
         hi = max(hi, (unsigned)__shfl_xor((int)hi, o, 64));
     }
-    if ((threadIdx.x & 63) == 0) {
-        atomicMin(&mnmx[0], lo);
-        atomicMax(&mnmx[1], hi);
+    if ((threadIdx.x & 63) == 0) { s_lo[threadIdx.x >> 6] = lo; s_hi[threadIdx.x >> 6] = hi; }
+    __syncthreads();
+    if (threadIdx.x == 0) {                                     // ONE atomic pair per workgroup: same-address atomics serialise
+        atomicMin(&mnmx[0], min(min(s_lo[0], s_lo[1]), min(s_lo[2], s_lo[3])));
+        atomicMax(&mnmx[1], max(max(s_hi[0], s_hi[1]), max(s_hi[2], s_hi[3])));
     }
 }
 
@@ -46,7 +49,7 @@ hipError_t launch_minmax_u16(const uint16_t *raw, size_t n, unsigned *mnmx, hipS
     if (n == 0 || (reinterpret_cast<uintptr_t>(raw) & 15)) return hipErrorInvalidValue;
     hipLaunchKernelGGL(minmax_init_kernel, dim3(1), dim3(256), 0, s, mnmx);
     size_t blocks = (n / 8 + 255) / 256;
-    if (blocks > 2048) blocks = 2048;
+    if (blocks > 512) blocks = 512;
     if (blocks == 0) blocks = 1;
     hipLaunchKernelGGL(minmax_u16_kernel, dim3((unsigned)blocks), dim3(256), 0, s, raw, n, mnmx);
     return hipGetLastError();
@@ -97,11 +100,24 @@ hipError_t launch_resample_u8(const uint16_t *raw, int w, int h, const unsigned 
 namespace pp {
 
 __device__ __forceinline__ int ld(const int *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ void st(int *p, int v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 
-__device__ __forceinline__ int find_root(const int *parent, int x)
+// root of x with path halving: every store writes an ancestor of the node, so racing finds / unions stay consistent
+__device__ __forceinline__ int find_root(int *parent, int x)
 {
     int p = ld(parent + x);
-    while (p != x) { x = p; p = ld(parent + x); }
+    while (p != x) {
+        const int g = ld(parent + p);
+        if (g != p) st(parent + x, g);
+        x = p; p = g;
+    }
+    return x;
+}
+
+// read-only walk for the flatten pass: there every store must be the final root, so no halving stores may race with it
+__device__ __forceinline__ int find_root_ro(const int *parent, int x)
+{
+    for (int p = ld(parent + x); p != x; p = ld(parent + x)) x = p;
     return x;
 }
 
@@ -119,42 +135,85 @@ __device__ __forceinline__ void unite(int *parent, int a, int b)
     }
 }
 
-// fg[i] != 0 marks foreground.  parent = own index for fg, -1 for bg; stats cleared.
+// fg[i] != 0 marks foreground.  parent = first pixel of the horizontal run inside the lane's 64-pixel segment (so the
+// forest starts with chains no longer than W/64 per row instead of one node per pixel), -1 for background; stats cleared.
 __global__ __launch_bounds__(256) void cc_init(const uint8_t *__restrict__ fg, int *parent, int *area, int *minx, int *miny,
-                                               int *maxx, int *maxy, long long n)
+                                               int *maxx, int *maxy, int W, long long n)
 {
     const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
-    if (i >= n) return;
-    parent[i] = fg[i] ? (int)i : -1;
-    area[i] = 0; minx[i] = 0x7FFFFFFF; miny[i] = 0x7FFFFFFF; maxx[i] = -1; maxy[i] = -1;
+    const bool in = i < n;
+    const bool f = in && fg[i] != 0;
+    const int x = in ? (int)(i % W) : 0;
+    const int lane = threadIdx.x & 63;
+    const unsigned long long fm = __ballot(f);
+    const unsigned long long prev = (fm << 1) & ~__ballot(x == 0);      // lanes whose left neighbour (same row, same wave) is fg
+    const unsigned long long starts = fm & ~prev;                        // first pixel of each run in this segment
+    if (in) {
+        int p = -1;
+        if (f) {
+            const unsigned long long below = starts & ((2ull << lane) - 1ull);
+            p = (int)i - (lane - (63 - __builtin_clzll(below)));
+        }
+        parent[i] = p;
+        area[i] = 0; minx[i] = 0x7FFFFFFF; miny[i] = 0x7FFFFFFF; maxx[i] = -1; maxy[i] = -1;
+    }
 }
 
+// 8-connected unions.  Horizontal: only where a run continues across a 64-pixel segment boundary.  Vertical: with the
+// pixel above if it is set -- skipped when the left neighbour and the upper-left pixel are set too (that pair already made
+// the same connection) -- otherwise with the two upper diagonals.
 __global__ __launch_bounds__(256) void cc_merge(const uint8_t *__restrict__ fg, int *parent, int H, int W, long long n)
 {
     const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
     if (i >= n || !fg[i]) return;
     const int hw = H * W;
     const int p = (int)(i % hw), y = p / W, x = p - y * W;
-    if (x > 0 && fg[i - 1]) unite(parent, (int)i, (int)i - 1);
+    const bool l = x > 0 && fg[i - 1];
+    if (l && (threadIdx.x & 63) == 0) unite(parent, (int)i, (int)i - 1);
     if (y > 0) {
-        if (fg[i - W]) unite(parent, (int)i, (int)i - W);
-        if (x > 0 && fg[i - W - 1]) unite(parent, (int)i, (int)i - W - 1);
-        if (x + 1 < W && fg[i - W + 1]) unite(parent, (int)i, (int)i - W + 1);
+        const bool ul = x > 0 && fg[i - W - 1], u = fg[i - W] != 0, ur = x + 1 < W && fg[i - W + 1];
+        if (u) {
+            if (!(l && ul)) unite(parent, (int)i, (int)i - W);
+        } else {
+            if (ul && !l) unite(parent, (int)i, (int)i - W - 1);      // with l set, the left pixel makes this union (as its 'u' or 'ur')
+            if (ur) unite(parent, (int)i, (int)i - W + 1);
+        }
     }
 }
 
+// flatten + per-component area and bounding box.  Lanes of a wave mostly share one root, and same-address atomics
+// serialise, so the wave first reduces per distinct root and one lane issues the five atomics.
 __global__ __launch_bounds__(256) void cc_stats(int *parent, int *area, int *minx, int *miny, int *maxx, int *maxy, int H, int W,
                                                 long long n)
 {
     const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
-    if (i >= n || parent[i] < 0) return;
-    const int r = find_root(parent, (int)i);
-    parent[i] = r;                                              // flatten (only this thread writes parent[i] in this kernel...
-    const int hw = H * W;                                       // ... and a non-root's value is never used as a union target)
-    const int p = (int)(i % hw), y = p / W, x = p - y * W;
-    atomicAdd(area + r, 1);
-    atomicMin(minx + r, x); atomicMax(maxx + r, x);
-    atomicMin(miny + r, y); atomicMax(maxy + r, y);
+    int r = -1, x = 0, y = 0;
+    if (i < n && parent[i] >= 0) {
+        r = find_root_ro(parent, (int)i);
+        parent[i] = r;
+        const int p = (int)(i % ((long long)H * W));
+        y = p / W; x = p - y * W;
+    }
+    const int lane = threadIdx.x & 63;
+    unsigned long long todo = __ballot(r >= 0);
+    while (todo) {
+        const int leader = __builtin_ctzll(todo);
+        const int r0 = __shfl(r, leader, 64);
+        const bool mine = r == r0;
+        const unsigned long long m = __ballot(mine);
+        int lx = mine ? x : 0x7FFFFFFF, hx = mine ? x : -1, ly = mine ? y : 0x7FFFFFFF, hy = mine ? y : -1;
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+            lx = min(lx, __shfl_xor(lx, o, 64)); hx = max(hx, __shfl_xor(hx, o, 64));
+            ly = min(ly, __shfl_xor(ly, o, 64)); hy = max(hy, __shfl_xor(hy, o, 64));
+        }
+        if (lane == leader) {
+            atomicAdd(area + r0, __builtin_popcountll(m));
+            atomicMin(minx + r0, lx); atomicMax(maxx + r0, hx);
+            atomicMin(miny + r0, ly); atomicMax(maxy + r0, hy);
+        }
+        todo &= ~m;
+    }
 }
 
 __global__ __launch_bounds__(256) void k_inv(const uint8_t *__restrict__ labels, uint8_t *inv, long long n)
@@ -224,7 +283,7 @@ hipError_t launch_postprocess_masks(const uint8_t *labels_in, uint8_t *labels_ou
     uint8_t *u0 = reinterpret_cast<uint8_t *>(maxy + n), *u1 = u0 + n, *u2 = u1 + n;
     const dim3 g((unsigned)((n + 255) / 256)), b(256);
     auto label = [&](const uint8_t *fg) {
-        hipLaunchKernelGGL(pp::cc_init, g, b, 0, s, fg, parent, area, minx, miny, maxx, maxy, n);
+        hipLaunchKernelGGL(pp::cc_init, g, b, 0, s, fg, parent, area, minx, miny, maxx, maxy, W, n);
         hipLaunchKernelGGL(pp::cc_merge, g, b, 0, s, fg, parent, H, W, n);
         hipLaunchKernelGGL(pp::cc_stats, g, b, 0, s, parent, area, minx, miny, maxx, maxy, H, W, n);
     };
@@ -264,15 +323,17 @@ __global__ __launch_bounds__(256) void k_threshold(const uint8_t *__restrict__ m
     bg[i] = f ? 0 : 255;
 }
 
-// 4-connected union (background regions)
+// 4-connected unions (background regions): across segment boundaries horizontally; vertically unless the left pair
+// already made the connection
 __global__ __launch_bounds__(256) void cc_merge4(const uint8_t *__restrict__ fg, int *parent, int H, int W, long long n)
 {
     const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
     if (i >= n || !fg[i]) return;
     const int hw = H * W;
     const int p = (int)(i % hw), y = p / W, x = p - y * W;
-    if (x > 0 && fg[i - 1]) pp::unite(parent, (int)i, (int)i - 1);
-    if (y > 0 && fg[i - W]) pp::unite(parent, (int)i, (int)i - W);
+    const bool l = x > 0 && fg[i - 1];
+    if (l && (threadIdx.x & 63) == 0) pp::unite(parent, (int)i, (int)i - 1);
+    if (y > 0 && fg[i - W] && !(l && fg[i - W - 1])) pp::unite(parent, (int)i, (int)i - W);
 }
 
 __global__ __launch_bounds__(256) void k_zero_counts(int *counts, int B)
@@ -418,11 +479,11 @@ hipError_t launch_extract_contours(const uint8_t *masks, int B, int H, int W, in
     const dim3 g((unsigned)((n + 255) / 256)), b(256);
     hipLaunchKernelGGL(ct::k_threshold, g, b, 0, s, masks, fg, bg, n);
     // foreground labelling (8-connected); its stats are not needed, the arrays are reused by the background pass
-    hipLaunchKernelGGL(pp::cc_init, g, b, 0, s, fg, fparent, area, minx, miny, maxx, maxy, n);
+    hipLaunchKernelGGL(pp::cc_init, g, b, 0, s, fg, fparent, area, minx, miny, maxx, maxy, W, n);
     hipLaunchKernelGGL(pp::cc_merge, g, b, 0, s, fg, fparent, H, W, n);
     hipLaunchKernelGGL(pp::cc_stats, g, b, 0, s, fparent, area, minx, miny, maxx, maxy, H, W, n);
     // background labelling (4-connected) with bounding boxes
-    hipLaunchKernelGGL(pp::cc_init, g, b, 0, s, bg, bparent, area, minx, miny, maxx, maxy, n);
+    hipLaunchKernelGGL(pp::cc_init, g, b, 0, s, bg, bparent, area, minx, miny, maxx, maxy, W, n);
     hipLaunchKernelGGL(ct::cc_merge4, g, b, 0, s, bg, bparent, H, W, n);
     hipLaunchKernelGGL(pp::cc_stats, g, b, 0, s, bparent, area, minx, miny, maxx, maxy, H, W, n);
     hipLaunchKernelGGL(ct::k_zero_counts, dim3((B + 255) / 256), b, 0, s, counts, B);

@@ -2,11 +2,13 @@
 // (include/mi_unet.h).  Reference: src/initialize.cpp:26-91, src/process.cpp:123-262, src/cleanup.cpp:10-64.
 // Same log file name, banner lines, message prefixes and bool/void error conventions; the TensorRT engine, the
 // thread-local execution context and the CUDA graph are replaced by one mi_unet handle.
+#include <algorithm>
 #include <chrono>
 #include <cstdlib>
 #include <filesystem>
 #include <iostream>
 #include <mutex>
+#include <sstream>
 #include <stdexcept>
 
 #include "../../include/medseg/cleanup.h"
@@ -172,15 +174,29 @@ int process_image_batch(const std::vector<std::string> &raw_paths, const std::ve
         std::vector<const uint16_t *> ptrs;
         std::vector<int> ws, hs;
         std::vector<size_t> idx;                           // images that could be read
-        for (size_t i = 0; i < n; ++i) {
+        std::vector<std::string> read_err(n);
+        const auto t_read = std::chrono::high_resolution_clock::now();
+        const int io_threads = (int)std::max<size_t>(1, std::min<size_t>(n, 8));   // a few I/O threads, never the whole machine
+#pragma omp parallel for schedule(dynamic) num_threads(io_threads)   // independent file reads; messages in file order below
+        for (long long i = 0; i < (long long)n; ++i) {
             try {
                 raws[i] = Preprocess::read_raw16(raw_paths[i], widths[i], heights[i]);
-                ptrs.push_back(raws[i].data()); ws.push_back(widths[i]); hs.push_back(heights[i]); idx.push_back(i);
             } catch (const std::exception &e) {
-                std::cerr << "Processing error: " << e.what() << " (" << raw_paths[i] << ")" << std::endl;
-                if (log_file.is_open()) log_file << "Processing error: " << e.what() << " (" << raw_paths[i] << ")" << std::endl;
+                read_err[i] = std::string("Processing error: ") + e.what() + " (" + raw_paths[i] + ")";
+                raws[i].clear();
             }
         }
+        for (size_t i = 0; i < n; ++i) {
+            if (read_err[i].empty()) {
+                ptrs.push_back(raws[i].data()); ws.push_back(widths[i]); hs.push_back(heights[i]); idx.push_back(i);
+            } else {
+                std::cerr << read_err[i] << std::endl;
+                if (log_file.is_open()) log_file << read_err[i] << std::endl;
+            }
+        }
+        if (log_file.is_open())
+            log_file << "Batch read time: " << std::chrono::duration_cast<std::chrono::milliseconds>(std::chrono::high_resolution_clock::now() - t_read).count()
+                     << " ms for " << n << " files" << std::endl;
         const size_t hw = (size_t)g_cfg.height * g_cfg.width;
         std::vector<uint8_t> tiles(hw * idx.size()), labels(hw * idx.size());
         const auto t0 = std::chrono::high_resolution_clock::now();
@@ -197,12 +213,17 @@ int process_image_batch(const std::vector<std::string> &raw_paths, const std::ve
             }
             const auto ms = std::chrono::duration_cast<std::chrono::milliseconds>(std::chrono::high_resolution_clock::now() - t0).count();
             if (log_file.is_open()) log_file << "Batch device time: " << ms << " ms for " << idx.size() << " images" << std::endl;
-            for (size_t k = 0; k < idx.size(); ++k) {
+            // PNG / JSON artefacts of the images are independent: one host thread each, console and log text collected per
+            // image and emitted in file order afterwards (the reference's sequential loop prints in that order)
+            std::vector<std::ostringstream> con(idx.size()), err(idx.size()), lg(idx.size());
+            std::vector<char> done(idx.size(), 0);
+            const auto t_art = std::chrono::high_resolution_clock::now();
+#pragma omp parallel for schedule(dynamic) num_threads(io_threads)
+            for (long long k = 0; k < (long long)idx.size(); ++k) {
                 const size_t i = idx[k];
                 try {
                     const std::string base_name = fs::path(raw_paths[i]).stem().string();
-                    if (log_file.is_open())
-                        log_file << "\n=== Processing Image: " << fs::path(raw_paths[i]).filename().string() << " ===" << std::endl;
+                    lg[k] << "\n=== Processing Image: " << fs::path(raw_paths[i]).filename().string() << " ===" << std::endl;
                     Image8 tile(g_cfg.height, g_cfg.width, 1), vis(g_cfg.height, g_cfg.width, 1);
                     std::copy(tiles.begin() + k * hw, tiles.begin() + (k + 1) * hw, tile.data.begin());
                     std::copy(labels.begin() + k * hw, labels.begin() + (k + 1) * hw, vis.data.begin());
@@ -222,14 +243,23 @@ int process_image_batch(const std::vector<std::string> &raw_paths, const std::ve
                             contours.push_back(std::move(cc));
                         }
                     }
-                    Mask2Polygon::write_polygon_outputs(contours, tile, output_dir, base_name, widths[i], heights[i]);
-                    if (log_file.is_open()) log_file << "Processing completed for: " << base_name << std::endl;
-                    ++ok;
+                    Mask2Polygon::write_polygon_outputs(contours, tile, output_dir, base_name, widths[i], heights[i], con[k]);
+                    lg[k] << "Processing completed for: " << base_name << std::endl;
+                    done[k] = 1;
                 } catch (const std::exception &e) {
-                    std::cerr << "Processing error: " << e.what() << std::endl;
-                    if (log_file.is_open()) log_file << "Processing error: " << e.what() << std::endl;
+                    err[k] << "Processing error: " << e.what() << std::endl;
+                    lg[k] << "Processing error: " << e.what() << std::endl;
                 }
             }
+            for (size_t k = 0; k < idx.size(); ++k) {
+                std::cout << con[k].str() << std::flush;
+                std::cerr << err[k].str() << std::flush;
+                if (log_file.is_open()) log_file << lg[k].str() << std::flush;
+                ok += done[k];
+            }
+            if (log_file.is_open())
+                log_file << "Batch artefact time: " << std::chrono::duration_cast<std::chrono::milliseconds>(std::chrono::high_resolution_clock::now() - t_art).count()
+                         << " ms for " << idx.size() << " images" << std::endl;
             return ok;
         }
         {

@@ -197,26 +197,27 @@ void create_overlay_image(const std::vector<Contour> &contours, const std::strin
 }
 
 void write_polygon_outputs(const std::vector<Contour> &contours, const Image8 &normalized_tile, const std::string &output_dir,
-                           const std::string &base_name, int original_width, int original_height)
+                           const std::string &base_name, int original_width, int original_height,
+                           std::ostream &console)
 {
     try {
-        std::cout << "Processing Mask: " << base_name + ".png" << std::endl;
-        std::cout << "Original Size: " << original_width << "x" << original_height << std::endl;
-        std::cout << "Scaled Size: " << normalized_tile.cols << "x" << normalized_tile.rows << std::endl;
+        console << "Processing Mask: " << base_name + ".png" << std::endl;
+        console << "Original Size: " << original_width << "x" << original_height << std::endl;
+        console << "Scaled Size: " << normalized_tile.cols << "x" << normalized_tile.rows << std::endl;
         if (contours.empty()) {
-            std::cout << "Warning: No Contours Detected" << std::endl;
+            console << "Warning: No Contours Detected" << std::endl;
             return;
         }
-        std::cout << "Extracted " << contours.size() << " Contours" << std::endl;
+        console << "Extracted " << contours.size() << " Contours" << std::endl;
         const std::string overlay_path = output_dir + "/" + base_name + "_contour_overlay.png";
         if (!medseg::write_png(overlay_path, draw_overlay(normalized_tile, contours), /*level0=*/false))
             throw std::runtime_error("Fail to Save Overlay PNG: " + overlay_path);
-        std::cout << "Overlay Image Saved to: " << overlay_path << std::endl;
+        console << "Overlay Image Saved to: " << overlay_path << std::endl;
         const double scale_x = static_cast<double>(original_width) / normalized_tile.cols;
         const double scale_y = static_cast<double>(original_height) / normalized_tile.rows;
         const std::string output_json_path = output_dir + "/" + base_name + ".json";
         generate_json(map_contour_points(contours, scale_x, scale_y), output_json_path, base_name, original_width, original_height);
-        std::cout << "JSON Saved to: " << output_json_path << std::endl;
+        console << "JSON Saved to: " << output_json_path << std::endl;
     } catch (const std::exception &e) {
         std::cerr << "Processing Failure: " << e.what() << std::endl;
     }

@@ -52,10 +52,19 @@ bool write_png(const std::string &path, const Image8 &img, bool level0)
             for (int x = 0; x < img.cols; ++x) { d[3 * x] = s[3 * x + 2]; d[3 * x + 1] = s[3 * x + 1]; d[3 * x + 2] = s[3 * x]; }
         }
     }
-    uLongf cap = compressBound((uLong)raw.size());
-    std::vector<uint8_t> z(cap);
-    if (compress2(z.data(), &cap, raw.data(), (uLong)raw.size(), level0 ? 0 : Z_DEFAULT_COMPRESSION) != Z_OK) return false;
-    z.resize(cap);
+    // level 0 = stored blocks (the reference's IMWRITE_PNG_COMPRESSION 0 files); otherwise OpenCV's imwrite defaults:
+    // level 1 with the run-length strategy -- fast, and the compressed bytes are not part of any contract
+    z_stream zs;
+    memset(&zs, 0, sizeof(zs));
+    if (deflateInit2(&zs, level0 ? 0 : 1, Z_DEFLATED, 15, 8, level0 ? Z_DEFAULT_STRATEGY : Z_RLE) != Z_OK) return false;
+    std::vector<uint8_t> z(deflateBound(&zs, (uLong)raw.size()));
+    zs.next_in = raw.data(); zs.avail_in = (uInt)raw.size();
+    zs.next_out = z.data(); zs.avail_out = (uInt)z.size();
+    const int zrc = deflate(&zs, Z_FINISH);
+    const size_t zlen = zs.total_out;
+    deflateEnd(&zs);
+    if (zrc != Z_STREAM_END) return false;
+    z.resize(zlen);
     chunk(out, "IDAT", z);
     chunk(out, "IEND", {});
     std::ofstream f(path, std::ios::binary | std::ios::trunc);
