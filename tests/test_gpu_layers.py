@@ -91,6 +91,45 @@ def test_conv3x3_wino_exact_on_even_integers_and_tap_orientation(op):
 
 
 @pytest.mark.parametrize("B,H,W,Cin,Cout", [
+    (1, 16, 16, 16, 128),      # one exact 16x16 block, one chunk
+    (2, 32, 48, 64, 128),      # several blocks, several chunks
+    (1, 5, 7, 32, 128),        # ragged: partial block in x and y
+    (1, 20, 40, 48, 256),      # two n-tiles, partial blocks, odd chunk count
+    (1, 9, 33, 24, 96),        # Cin % 16 != 0 (masked last chunk), Cout < 128 (masked columns)
+    (3, 4, 4, 128, 256),       # deep-layer shape
+    (1, 2, 2, 1024, 128),      # K = 9216 * 4
+    (1, 18, 18, 16, 128),      # a 2-pixel rim past the block boundary
+])
+def test_conv3x3_wino4(B, H, W, Cin, Cout):
+    # F(4x4,3x3): transforms with coefficients up to 8 and 1/24 -- still fp32 rounding noise at this scale
+    r = _rng(B * 1000 + H * 100 + W + Cin + Cout)
+    x = r.standard_normal((B, H, W, Cin), dtype=np.float32)
+    w = (r.standard_normal((Cout, Cin, 3, 3), dtype=np.float32) * np.sqrt(2.0 / (9 * Cin))).astype(np.float32)
+    scale = (1.0 + 0.1 * r.standard_normal(Cout)).astype(np.float32)
+    shift = (0.1 * r.standard_normal(Cout)).astype(np.float32)
+    got = binding.layer_debug("conv3x3_wino4", x, w, scale, shift, relu=True)
+    ref = np.maximum(orc.conv3x3(x, w) * scale + shift, 0.0)
+    assert not np.isnan(got).any(), "unwritten (NaN-poisoned) outputs"
+    assert np.max(np.abs(got - ref)) < _tol(ref)
+
+
+def test_conv3x3_wino4_tap_orientation_exact():
+    # G of F(4x4,3x3) has 1/4, 1/6, 1/12, 1/24: a single tap of weight 576 makes every U entry an integer, small-integer
+    # inputs keep every intermediate exactly representable, so the result must equal the direct sum bit for bit; single
+    # taps check the orientation of all three transforms (a transposed G, B or A would mirror or swap taps).
+    r = _rng(13)
+    B, H, W, Cin, Cout = 2, 11, 19, 24, 128
+    x = r.integers(-2, 3, (B, H, W, Cin)).astype(np.float32)
+    for (ky, kx, ci, co) in [(0, 2, 5, 7), (2, 0, 23, 127), (1, 1, 0, 0), (0, 0, 17, 33), (2, 2, 9, 40), (1, 0, 3, 3), (0, 1, 16, 64),
+                             (2, 1, 1, 31), (1, 2, 8, 96)]:
+        w = np.zeros((Cout, Cin, 3, 3), np.float32)
+        w[co, ci, ky, kx] = 576.0
+        got = binding.layer_debug("conv3x3_wino4", x, w)
+        assert np.array_equal(got, orc.conv3x3(x, w)), (ky, kx, ci, co)
+        assert np.count_nonzero(got[..., [c for c in range(Cout) if c != co]]) == 0
+
+
+@pytest.mark.parametrize("B,H,W,Cin,Cout", [
     (1, 8, 32, 64, 32),        # N = 128: taps straddle a 64-column tile boundary at Cout = 32
     (2, 4, 4, 128, 64),
     (1, 3, 5, 1024, 512),      # ragged, u1.t shape

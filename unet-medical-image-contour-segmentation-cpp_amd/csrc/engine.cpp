@@ -125,6 +125,24 @@ void pack_wino(const float *w, const double *scale, int cin, int cout, float *ds
         }
 }
 
+// U = G g G^T for F(4x4,3x3) (6x6, position p = 6*xi + nu), packed for conv3x3_wino4_f32 as [Cin/16][36][CoutPad][16]
+void pack_wino4(const float *w, const double *scale, int cin, int cout, float *dst, size_t cpad)
+{
+    static const double G[6][3] = { { 1.0 / 4, 0, 0 },          { -1.0 / 6, -1.0 / 6, -1.0 / 6 }, { -1.0 / 6, 1.0 / 6, -1.0 / 6 },
+                                    { 1.0 / 24, 1.0 / 12, 1.0 / 6 }, { 1.0 / 24, -1.0 / 12, 1.0 / 6 }, { 0, 0, 1 } };
+    for (int co = 0; co < cout; ++co)
+        for (int ci = 0; ci < cin; ++ci) {
+            double g[9], t[6][3];
+            for (int k = 0; k < 9; ++k) g[k] = (double)w[((size_t)co * cin + ci) * 9 + k] * (scale ? scale[co] : 1.0);
+            for (int i = 0; i < 6; ++i)
+                for (int j = 0; j < 3; ++j) t[i][j] = G[i][0] * g[0 * 3 + j] + G[i][1] * g[1 * 3 + j] + G[i][2] * g[2 * 3 + j];
+            for (int i = 0; i < 6; ++i)
+                for (int j = 0; j < 6; ++j)
+                    dst[(((size_t)(ci / WINO4_KC) * 36 + i * 6 + j) * cpad + co) * WINO4_KC + ci % WINO4_KC] =
+                        (float)(t[i][0] * G[j][0] + t[i][1] * G[j][1] + t[i][2] * G[j][2]);
+        }
+}
+
 // same U, packed for conv3x3_wino16_f32: [Cin/8][8 position pairs][CoutPad][16], element 4*(k/2) + 2*(pos&1) + (k&1)
 void pack_wino16(const float *w, const double *scale, int cin, int cout, float *dst, size_t cpad)
 {
@@ -199,11 +217,17 @@ void pack_convT_bf16(const float *w, int cin, int cout, uint16_t *dst, size_t np
 
 struct HostWeights {
     std::vector<float> blob;                    // packed, device layout
-    struct Off { size_t w, shift; };
+    struct Off { size_t w, shift, w4; };       // w4: F(4x4,3x3) packing of the same layer (0 = none)
     std::vector<Off> conv;                      // per 3x3 conv in file order (first one = FIRST layer layout)
     std::vector<Off> convT;
     Off head{};
 };
+
+bool wino4_enabled()
+{
+    const char *e = std::getenv("MIUNET_WINO4");
+    return !(e && e[0] == '0');
+}
 
 // parse "MIUNETW1" (miunet/spec.py), fold BN, repack
 int build_host_weights(const mi_unet_config &cfg, int algo, const void *blob, size_t len, HostWeights &hw)
@@ -264,6 +288,11 @@ int build_host_weights(const mi_unet_config &cfg, int algo, const void *blob, si
             off.w = alloc((size_t)nch * 16 * cpad * WINO_KC);
             if (algo == MI_UNET_CONV_WINOGRAD16) pack_wino16(w, sc.data(), cin, cout, &out[off.w], cpad);
             else pack_wino(w, sc.data(), cin, cout, &out[off.w], cpad);
+            if (algo == MI_UNET_CONV_WINOGRAD && cout % 128 == 0 && wino4_enabled()) {   // second packing: the F(4x4,3x3) kernel takes
+                const int nch4 = (cin + WINO4_KC - 1) / WINO4_KC;                      // the layer whenever its grid fills the chip
+                off.w4 = alloc((size_t)nch4 * 36 * cpad * WINO4_KC);
+                pack_wino4(w, sc.data(), cin, cout, &out[off.w4], cpad);
+            }
         } else {                                 // MFMA layout: [chunk][tap][n (padded)][KC]
             const int nch = (cin + KC - 1) / KC;
             const size_t cpad = round_up(cout, NPAD);
@@ -341,6 +370,7 @@ int build_plan(mi_unet *h, const HostWeights &hw)
         Step s;
         s.kind = Step::CONV; s.name = name;
         s.a.in = in; s.a.wpk = W_(hw.conv[ci].w); s.a.bias = W_(hw.conv[ci].shift); s.a.out = out;
+        s.a.wpk4 = hw.conv[ci].w4 ? W_(hw.conv[ci].w4) : nullptr;
         s.a.B = 0; s.a.H = H; s.a.W = Wd; s.a.Cin = cin; s.a.ldc = ldc; s.a.Cout = cout;
         s.a.CoutPad = (int)round_up(cout, NPAD); s.a.ldo = ldo; s.a.co_off = co_off; s.a.relu = 1;
         conv_cost(s, H, Wd, cin, cout, 9, false);
@@ -473,7 +503,14 @@ int launch_plan(mi_unet *h, const uint8_t *d_imgs, int B, uint8_t *d_labels, flo
             if (h->algo == MI_UNET_CONV_BF16) { kname = "conv3x3_bf16"; e = launch_conv3x3_bf16(a, s); }
             else if (h->algo == MI_UNET_CONV_FP16) { kname = "conv3x3_fp16"; e = launch_conv3x3_fp16(a, s); }
             else if (h->algo == MI_UNET_CONV_WINOGRAD16) { kname = "conv3x3_wino16"; e = launch_conv3x3_wino16(a, s); }
-            else if (h->algo == MI_UNET_CONV_WINOGRAD) { kname = "conv3x3_wino"; e = launch_conv3x3_wino(a, s); }
+            else if (h->algo == MI_UNET_CONV_WINOGRAD) {
+                // F(4x4,3x3) where it was packed (Cout % 128 == 0) and its 16x16-pixel x 128-channel grid fills the chip;
+                // small grids (single images, deep levels) stay on F(2x2,3x3), which can split K
+                // (MIUNET_SPLITK=0 = batch-invariant mode: no split-K workspace, and the choice must not depend on B either)
+                const long long wg4 = (long long)((a.W + 15) / 16) * ((a.H + 15) / 16) * B * (a.Cout / 128);
+                if (a.wpk4 != nullptr && (wg4 >= 256 || h->d_ksplit == nullptr)) { kname = "conv3x3_wino4"; e = launch_conv3x3_wino4(a, s); }
+                else { kname = "conv3x3_wino"; e = launch_conv3x3_wino(a, s); }
+            }
             else { kname = "conv3x3_mfma"; e = launch_conv3x3_mfma(a, s); }
             break;
         }
@@ -930,7 +967,19 @@ int mi_unet_layer_debug(int device, const char *op, const float *in, int B, int 
     std::vector<float> wpk, bias;
     size_t out_n = 0;
     ConvArgs a{};
-    if (o == "conv3x3_wino" || o == "conv3x3_wino16") {
+    if (o == "conv3x3_wino4") {
+        if (!w || Cout <= 0 || Cin % 4) return fail(MI_UNET_EARG, "layer_debug: conv needs weights and Cin % 4 == 0");
+        const int nch = (Cin + WINO4_KC - 1) / WINO4_KC;
+        const size_t npad = round_up((size_t)Cout, NPAD);
+        wpk.assign((size_t)nch * 36 * npad * WINO4_KC, 0.f);
+        bias.assign(Cout, 0.f);
+        std::vector<double> sc(Cout, 1.0);
+        for (int co = 0; co < Cout; ++co) { bias[co] = shift ? shift[co] : 0.f; if (scale) sc[co] = scale[co]; }
+        pack_wino4(w, sc.data(), Cin, Cout, wpk.data(), npad);
+        out_n = (size_t)B * H * W * Cout;
+        a.B = B; a.H = H; a.W = W; a.Cin = Cin; a.ldc = Cin; a.Cout = Cout; a.CoutPad = (int)npad; a.ldo = Cout; a.co_off = 0;
+        a.relu = relu;
+    } else if (o == "conv3x3_wino" || o == "conv3x3_wino16") {
         if (!w || Cout <= 0 || Cin % 4) return fail(MI_UNET_EARG, "layer_debug: conv needs weights and Cin % 4 == 0");
         const int nch = (Cin + WINO_KC - 1) / WINO_KC;
         const size_t npad = round_up((size_t)Cout, NPAD);
@@ -1001,7 +1050,9 @@ int mi_unet_layer_debug(int device, const char *op, const float *in, int B, int 
         DBG_TRY(hipMemcpy(d_w, wpk.data(), sizeof(float) * wpk.size(), hipMemcpyHostToDevice));
         DBG_TRY(hipMemcpy(d_b, bias.data(), sizeof(float) * bias.size(), hipMemcpyHostToDevice));
         a.in = d_in; a.wpk = d_w; a.bias = d_b; a.out = d_out;
+        if (o == "conv3x3_wino4") a.wpk4 = d_w;
         DBG_TRY(o == "conv3x3" ? launch_conv3x3_mfma(a, nullptr)
+                : o == "conv3x3_wino4" ? launch_conv3x3_wino4(a, nullptr)
                 : o == "conv3x3_wino" ? launch_conv3x3_wino(a, nullptr)
                 : o == "conv3x3_wino16" ? launch_conv3x3_wino16(a, nullptr)
                 : o == "conv3x3_bf16" ? launch_conv3x3_bf16(a, nullptr)

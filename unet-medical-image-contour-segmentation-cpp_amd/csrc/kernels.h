@@ -16,6 +16,7 @@ constexpr int NPAD = 128;     // packed Cout granule (covers both BN = 64 and BN
 struct ConvArgs {
     const float *in;      // [B][H][W][ldc]
     const float *wpk;     // packed weights [nchunks][taps][CoutPad][KC]  (CoutPad counts N = 4*Cout for convT)
+    const float *wpk4;    // optional second packing of the same conv3x3 for the F(4x4,3x3) kernel (see launch_conv3x3_wino4), or nullptr
     const float *bias;    // [Cout] folded BN shift (conv) or convT bias
     float *out;           // conv: [B][H][W][ldo]; convT: [B][2H][2W][ldo]
     int B, H, W;          // INPUT spatial size
@@ -47,6 +48,11 @@ hipError_t launch_conv3x3_wino(const ConvArgs &a, hipStream_t s);
 // 8-wave / two-waves-per-SIMD re-tiling of the same algorithm on v_mfma_f32_16x16x4_f32; a.wpk is packed as
 // [Cin/8][8 position pairs][CoutPad][16] with element 4*kq + 2*(pos & 1) + s = U_pos[k = 2*kq + s].
 hipError_t launch_conv3x3_wino16(const ConvArgs &a, hipStream_t s);
+// Winograd F(4x4,3x3) on v_mfma_f32_16x16x4_f32: 16 tiles (16x16 output pixels) x 128 channels per workgroup.  a.wpk4 holds
+// U = G g G^T (6x6) packed as [Cin/16][36 positions][CoutPad][16]; no split-K (small grids stay on the F(2x2) kernel).
+constexpr int WINO4_KC = 16;
+constexpr int WINO4_SC = 32;
+hipError_t launch_conv3x3_wino4(const ConvArgs &a, hipStream_t s);
 hipError_t launch_convT2x2_mfma(const ConvArgs &a, hipStream_t s);
 
 // BASELINE config 3: bf16 operands, fp32 accumulate on v_mfma_f32_32x32x16_bf16.  Activations stay fp32 in HBM and are
