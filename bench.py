@@ -154,9 +154,15 @@ def main():
     if rank == 0:
         images = B * world * args.steps
         ips = images / dt
-        # dominant kernel: the fp32 MFMA implicit-GEMM conv (17 launches per step, 97 % of the FLOPs)
-        dom = [s for s in stats if s["kernel"] in ("conv3x3_mfma", "conv3x3_wino", "conv3x3_wino16", "conv3x3_bf16", "conv3x3_fp16")]
-        dom_kernel = dom[0]["kernel"] if dom else "conv3x3_mfma"
+        # dominant kernel: the conv3x3 kernel with the largest share of device time (the default plan mixes the F(4x4,3x3)
+        # kernel with the F(2x2,3x3) one for small grids)
+        conv_kernels = ("conv3x3_mfma", "conv3x3_wino", "conv3x3_wino16", "conv3x3_wino4", "conv3x3_bf16", "conv3x3_fp16")
+        by_kernel = {}
+        for s in stats:
+            if s["kernel"] in conv_kernels:
+                by_kernel[s["kernel"]] = by_kernel.get(s["kernel"], 0.0) + s["ms"]
+        dom_kernel = max(by_kernel, key=by_kernel.get) if by_kernel else "conv3x3_mfma"
+        dom = [s for s in stats if s["kernel"] == dom_kernel]
         dom_flops = sum(s["flops"] for s in dom)
         dom_ms = sum(s["ms"] for s in dom)
         all_ms = sum(s["ms"] for s in stats)
@@ -184,11 +190,15 @@ def main():
                                    "argmax label maps", "images_per_gpu_per_step": B, "global_batch": B * world,
                        "parallelism": f"dp{world}" + (" (RCCL weight broadcast + per-step label-map gather)" if world > 1 else "")},
             "roofline": {
-                "bound": "mfma", "kernel": dom_kernel + ((" (v_mfma_f32_32x32x16_%s)" % ("f16" if lp_name == "fp16" else "bf16")) if is_bf16 else " (v_mfma_f32_32x32x2_f32)"),
-                "algorithm": "winograd F(2x2,3x3): achieved counts ALGORITHMIC (direct-convolution) FLOPs, the MFMA pipe "
+                "bound": "mfma", "kernel": dom_kernel + ((" (v_mfma_f32_32x32x16_%s)" % ("f16" if lp_name == "fp16" else "bf16")) if is_bf16
+                                       else " (v_mfma_f32_16x16x4_f32)" if dom_kernel == "conv3x3_wino4" else " (v_mfma_f32_32x32x2_f32)"),
+                "algorithm": "winograd F(4x4,3x3): achieved counts ALGORITHMIC (direct-convolution) FLOPs, the MFMA pipe "
+                             "executes 1/4 of them" if dom_kernel == "conv3x3_wino4" else
+                             "winograd F(2x2,3x3): achieved counts ALGORITHMIC (direct-convolution) FLOPs, the MFMA pipe "
                              "executes 1/2.25 of them" if dom_kernel.startswith("conv3x3_wino") else "direct implicit GEMM",
                 "achieved": achieved, "peak": peak, "unit": "TFLOP/s", "frac": achieved / peak,
-                "traffic": pmc_traffic({"conv3x3_wino": "miunet::conv3x3_wino_f32<*>", "conv3x3_wino16": "miunet::conv3x3_wino16_f32"}.get(
+                "traffic": pmc_traffic({"conv3x3_wino": "miunet::conv3x3_wino_f32<*>", "conv3x3_wino16": "miunet::conv3x3_wino16_f32",
+                                        "conv3x3_wino4": "miunet::conv3x3_wino4_f32<*>"}.get(
                     dom_kernel, "miunet::conv_mfma_f32<9, 8, 64, 16, false>")),
                 "launches": len(dom), "avg_launch_ms": dom_ms / max(1, len(dom)),
                 "avg_launch_gflop": dom_flops / max(1, len(dom)) / 1e9,

@@ -99,6 +99,10 @@ def test_conv3x3_wino_exact_on_even_integers_and_tap_orientation(op):
     (3, 4, 4, 128, 256),       # deep-layer shape
     (1, 2, 2, 1024, 128),      # K = 9216 * 4
     (1, 18, 18, 16, 128),      # a 2-pixel rim past the block boundary
+    (2, 32, 32, 64, 64),       # Cout = 64: the one-block-per-wave variant
+    (1, 21, 35, 128, 64),      # ... ragged
+    (1, 16, 16, 32, 192),      # Cout % 128 == 64: one-block variant, three n-tiles
+    (1, 16, 16, 32, 48),       # Cout < 64 (masked columns)
 ])
 def test_conv3x3_wino4(B, H, W, Cin, Cout):
     # F(4x4,3x3): transforms with coefficients up to 8 and 1/24 -- still fp32 rounding noise at this scale

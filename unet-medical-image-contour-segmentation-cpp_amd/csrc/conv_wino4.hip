@@ -1,4 +1,6 @@
 // conv_wino4.hip -- Winograd F(4x4,3x3) convolution on the fp32 MFMA (v_mfma_f32_16x16x4_f32), gfx950 only.
+#include <type_traits>
+
 #include "kernel_common.h"
 
 namespace miunet {
@@ -25,6 +27,26 @@ namespace miunet {
 //     are threaded between the MFMAs of the chunk that precedes their use;
 //   * K order inside a 16-channel chunk: MFMA step s of lane group kq consumes channel 4*kq + s (one ds_read_b128 / one
 //     buffer_load_b128 per lane feeds four MFMA steps).
+// a - b on packed pairs: hipcc scalarises a plain fsub of <4 x float> into four v_sub_f32; two v_pk_add_f32 with a negated
+// operand do the same work in half the issue slots (the matrix pipe shares them)
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ f32x4 pk_sub(const f32x4 a, const f32x4 b)
+{
+    f32x2 lo, hi;
+    asm("v_pk_add_f32 %0, %1, %2 neg_lo:[0,1] neg_hi:[0,1]" : "=v"(lo) : "v"(a.lo), "v"(b.lo));
+    asm("v_pk_add_f32 %0, %1, %2 neg_lo:[0,1] neg_hi:[0,1]" : "=v"(hi) : "v"(a.hi), "v"(b.hi));
+    return __builtin_shufflevector(lo, hi, 0, 1, 2, 3);
+}
+
+// 72 accumulators of 4 registers do not fit the 256 AGPRs: hipcc then shuttles the overflow through AGPRs around every
+// MFMA (64 v_accvgpr moves per chunk).  The last four positions of the two-block kernel therefore use the VGPR form of the
+// instruction directly; their results are only ever re-read as SrcC of the next MFMA on the same registers (the
+// hardware-interlocked accumulate chain, one independent MFMA in between) until the epilogue, which starts with a barrier.
+__device__ __forceinline__ void mfma16_vgpr(f32x4 &acc, const float a, const float b)
+{
+    asm("v_mfma_f32_16x16x4_f32 %0, %1, %2, %0" : "+v"(acc) : "v"(a), "v"(b));
+}
+
 struct W4 {
     static constexpr int TMB = 16;                          // 4x4 output tiles per workgroup (4 wide x 4 tall)
     static constexpr int VROW = WINO4_KC + 4;               // padded floats per tile row of V
@@ -36,13 +58,16 @@ struct W4 {
     static constexpr int RAW_FLOATS = RAWPIX * RAW_P;       // one 16-channel chunk of the halo patch
     static constexpr int RAW_ITERS = (RAWPIX * (WINO4_KC / 4) + 255) / 256;     // 6 (the last one: 16 live lanes)
     static constexpr size_t LDS_BYTES = sizeof(float) * (2 * VBUF + 2 * RAW_FLOATS);
-    static constexpr int UD = 6;                            // U prefetch distance in positions (36 % UD == 0)
 };
 
+// NB = 16-channel blocks per wave: 2 (workgroup = 128 output channels) or 1 (64 channels, for the Cout = 64 layers: half
+// the MFMA work per transformed tile, but still 1.6x the F(2x2) kernel there).
+template <int NB>
 __global__ __launch_bounds__(256, 1) void conv3x3_wino4_f32(const ConvArgs a, const int tiles_x, const int tiles_y,
                                                             const int m_tiles, const int nwg)
 {
-    constexpr int VROW = W4::VROW, VPOS = W4::VPOS, VBUF = W4::VBUF, RAW_P = W4::RAW_P, UD = W4::UD;
+    constexpr int VROW = W4::VROW, VPOS = W4::VPOS, VBUF = W4::VBUF, RAW_P = W4::RAW_P;
+    constexpr int UD = NB == 1 ? 9 : 6;       // U prefetch distance in positions (36 % UD == 0); the one-block variant has registers to spare
     extern __shared__ __attribute__((aligned(16))) float lds[];
     float *const Vs = lds;                    // [2][36][16][VROW]
     float *const Raw = lds + 2 * VBUF;        // [2][RAWPIX][RAW_P]: the input halo patch of one 16-channel chunk, double-buffered
@@ -58,7 +83,7 @@ __global__ __launch_bounds__(256, 1) void conv3x3_wino4_f32(const ConvArgs a, co
     const int tx = m % tiles_x; m /= tiles_x;
     const int ty = m % tiles_y;
     const int b = m / tiles_y;
-    const int bx0 = tx * 16, by0 = ty * 16, n0 = n_tile * 128;
+    const int bx0 = tx * 16, by0 = ty * 16, n0 = n_tile * 64 * NB;
     const float *in_img = a.in + (size_t)b * a.H * a.W * a.ldc;
 
     // ---- stage 1: raw halo patch, one 16-channel chunk at a time, global -> registers -> LDS (4 lanes = one pixel's 64
@@ -94,7 +119,6 @@ __global__ __launch_bounds__(256, 1) void conv3x3_wino4_f32(const ConvArgs a, co
     //   wave 0: xi 1, 2 = (d4 - 4 d2) +- (d3 - 4 d1)        wave 1: xi 3, 4 = (d4 - d2) +- (2 d3 - 2 d1)
     //   wave 2: xi 0    = 4 d0 - 5 d2 + d4                  wave 3: xi 5    = 4 d1 - 5 d3 + d5
     const bool two = wave < 2;
-    const float c_al = wave == 0 ? 4.f : 1.f, c_be = wave == 0 ? 1.f : 2.f, c_ga = wave == 0 ? 4.f : 2.f;
     const int t_tile = lane >> 2, t_quad = lane & 3;
     const int row0 = two ? 1 : wave - 2, rstep = two ? 1 : 2;
     const float *const p_rd = Raw + ((4 * (t_tile >> 2) + row0) * 18 + 4 * (t_tile & 3)) * RAW_P + 4 * t_quad;
@@ -113,24 +137,33 @@ __global__ __launch_bounds__(256, 1) void conv3x3_wino4_f32(const ConvArgs a, co
     };
     auto piece_col = [&](int k) {
         const f32x4 *d = px_;
-        if (two) {
-            const f32x4 ta = d[3] - c_al * d[1];
-            const f32x4 tb = c_be * d[2] - c_ga * d[0];
-            cR[0][k] = ta + tb;
-            cR[1][k] = ta - tb;
+        f32x4 ra, rb;
+        if (wave == 0) {
+            const f32x4 ta = d[3] - 4.f * d[1];
+            const f32x4 tb = d[2] - 4.f * d[0];
+            ra = ta + tb;
+            rb = pk_sub(ta, tb);
+        } else if (wave == 1) {
+            const f32x4 ta = pk_sub(d[3], d[1]);
+            const f32x4 tb = pk_sub(d[2], d[0]);
+            ra = ta + 2.f * tb;
+            rb = ta - 2.f * tb;
         } else {
-            cR[0][k] = 4.f * d[0] - 5.f * d[1] + d[2];
+            ra = 4.f * d[0] - 5.f * d[1] + d[2];
+            rb = ra;
         }
+        cR[0][k] = ra;
+        cR[1][k] = rb;
     };
     auto piece_prep = [&](int row) {
         const f32x4 *c = cR[row];
-        e_[0] = c[4] - 4.f * c[2]; e_[1] = c[3] - 4.f * c[1]; e_[2] = c[4] - c[2]; e_[3] = c[3] - c[1];
+        e_[0] = c[4] - 4.f * c[2]; e_[1] = c[3] - 4.f * c[1]; e_[2] = pk_sub(c[4], c[2]); e_[3] = pk_sub(c[3], c[1]);
     };
     auto piece_store = [&](int row, float *dst, int nu) {
         const f32x4 *c = cR[row];
         const f32x4 v = nu == 0 ? 4.f * c[0] - 5.f * c[2] + c[4]
                       : nu == 1 ? e_[0] + e_[1]
-                      : nu == 2 ? e_[0] - e_[1]
+                      : nu == 2 ? pk_sub(e_[0], e_[1])
                       : nu == 3 ? e_[2] + 2.f * e_[3]
                       : nu == 4 ? e_[2] - 2.f * e_[3]
                                 : 4.f * c[1] - 5.f * c[3] + c[5];
@@ -150,8 +183,8 @@ __global__ __launch_bounds__(256, 1) void conv3x3_wino4_f32(const ConvArgs a, co
         }
     };
 
-    // ---- MFMA role: wave w, channels n0 + 32 w .. + 31 (two 16-column blocks), all 36 positions
-    const int ncol0 = n0 + 32 * wave + j16;
+    // ---- MFMA role: wave w, channels n0 + 16 NB w .. (NB 16-column blocks), all 36 positions
+    const int ncol0 = n0 + 16 * NB * wave + j16;
     const unsigned u_pos_bytes = (unsigned)a.CoutPad * WINO4_KC * 4;
     const unsigned u_voff = (unsigned)(ncol0 * WINO4_KC + 4 * kq) * 4;
     const int all_chunks = (a.Cin + WINO4_KC - 1) / WINO4_KC;
@@ -163,21 +196,37 @@ __global__ __launch_bounds__(256, 1) void conv3x3_wino4_f32(const ConvArgs a, co
     };
     const float *const v_rd = Vs + j16 * VROW + 4 * kq;                       // + buf*VBUF + pos*VPOS
 
-    f32x4 acc[36][2];
+    f32x4 acc[36][NB];
 #pragma unroll
     for (int p = 0; p < 36; ++p)
 #pragma unroll
-        for (int r = 0; r < 4; ++r) { acc[p][0][r] = 0.f; acc[p][1][r] = 0.f; }
+        for (int blk = 0; blk < NB; ++blk) {
+            // position (xi, nu) = (1, 1) starts at the shift: A^T e_1 e_1^T A is the all-ones tile, so the bias add is free
+            const float init = (p == 7 && ncol0 + 16 * blk < a.Cout) ? a.bias[ncol0 + 16 * blk] : 0.f;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) acc[p][blk][r] = init;
+        }
 
     const int nchunks = all_chunks;
-    f32x4 u[UD][2];
+    f32x4 u[UD][NB];
 #pragma unroll
-    for (int p = 0; p < UD; ++p) { u[p][0] = u_load(0, p, 0); u[p][1] = u_load(0, p, 1); }
+    for (int p = 0; p < UD; ++p)
+#pragma unroll
+        for (int blk = 0; blk < NB; ++blk) u[p][blk] = u_load(0, p, blk);
     // prologue: raw patches of chunks 0 and 1 -> LDS, V of chunk 0
-    raw_load(0);
-    raw_store(0);
-    raw_load(1);
-    raw_store(1);
+    {
+        f32x4 raw_reg1[W4::RAW_ITERS];        // both chunks in flight at once: one memory latency, not two
+        raw_load(0);
+        const bool c_ok = WINO4_KC + 4 * (tid & 3) < a.Cin;
+#pragma unroll
+        for (int s = 0; s < W4::RAW_ITERS; ++s)
+            raw_reg1[s] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(in_rsrc, c_ok ? raw_voff[s] : 0xFFFFFFFFu, WINO4_KC * 4, 0));
+        raw_store(0);
+#pragma unroll
+        for (int s = 0; s < W4::RAW_ITERS; ++s)
+            if (s + 1 < W4::RAW_ITERS || (tid >> 2) + 64 * s < W4::RAWPIX)
+                *reinterpret_cast<f32x4 *>(raw_wr + W4::RAW_FLOATS + s * 64 * RAW_P) = raw_reg1[s];
+    }
     __syncthreads();
     transform_all(0, 0);
     __syncthreads();
@@ -205,11 +254,16 @@ __global__ __launch_bounds__(256, 1) void conv3x3_wino4_f32(const ConvArgs a, co
             if (p == 2) piece_load(0, rbuf);
 #endif
             __builtin_amdgcn_sched_barrier(0);        // ... issued BEFORE this position's MFMAs (hipcc would sink them to their use)
-            const f32x4 b0 = u[p % UD][0], b1 = u[p % UD][1];
+            f32x4 bv[NB];
+#pragma unroll
+            for (int blk = 0; blk < NB; ++blk) bv[blk] = u[p % UD][blk];
 #pragma unroll
             for (int s = 0; s < 4; ++s) {
-                acc[p][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[s], b0[s], acc[p][0], 0, 0, 0);
-                acc[p][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[s], b1[s], acc[p][1], 0, 0, 0);
+#pragma unroll
+                for (int blk = 0; blk < NB; ++blk) {
+                    if (NB == 2 && p >= 32) mfma16_vgpr(acc[p][blk], av[s], bv[blk][s]);
+                    else acc[p][blk] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[s], bv[blk][s], acc[p][blk], 0, 0, 0);
+                }
 #ifndef W4_ABL_NO_TRANSFORM
                 if (s == 1) {
                     if (p >= 3 && p < 9) piece_col(p - 3);
@@ -229,8 +283,8 @@ __global__ __launch_bounds__(256, 1) void conv3x3_wino4_f32(const ConvArgs a, co
             }
             const int pn = p + UD;                                                              // refill the ring slot
 #ifndef W4_ABL_NO_ULOAD
-            u[p % UD][0] = u_load(pn < 36 ? chunk : nxt, pn % 36, 0);
-            u[p % UD][1] = u_load(pn < 36 ? chunk : nxt, pn % 36, 1);
+#pragma unroll
+            for (int blk = 0; blk < NB; ++blk) u[p % UD][blk] = u_load(pn < 36 ? chunk : nxt, pn % 36, blk);
 #endif
             av = avn;
             __builtin_amdgcn_sched_barrier(0);
@@ -238,69 +292,116 @@ __global__ __launch_bounds__(256, 1) void conv3x3_wino4_f32(const ConvArgs a, co
         __syncthreads();
     }
 
-    // ---- epilogue: Y = A^T M A in-lane, + shift, ReLU, 4x4 store (+ the 2x2 pooled maxima).
-    // Lane = channel j16 of block blk, register r = tile (row kq, column r) of the 4x4 tile block.
+    // ---- epilogue: Y = A^T M A in-lane on all four tiles of a lane at once (the accumulator's four registers = tile
+    // columns r = 0..3 of tile row kq, lane = channel), ReLU, 4x4 stores (+ the 2x2 pooled maxima).  The shift was the
+    // initial value of position (1,1), whose inverse transform is the all-ones tile.  Stores are buffer stores on a
+    // per-image descriptor: one per-lane byte offset for the whole tile row, the pixel displacement in the scalar offset;
+    // pixels past the image edge and masked channels get voffset 0xFFFFFFFF, which the range check drops.
+    const float relu_lo = a.relu ? 0.f : -3.402823466e+38f;
+    const __amdgpu_buffer_rsrc_t out_rsrc = __builtin_amdgcn_make_buffer_rsrc(
+        a.out + (size_t)b * a.H * a.W * a.ldo, 0, a.H * a.W * a.ldo * 4, 0x00020000);
+    const int Hp = a.H >> 1, Wp = a.W >> 1;
+    const bool do_pool = a.pool_out != nullptr;
+    const __amdgpu_buffer_rsrc_t pool_rsrc = __builtin_amdgcn_make_buffer_rsrc(
+        do_pool ? a.pool_out + (size_t)b * Hp * Wp * a.pool_ld : a.out, 0, do_pool ? Hp * Wp * a.pool_ld * 4 : 0, 0x00020000);
+    const int oy = by0 + 4 * kq;
+    const unsigned pix_bytes = (unsigned)a.ldo * 4, row_bytes = (unsigned)a.W * pix_bytes;
+    const unsigned ppix_bytes = (unsigned)a.pool_ld * 4, prow_bytes = (unsigned)Wp * ppix_bytes;
+    auto epilogue = [&](auto interior_tag) {
+        constexpr bool INTERIOR = decltype(interior_tag)::value;
 #pragma unroll
-    for (int blk = 0; blk < 2; ++blk) {
-        const int ncol = ncol0 + 16 * blk;
-        const bool n_ok = ncol < a.Cout;
-        const float sh = n_ok ? a.bias[ncol] : 0.f;
+        for (int blk = 0; blk < NB; ++blk) {
+            const int ncol = ncol0 + 16 * blk;
+            const bool n_ok = ncol < a.Cout;
+            const unsigned vbase = n_ok ? (unsigned)((oy * a.W + bx0) * a.ldo + a.co_off + ncol) * 4 : 0xFFFFFFFFu;
+            const unsigned pbase = n_ok ? (unsigned)(((oy >> 1) * Wp + (bx0 >> 1)) * a.pool_ld + ncol) * 4 : 0xFFFFFFFFu;
+            unsigned vcol[4][4], pcol[4][2];          // edge workgroups: per-column offsets (dead columns -> dropped stores)
+            if constexpr (!INTERIOR) {
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const int oy = by0 + 4 * kq, ox = bx0 + 4 * r;
-            float t[4][6];
+                for (int r = 0; r < 4; ++r) {
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) vcol[r][k] = bx0 + 4 * r + k < a.W ? vbase : 0xFFFFFFFFu;
+                    pcol[r][0] = bx0 + 4 * r + 1 < a.W ? pbase : 0xFFFFFFFFu;
+                    pcol[r][1] = bx0 + 4 * r + 3 < a.W ? pbase : 0xFFFFFFFFu;
+                }
+            }
+            f32x4 t[4][6];
 #pragma unroll
             for (int nu = 0; nu < 6; ++nu) {
-                const float m0 = acc[nu][blk][r], m1 = acc[6 + nu][blk][r], m2 = acc[12 + nu][blk][r], m3 = acc[18 + nu][blk][r],
-                            m4 = acc[24 + nu][blk][r], m5 = acc[30 + nu][blk][r];
-                const float s12 = m1 + m2, d12 = m1 - m2, s34 = m3 + m4, d34 = m3 - m4;
+                const f32x4 m0 = acc[nu][blk], m1 = acc[6 + nu][blk], m2 = acc[12 + nu][blk], m3 = acc[18 + nu][blk],
+                            m4 = acc[24 + nu][blk], m5 = acc[30 + nu][blk];
+                const f32x4 s12 = m1 + m2, d12 = pk_sub(m1, m2), s34 = m3 + m4, d34 = pk_sub(m3, m4);
                 t[0][nu] = m0 + s12 + s34;
                 t[1][nu] = d12 + 2.f * d34;
                 t[2][nu] = s12 + 4.f * s34;
                 t[3][nu] = d12 + 8.f * d34 + m5;
             }
-            float y[4][4];
+            f32x4 carry0, carry1;                     // horizontal maxima of the even row, for the 2x2 pooling
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
-                const float s12 = t[i][1] + t[i][2], d12 = t[i][1] - t[i][2], s34 = t[i][3] + t[i][4], d34 = t[i][3] - t[i][4];
-                y[i][0] = t[i][0] + s12 + s34;
-                y[i][1] = d12 + 2.f * d34;
-                y[i][2] = s12 + 4.f * s34;
-                y[i][3] = d12 + 8.f * d34 + t[i][5];
-            }
+                const f32x4 s12 = t[i][1] + t[i][2], d12 = pk_sub(t[i][1], t[i][2]), s34 = t[i][3] + t[i][4], d34 = pk_sub(t[i][3], t[i][4]);
+                f32x4 y[4];
+                y[0] = t[i][0] + s12 + s34;
+                y[1] = d12 + 2.f * d34;
+                y[2] = s12 + 4.f * s34;
+                y[3] = d12 + 8.f * d34 + t[i][5];
+                const bool row_ok = INTERIOR || oy + i < a.H;          // per-lane (kq) row predicate of an edge workgroup
 #pragma unroll
-            for (int i = 0; i < 4; ++i)
+                for (int k = 0; k < 4; ++k)
 #pragma unroll
-                for (int k = 0; k < 4; ++k) {
-                    float v = y[i][k] + sh;
-                    if (a.relu) v = v > 0.f ? v : 0.f;
-                    y[i][k] = v;
-                    if (n_ok && oy + i < a.H && ox + k < a.W)
-                        a.out[(((size_t)b * a.H + oy + i) * a.W + ox + k) * a.ldo + a.co_off + ncol] = v;
+                    for (int r = 0; r < 4; ++r) {
+                        const float v = fmaxf(y[k][r], relu_lo);
+                        y[k][r] = v;
+                        unsigned voff = vbase;
+                        if constexpr (!INTERIOR) voff = row_ok ? vcol[r][k] : 0xFFFFFFFFu;
+                        __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), out_rsrc, voff,
+                                                              i * row_bytes + (4 * r + k) * pix_bytes, 0);
+                    }
+                if (do_pool) {
+                    f32x4 hm0, hm1;                   // horizontal maxima of this row: pooled columns 2r and 2r + 1
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) { hm0[r] = fmaxf(y[0][r], y[1][r]); hm1[r] = fmaxf(y[2][r], y[3][r]); }
+                    if ((i & 1) == 0) { carry0 = hm0; carry1 = hm1; }
+                    else {
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) {
+                            const float p0 = fmaxf(hm0[r], carry0[r]), p1 = fmaxf(hm1[r], carry1[r]);
+                            unsigned v0 = pbase, v1 = pbase;
+                            if constexpr (!INTERIOR) { v0 = row_ok ? pcol[r][0] : 0xFFFFFFFFu; v1 = row_ok ? pcol[r][1] : 0xFFFFFFFFu; }
+                            __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, p0), pool_rsrc, v0,
+                                                                  (i >> 1) * prow_bytes + (2 * r) * ppix_bytes, 0);
+                            __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, p1), pool_rsrc, v1,
+                                                                  (i >> 1) * prow_bytes + (2 * r + 1) * ppix_bytes, 0);
+                        }
+                    }
                 }
-            if (a.pool_out != nullptr && n_ok) {
-#pragma unroll
-                for (int i = 0; i < 2; ++i)
-#pragma unroll
-                    for (int k = 0; k < 2; ++k)
-                        if (oy + 2 * i + 1 < a.H && ox + 2 * k + 1 < a.W)
-                            a.pool_out[(((size_t)b * (a.H >> 1) + ((oy >> 1) + i)) * (a.W >> 1) + ((ox >> 1) + k)) * a.pool_ld + ncol] =
-                                fmaxf(fmaxf(y[2 * i][2 * k], y[2 * i][2 * k + 1]), fmaxf(y[2 * i + 1][2 * k], y[2 * i + 1][2 * k + 1]));
             }
         }
-    }
+    };
+    if (by0 + 16 <= a.H && bx0 + 16 <= a.W) epilogue(std::true_type{});     // workgroup-uniform: no per-pixel predicates
+    else epilogue(std::false_type{});
+}
+
+template <int NB>
+static hipError_t launch_wino4_cfg(const ConvArgs &a, hipStream_t s)
+{
+    const int tiles_x = (a.W + 15) / 16, tiles_y = (a.H + 15) / 16;
+    const int m_tiles = tiles_x * tiles_y * a.B;
+    const int n_tiles = (a.Cout + 64 * NB - 1) / (64 * NB);
+    const int nwg = m_tiles * n_tiles;
+    auto kern = conv3x3_wino4_f32<NB>;
+    if (hipError_t e = ensure_dynamic_lds(kern, W4::LDS_BYTES); e != hipSuccess) return e;
+    hipLaunchKernelGGL(kern, dim3(nwg), dim3(256), W4::LDS_BYTES, s, a, tiles_x, tiles_y, m_tiles, nwg);
+    return hipGetLastError();
 }
 
 hipError_t launch_conv3x3_wino4(const ConvArgs &a, hipStream_t s)
 {
     if (a.wpk4 == nullptr || a.Cin % 4 || a.ldc % 4 || a.CoutPad % NPAD) return hipErrorInvalidValue;
-    const int tiles_x = (a.W + 15) / 16, tiles_y = (a.H + 15) / 16;
-    const int m_tiles = tiles_x * tiles_y * a.B;
-    const int n_tiles = (a.Cout + 127) / 128;
-    const int nwg = m_tiles * n_tiles;
-    if (hipError_t e = ensure_dynamic_lds(conv3x3_wino4_f32, W4::LDS_BYTES); e != hipSuccess) return e;
-    hipLaunchKernelGGL(conv3x3_wino4_f32, dim3(nwg), dim3(256), W4::LDS_BYTES, s, a, tiles_x, tiles_y, m_tiles, nwg);
-    return hipGetLastError();
+    // 128 output channels per workgroup when Cout fills them; 64 for the Cout = 64 layers (and any Cout % 128 in (0, 64])
+    const int rem = a.Cout % 128;
+    if (a.Cout >= 128 && (rem == 0 || rem > 64)) return launch_wino4_cfg<2>(a, s);
+    return launch_wino4_cfg<1>(a, s);
 }
 
 }  // namespace miunet

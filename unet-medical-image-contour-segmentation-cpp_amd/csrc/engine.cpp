@@ -288,7 +288,7 @@ int build_host_weights(const mi_unet_config &cfg, int algo, const void *blob, si
             off.w = alloc((size_t)nch * 16 * cpad * WINO_KC);
             if (algo == MI_UNET_CONV_WINOGRAD16) pack_wino16(w, sc.data(), cin, cout, &out[off.w], cpad);
             else pack_wino(w, sc.data(), cin, cout, &out[off.w], cpad);
-            if (algo == MI_UNET_CONV_WINOGRAD && cout % 128 == 0 && wino4_enabled()) {   // second packing: the F(4x4,3x3) kernel takes
+            if (algo == MI_UNET_CONV_WINOGRAD && cout % 64 == 0 && wino4_enabled()) {   // second packing: the F(4x4,3x3) kernel takes
                 const int nch4 = (cin + WINO4_KC - 1) / WINO4_KC;                      // the layer whenever its grid fills the chip
                 off.w4 = alloc((size_t)nch4 * 36 * cpad * WINO4_KC);
                 pack_wino4(w, sc.data(), cin, cout, &out[off.w4], cpad);
@@ -504,10 +504,10 @@ int launch_plan(mi_unet *h, const uint8_t *d_imgs, int B, uint8_t *d_labels, flo
             else if (h->algo == MI_UNET_CONV_FP16) { kname = "conv3x3_fp16"; e = launch_conv3x3_fp16(a, s); }
             else if (h->algo == MI_UNET_CONV_WINOGRAD16) { kname = "conv3x3_wino16"; e = launch_conv3x3_wino16(a, s); }
             else if (h->algo == MI_UNET_CONV_WINOGRAD) {
-                // F(4x4,3x3) where it was packed (Cout % 128 == 0) and its 16x16-pixel x 128-channel grid fills the chip;
+                // F(4x4,3x3) where it was packed (Cout % 64 == 0) and its 16x16-pixel x 128-channel grid fills the chip;
                 // small grids (single images, deep levels) stay on F(2x2,3x3), which can split K
                 // (MIUNET_SPLITK=0 = batch-invariant mode: no split-K workspace, and the choice must not depend on B either)
-                const long long wg4 = (long long)((a.W + 15) / 16) * ((a.H + 15) / 16) * B * (a.Cout / 128);
+                const long long wg4 = (long long)((a.W + 15) / 16) * ((a.H + 15) / 16) * B * ((a.Cout + 127) / 128);
                 if (a.wpk4 != nullptr && (wg4 >= 256 || h->d_ksplit == nullptr)) { kname = "conv3x3_wino4"; e = launch_conv3x3_wino4(a, s); }
                 else { kname = "conv3x3_wino"; e = launch_conv3x3_wino(a, s); }
             }

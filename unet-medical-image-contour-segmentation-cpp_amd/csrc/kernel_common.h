@@ -18,20 +18,25 @@ __device__ __forceinline__ int xcd_remap(int bid, int nwg)
     return start + (bid >> 3);
 }
 
-// Kernels that need more than 64 KB of dynamic LDS must opt in once per (kernel, device).
+// Kernels that need more than 64 KB of dynamic LDS must opt in once per (kernel, device).  Keyed by the kernel's address:
+// template instantiations share one function-pointer TYPE, so a per-type flag would cover only the first of them.
 template <typename K>
 inline hipError_t ensure_dynamic_lds(K kernel, size_t bytes)
 {
-    static bool done[64] = {};
+    struct Slot { const void *fn; bool done[64]; };
+    static Slot slots[16] = {};
+    const void *fn = reinterpret_cast<const void *>(kernel);
     int dev = 0;
     hipError_t e = hipGetDevice(&dev);
     if (e != hipSuccess) return e;
     if (dev < 0 || dev >= 64) return hipErrorInvalidDevice;
-    if (!done[dev]) {
-        e = hipFuncSetAttribute(reinterpret_cast<const void *>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
-        if (e != hipSuccess) return e;
-        done[dev] = true;
-    }
+    Slot *sl = nullptr;
+    for (Slot &c : slots)
+        if (c.fn == fn || c.fn == nullptr) { sl = &c; break; }
+    if (sl != nullptr && sl->fn == fn && sl->done[dev]) return hipSuccess;
+    e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+    if (e != hipSuccess) return e;
+    if (sl != nullptr) { sl->fn = fn; sl->done[dev] = true; }       // table full: just set the attribute every time
     return hipSuccess;
 }
 
