@@ -77,30 +77,37 @@ __global__ __launch_bounds__(256, 1) void conv3x3_wino4_f32(const ConvArgs a, co
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int j16 = lane & 15, kq = lane >> 4;
 
-    const int L = xcd_remap(blockIdx.x, nwg);
-    const int n_tile = L / m_tiles;
-    int m = L - n_tile * m_tiles;
-    const int tx = m % tiles_x; m /= tiles_x;
-    const int ty = m % tiles_y;
-    const int b = m / tiles_y;
-    const int bx0 = tx * 16, by0 = ty * 16, n0 = n_tile * 64 * NB;
-    const float *in_img = a.in + (size_t)b * a.H * a.W * a.ldc;
-
-    // ---- stage 1: raw halo patch, one 16-channel chunk at a time, global -> registers -> LDS (4 lanes = one pixel's 64
+    // ---- per-tile state.  The workgroup is persistent: it walks the tiles of its XCD's logical range with a stride of that
+    // XCD's workgroup count (the 32 CUs of an XCD work on neighbouring tiles of one channel group at a time), and the loads
+    // that open tile T+1 (its first two raw chunks, its first U fragments) are issued before the epilogue of tile T.
+    int bx0 = 0, by0 = 0, b = 0, ncol0 = 0;
+    unsigned u_voff = 0;
+    __amdgpu_buffer_rsrc_t in_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(a.in), 0, 0, 0x00020000);
+    // stage 1: raw halo patch, one 16-channel chunk at a time, global -> registers -> LDS (4 lanes = one pixel's 64
     // bytes; zero padding, channels past Cin and dead slots through the buffer range check: voffset 0xFFFFFFFF reads zeros)
-    const __amdgpu_buffer_rsrc_t in_rsrc =
-        __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(in_img), 0, a.H * a.W * a.ldc * 4, 0x00020000);
     unsigned raw_voff[W4::RAW_ITERS];
+    auto setup_tile = [&](int L) {
+        const int n_tile = L / m_tiles;
+        int m = L - n_tile * m_tiles;
+        const int tx = m % tiles_x; m /= tiles_x;
+        const int ty = m % tiles_y;
+        b = m / tiles_y;
+        bx0 = tx * 16; by0 = ty * 16;
+        ncol0 = n_tile * 64 * NB + 16 * NB * wave + j16;
+        u_voff = (unsigned)(ncol0 * WINO4_KC + 4 * kq) * 4;
+        in_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(a.in + (size_t)b * a.H * a.W * a.ldc), 0,
+                                                    a.H * a.W * a.ldc * 4, 0x00020000);
 #pragma unroll
-    for (int s = 0; s < W4::RAW_ITERS; ++s) {
-        const int pix = (tid >> 2) + 64 * s;
-        const int py = pix / 18, px = pix - py * 18;
-        const int gy = by0 - 1 + py, gx = bx0 - 1 + px;
-        const bool inb = pix < W4::RAWPIX && gy >= 0 && gy < a.H && gx >= 0 && gx < a.W;
-        raw_voff[s] = inb ? (unsigned)(((gy * a.W + gx) * a.ldc + 4 * (tid & 3)) * 4) : 0xFFFFFFFFu;
-    }
+        for (int s = 0; s < W4::RAW_ITERS; ++s) {
+            const int pix = (tid >> 2) + 64 * s;
+            const int py = pix / 18, px = pix - py * 18;
+            const int gy = by0 - 1 + py, gx = bx0 - 1 + px;
+            const bool inb = pix < W4::RAWPIX && gy >= 0 && gy < a.H && gx >= 0 && gx < a.W;
+            raw_voff[s] = inb ? (unsigned)(((gy * a.W + gx) * a.ldc + 4 * (tid & 3)) * 4) : 0xFFFFFFFFu;
+        }
+    };
     float *const raw_wr = Raw + (tid >> 2) * RAW_P + 4 * (tid & 3);          // + buf*RAW_FLOATS + s*64*RAW_P
-    f32x4 raw_reg[W4::RAW_ITERS];
+    f32x4 raw_reg[W4::RAW_ITERS], raw_reg1[W4::RAW_ITERS];     // raw_reg1: only between a tile's opening loads and its prologue
     auto raw_load = [&](int chunk) {
         const int c0 = chunk * WINO4_KC;
         const bool c_ok = c0 + 4 * (tid & 3) < a.Cin;
@@ -184,9 +191,7 @@ __global__ __launch_bounds__(256, 1) void conv3x3_wino4_f32(const ConvArgs a, co
     };
 
     // ---- MFMA role: wave w, channels n0 + 16 NB w .. (NB 16-column blocks), all 36 positions
-    const int ncol0 = n0 + 16 * NB * wave + j16;
     const unsigned u_pos_bytes = (unsigned)a.CoutPad * WINO4_KC * 4;
-    const unsigned u_voff = (unsigned)(ncol0 * WINO4_KC + 4 * kq) * 4;
     const int all_chunks = (a.Cin + WINO4_KC - 1) / WINO4_KC;
     const __amdgpu_buffer_rsrc_t u_rsrc =
         __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(a.wpk4), 0, (int)(all_chunks * 36 * u_pos_bytes), 0x00020000);
@@ -196,6 +201,41 @@ __global__ __launch_bounds__(256, 1) void conv3x3_wino4_f32(const ConvArgs a, co
     };
     const float *const v_rd = Vs + j16 * VROW + 4 * kq;                       // + buf*VBUF + pos*VPOS
 
+    const int nchunks = all_chunks;
+    const float relu_lo = a.relu ? 0.f : -3.402823466e+38f;
+    const int Hp = a.H >> 1, Wp = a.W >> 1;
+    const bool do_pool = a.pool_out != nullptr;
+    const unsigned pix_bytes = (unsigned)a.ldo * 4, row_bytes = (unsigned)a.W * pix_bytes;
+    const unsigned ppix_bytes = (unsigned)a.pool_ld * 4, prow_bytes = (unsigned)Wp * ppix_bytes;
+    f32x4 u[UD][NB];
+    // the loads that open a tile: the U ring, then the raw patches of chunks 0 and 1 (both in flight at once)
+    auto open_tile = [&]() {
+#pragma unroll
+        for (int p = 0; p < UD; ++p)
+#pragma unroll
+            for (int blk = 0; blk < NB; ++blk) u[p][blk] = u_load(0, p, blk);
+        raw_load(0);
+        const bool c_ok = WINO4_KC + 4 * (tid & 3) < a.Cin;
+#pragma unroll
+        for (int s = 0; s < W4::RAW_ITERS; ++s)
+            raw_reg1[s] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(in_rsrc, c_ok ? raw_voff[s] : 0xFFFFFFFFu, WINO4_KC * 4, 0));
+    };
+
+    // PERSIST (one-block variant): this workgroup's share of its XCD's logical tile range (the bijective XCD remap of
+    // kernel_common.h, walked with a stride).  The two-block variant has no registers left to hold a second tile's opening
+    // loads across its epilogue: one tile per workgroup there (the loop below runs once and folds away).
+    constexpr bool PERSIST = NB == 1;
+    const int G = gridDim.x, xcd = blockIdx.x & 7;
+    const int slot = PERSIST ? (int)(blockIdx.x >> 3) : 0;
+    const int slots = PERSIST ? (G >> 3) + (xcd < (G & 7) ? 1 : 0) : 1;
+    const int q_ = nwg >> 3, r_ = nwg & 7;
+    const int t_start = PERSIST ? ((xcd < r_) ? xcd * (q_ + 1) : r_ * (q_ + 1) + (xcd - r_) * q_) : xcd_remap(blockIdx.x, nwg);
+    const int t_count = PERSIST ? q_ + (xcd < r_ ? 1 : 0) : 1;
+    if (slot < t_count) {
+        setup_tile(t_start + slot);
+        open_tile();
+    }
+    for (int tt = slot; tt < t_count; tt += slots) {
     f32x4 acc[36][NB];
 #pragma unroll
     for (int p = 0; p < 36; ++p)
@@ -206,27 +246,12 @@ __global__ __launch_bounds__(256, 1) void conv3x3_wino4_f32(const ConvArgs a, co
 #pragma unroll
             for (int r = 0; r < 4; ++r) acc[p][blk][r] = init;
         }
-
-    const int nchunks = all_chunks;
-    f32x4 u[UD][NB];
-#pragma unroll
-    for (int p = 0; p < UD; ++p)
-#pragma unroll
-        for (int blk = 0; blk < NB; ++blk) u[p][blk] = u_load(0, p, blk);
     // prologue: raw patches of chunks 0 and 1 -> LDS, V of chunk 0
-    {
-        f32x4 raw_reg1[W4::RAW_ITERS];        // both chunks in flight at once: one memory latency, not two
-        raw_load(0);
-        const bool c_ok = WINO4_KC + 4 * (tid & 3) < a.Cin;
+    raw_store(0);
 #pragma unroll
-        for (int s = 0; s < W4::RAW_ITERS; ++s)
-            raw_reg1[s] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(in_rsrc, c_ok ? raw_voff[s] : 0xFFFFFFFFu, WINO4_KC * 4, 0));
-        raw_store(0);
-#pragma unroll
-        for (int s = 0; s < W4::RAW_ITERS; ++s)
-            if (s + 1 < W4::RAW_ITERS || (tid >> 2) + 64 * s < W4::RAWPIX)
-                *reinterpret_cast<f32x4 *>(raw_wr + W4::RAW_FLOATS + s * 64 * RAW_P) = raw_reg1[s];
-    }
+    for (int s = 0; s < W4::RAW_ITERS; ++s)
+        if (s + 1 < W4::RAW_ITERS || (tid >> 2) + 64 * s < W4::RAWPIX)
+            *reinterpret_cast<f32x4 *>(raw_wr + W4::RAW_FLOATS + s * 64 * RAW_P) = raw_reg1[s];
     __syncthreads();
     transform_all(0, 0);
     __syncthreads();
@@ -297,32 +322,34 @@ __global__ __launch_bounds__(256, 1) void conv3x3_wino4_f32(const ConvArgs a, co
     // initial value of position (1,1), whose inverse transform is the all-ones tile.  Stores are buffer stores on a
     // per-image descriptor: one per-lane byte offset for the whole tile row, the pixel displacement in the scalar offset;
     // pixels past the image edge and masked channels get voffset 0xFFFFFFFF, which the range check drops.
-    const float relu_lo = a.relu ? 0.f : -3.402823466e+38f;
+    const int e_b = b, e_by0 = by0, e_bx0 = bx0, e_ncol0 = ncol0;
+    if constexpr (PERSIST) {
+        if (tt + slots < t_count) {           // open the next tile: its loads fly during this tile's epilogue
+            setup_tile(t_start + tt + slots);
+            open_tile();
+        }
+    }
     const __amdgpu_buffer_rsrc_t out_rsrc = __builtin_amdgcn_make_buffer_rsrc(
-        a.out + (size_t)b * a.H * a.W * a.ldo, 0, a.H * a.W * a.ldo * 4, 0x00020000);
-    const int Hp = a.H >> 1, Wp = a.W >> 1;
-    const bool do_pool = a.pool_out != nullptr;
+        a.out + (size_t)e_b * a.H * a.W * a.ldo, 0, a.H * a.W * a.ldo * 4, 0x00020000);
     const __amdgpu_buffer_rsrc_t pool_rsrc = __builtin_amdgcn_make_buffer_rsrc(
-        do_pool ? a.pool_out + (size_t)b * Hp * Wp * a.pool_ld : a.out, 0, do_pool ? Hp * Wp * a.pool_ld * 4 : 0, 0x00020000);
-    const int oy = by0 + 4 * kq;
-    const unsigned pix_bytes = (unsigned)a.ldo * 4, row_bytes = (unsigned)a.W * pix_bytes;
-    const unsigned ppix_bytes = (unsigned)a.pool_ld * 4, prow_bytes = (unsigned)Wp * ppix_bytes;
+        do_pool ? a.pool_out + (size_t)e_b * Hp * Wp * a.pool_ld : a.out, 0, do_pool ? Hp * Wp * a.pool_ld * 4 : 0, 0x00020000);
+    const int oy = e_by0 + 4 * kq;
     auto epilogue = [&](auto interior_tag) {
         constexpr bool INTERIOR = decltype(interior_tag)::value;
 #pragma unroll
         for (int blk = 0; blk < NB; ++blk) {
-            const int ncol = ncol0 + 16 * blk;
+            const int ncol = e_ncol0 + 16 * blk;
             const bool n_ok = ncol < a.Cout;
-            const unsigned vbase = n_ok ? (unsigned)((oy * a.W + bx0) * a.ldo + a.co_off + ncol) * 4 : 0xFFFFFFFFu;
-            const unsigned pbase = n_ok ? (unsigned)(((oy >> 1) * Wp + (bx0 >> 1)) * a.pool_ld + ncol) * 4 : 0xFFFFFFFFu;
+            const unsigned vbase = n_ok ? (unsigned)((oy * a.W + e_bx0) * a.ldo + a.co_off + ncol) * 4 : 0xFFFFFFFFu;
+            const unsigned pbase = n_ok ? (unsigned)(((oy >> 1) * Wp + (e_bx0 >> 1)) * a.pool_ld + ncol) * 4 : 0xFFFFFFFFu;
             unsigned vcol[4][4], pcol[4][2];          // edge workgroups: per-column offsets (dead columns -> dropped stores)
             if constexpr (!INTERIOR) {
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
 #pragma unroll
-                    for (int k = 0; k < 4; ++k) vcol[r][k] = bx0 + 4 * r + k < a.W ? vbase : 0xFFFFFFFFu;
-                    pcol[r][0] = bx0 + 4 * r + 1 < a.W ? pbase : 0xFFFFFFFFu;
-                    pcol[r][1] = bx0 + 4 * r + 3 < a.W ? pbase : 0xFFFFFFFFu;
+                    for (int k = 0; k < 4; ++k) vcol[r][k] = e_bx0 + 4 * r + k < a.W ? vbase : 0xFFFFFFFFu;
+                    pcol[r][0] = e_bx0 + 4 * r + 1 < a.W ? pbase : 0xFFFFFFFFu;
+                    pcol[r][1] = e_bx0 + 4 * r + 3 < a.W ? pbase : 0xFFFFFFFFu;
                 }
             }
             f32x4 t[4][6];
@@ -378,8 +405,21 @@ __global__ __launch_bounds__(256, 1) void conv3x3_wino4_f32(const ConvArgs a, co
             }
         }
     };
-    if (by0 + 16 <= a.H && bx0 + 16 <= a.W) epilogue(std::true_type{});     // workgroup-uniform: no per-pixel predicates
+    if (e_by0 + 16 <= a.H && e_bx0 + 16 <= a.W) epilogue(std::true_type{});     // workgroup-uniform: no per-pixel predicates
     else epilogue(std::false_type{});
+    }   // persistent tile loop
+}
+
+static int persistent_cus()
+{
+    static int cus[64] = {};
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return 256;
+    if (cus[dev] == 0) {
+        hipDeviceProp_t p;
+        cus[dev] = (hipGetDeviceProperties(&p, dev) == hipSuccess && p.multiProcessorCount > 0) ? p.multiProcessorCount : 256;
+    }
+    return cus[dev];
 }
 
 template <int NB>
@@ -391,7 +431,9 @@ static hipError_t launch_wino4_cfg(const ConvArgs &a, hipStream_t s)
     const int nwg = m_tiles * n_tiles;
     auto kern = conv3x3_wino4_f32<NB>;
     if (hipError_t e = ensure_dynamic_lds(kern, W4::LDS_BYTES); e != hipSuccess) return e;
-    hipLaunchKernelGGL(kern, dim3(nwg), dim3(256), W4::LDS_BYTES, s, a, tiles_x, tiles_y, m_tiles, nwg);
+    // one-block variant: persistent, one workgroup per CU (144 KB of LDS each); two-block variant: one tile per workgroup
+    const int grid = (NB == 1 && nwg > persistent_cus()) ? persistent_cus() : nwg;
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(256), W4::LDS_BYTES, s, a, tiles_x, tiles_y, m_tiles, nwg);
     return hipGetLastError();
 }
 

@@ -123,8 +123,9 @@ def make_threshold_weights(spec: UNetSpec) -> dict:
     """Structured weights for end-to-end runs: random weights give speckle label maps that postprocess_mask erases
     (nothing reaches 6 % of the image), so the polygon half would never run.  Here the network is an intensity
     classifier routed through the top skip connection: channel 0 carries x = pixel/255 unchanged (centre taps, BN
-    scale 1), everything else is zero, and the head is  class0 = 0.3, class1 = 0.5 x + 0.1, class2 = x - 0.15
-    =>  x < 0.4 -> 0,  0.4 < x < 0.5 -> 1,  x > 0.5 -> 2."""
+    scale 1), everything else is zero, and the head is  class0 = 0.301, class1 = 0.5 x + 0.1, class2 = x - 0.15
+    =>  x < 0.402 -> 0,  0.402 < x < 0.5 -> 1,  x > 0.5 -> 2.  Both thresholds fall BETWEEN 8-bit levels (102.51 and 127.5
+    of 255), so no pixel value produces tied logits: the smallest margin is ~1e-3 and label maps are comparable exactly."""
     t = {}
     for name, shape in spec.tensor_list():
         if name.endswith(".gamma"):
@@ -141,5 +142,5 @@ def make_threshold_weights(spec: UNetSpec) -> dict:
     t[f"up{L}.c2.w"][0, 0, 1, 1] = 1.0
     t["outc.w"][1, 0] = 0.5
     t["outc.w"][2, 0] = 1.0
-    t["outc.b"][:3] = [0.3, 0.1, -0.15]
+    t["outc.b"][:3] = [0.301, 0.1, -0.15]
     return t
