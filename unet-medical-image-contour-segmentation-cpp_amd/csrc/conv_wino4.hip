@@ -53,10 +53,15 @@ struct W4 {
     static constexpr int VPOS = TMB * VROW;                 // floats per position
     static constexpr int VBUF = 36 * VPOS;                  // floats per V buffer
     static constexpr int RAWPIX = 18 * 18;
-    static constexpr int RAW_P = WINO4_KC + 4;              // padded floats per raw pixel (80-byte stride: the 4 tiles x 4 quads
-                                                            // of a 16-lane group hit 64 distinct banks)
-    static constexpr int RAW_FLOATS = RAWPIX * RAW_P;       // one 16-channel chunk of the halo patch
-    static constexpr int RAW_ITERS = (RAWPIX * (WINO4_KC / 4) + 255) / 256;     // 6 (the last one: 16 live lanes)
+    // the raw patch of one 16-channel chunk is written by LDS-DMA loads (buffer_load_dwordx4 ... lds: 64 lanes x 16 bytes
+    // land CONTIGUOUSLY, no padding possible), so bank spreading comes from the ORDER of the pixel slots instead: a patch
+    // row holds 20 slots of 64 bytes and pixel x = 4a + c sits in slot 5c + a -- the four tiles of a 16-lane group read
+    // x, x+4, x+8, x+12 = consecutive slots = four distinct 16-word bank groups, times four channel quads = all 64 banks.
+    static constexpr int RAW_ROW = 20;                      // pixel slots per patch row (18 live)
+    static constexpr int RAW_SLOTS = 18 * RAW_ROW;          // 360 live slots, written by 23 wave-wide loads of 16 slots
+    static constexpr int RAW_LOADS = (RAW_SLOTS + 15) / 16; // 23
+    static constexpr int RAW_FLOATS = RAW_LOADS * 16 * WINO4_KC;   // buffer padded to whole loads (dead lanes write zeros)
+    static constexpr int RAW_ITERS = (RAW_LOADS + 3) / 4;   // loads per wave (6; wave 3 skips its last)
     static constexpr size_t LDS_BYTES = sizeof(float) * (2 * VBUF + 2 * RAW_FLOATS);
 };
 
@@ -66,11 +71,11 @@ template <int NB>
 __global__ __launch_bounds__(256, 1) void conv3x3_wino4_f32(const ConvArgs a, const int tiles_x, const int tiles_y,
                                                             const int m_tiles, const int nwg)
 {
-    constexpr int VROW = W4::VROW, VPOS = W4::VPOS, VBUF = W4::VBUF, RAW_P = W4::RAW_P;
+    constexpr int VROW = W4::VROW, VPOS = W4::VPOS, VBUF = W4::VBUF;
     constexpr int UD = NB == 1 ? 9 : 6;       // U prefetch distance in positions (36 % UD == 0); the one-block variant has registers to spare
     extern __shared__ __attribute__((aligned(16))) float lds[];
     float *const Vs = lds;                    // [2][36][16][VROW]
-    float *const Raw = lds + 2 * VBUF;        // [2][RAWPIX][RAW_P]: the input halo patch of one 16-channel chunk, double-buffered
+    float *const Raw = lds + 2 * VBUF;        // [2][18 rows][20 slots][16]: the input halo patch of one 16-channel chunk, double-buffered
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -99,27 +104,23 @@ __global__ __launch_bounds__(256, 1) void conv3x3_wino4_f32(const ConvArgs a, co
                                                     a.H * a.W * a.ldc * 4, 0x00020000);
 #pragma unroll
         for (int s = 0; s < W4::RAW_ITERS; ++s) {
-            const int pix = (tid >> 2) + 64 * s;
-            const int py = pix / 18, px = pix - py * 18;
+            const int g = (wave + 4 * s) * 16 + (lane >> 2);                  // linear slot of this lane in load wave + 4s
+            const int py = g / W4::RAW_ROW, sl = g - py * W4::RAW_ROW;
+            const int px = 4 * (sl % 5) + sl / 5;
             const int gy = by0 - 1 + py, gx = bx0 - 1 + px;
-            const bool inb = pix < W4::RAWPIX && gy >= 0 && gy < a.H && gx >= 0 && gx < a.W;
-            raw_voff[s] = inb ? (unsigned)(((gy * a.W + gx) * a.ldc + 4 * (tid & 3)) * 4) : 0xFFFFFFFFu;
+            const bool inb = g < W4::RAW_SLOTS && px < 18 && gy >= 0 && gy < a.H && gx >= 0 && gx < a.W;
+            raw_voff[s] = inb ? (unsigned)(((gy * a.W + gx) * a.ldc + 4 * (lane & 3)) * 4) : 0xFFFFFFFFu;
         }
     };
-    float *const raw_wr = Raw + (tid >> 2) * RAW_P + 4 * (tid & 3);          // + buf*RAW_FLOATS + s*64*RAW_P
-    f32x4 raw_reg[W4::RAW_ITERS], raw_reg1[W4::RAW_ITERS];     // raw_reg1: only between a tile's opening loads and its prologue
-    auto raw_load = [&](int chunk) {
+    typedef __attribute__((address_space(3))) void *lds_ptr;
+    auto raw_dma = [&](int chunk, int buf) {   // global -> LDS directly: no registers, no ds_write; completion = vmcnt
         const int c0 = chunk * WINO4_KC;
-        const bool c_ok = c0 + 4 * (tid & 3) < a.Cin;
+        const bool c_ok = c0 + 4 * (lane & 3) < a.Cin;
 #pragma unroll
         for (int s = 0; s < W4::RAW_ITERS; ++s)
-            raw_reg[s] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(in_rsrc, c_ok ? raw_voff[s] : 0xFFFFFFFFu, c0 * 4, 0));
-    };
-    auto raw_store = [&](int buf) {
-#pragma unroll
-        for (int s = 0; s < W4::RAW_ITERS; ++s)
-            if (s + 1 < W4::RAW_ITERS || (tid >> 2) + 64 * s < W4::RAWPIX)
-                *reinterpret_cast<f32x4 *>(raw_wr + buf * W4::RAW_FLOATS + s * 64 * RAW_P) = raw_reg[s];
+            if (wave + 4 * s < W4::RAW_LOADS)
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(in_rsrc, (lds_ptr)(Raw + buf * W4::RAW_FLOATS + (wave + 4 * s) * 16 * WINO4_KC), 16,
+                                                         c_ok ? raw_voff[s] : 0xFFFFFFFFu, c0 * 4, 0, 0);
     };
 
     // ---- stage 2: V = B^T d B for one 16-channel chunk; lane = (tile, channel quad), wave = row group of B^T:
@@ -128,15 +129,15 @@ __global__ __launch_bounds__(256, 1) void conv3x3_wino4_f32(const ConvArgs a, co
     const bool two = wave < 2;
     const int t_tile = lane >> 2, t_quad = lane & 3;
     const int row0 = two ? 1 : wave - 2, rstep = two ? 1 : 2;
-    const float *const p_rd = Raw + ((4 * (t_tile >> 2) + row0) * 18 + 4 * (t_tile & 3)) * RAW_P + 4 * t_quad;
-    const int p_rstride = rstep * 18 * RAW_P;
+    const float *const p_rd = Raw + (((4 * (t_tile >> 2) + row0) * W4::RAW_ROW + (t_tile & 3)) * 4 + t_quad) * 4;
+    const int p_rstride = rstep * W4::RAW_ROW * WINO4_KC;
     const int xi_a = two ? (wave == 0 ? 1 : 3) : (wave == 2 ? 0 : 5);
     float *const v_wr_a = Vs + xi_a * 6 * VPOS + t_tile * VROW + 4 * t_quad;      // + buf*VBUF + nu*VPOS; row b = + 6*VPOS
     f32x4 px_[4];                             // patch column k of this lane's rows
     f32x4 cR[2][6];                           // rows of B^T d (row b only on the two-row waves)
     f32x4 e_[4];
     auto piece_load = [&](int k, int rbuf) {
-        const float *src = p_rd + rbuf * W4::RAW_FLOATS + k * RAW_P;
+        const float *src = p_rd + rbuf * W4::RAW_FLOATS + ((k & 3) * 5 + (k >> 2)) * WINO4_KC;      // pixel 4*tx + k -> slot 5*(k&3) + tx + (k>>2)
         px_[0] = *reinterpret_cast<const f32x4 *>(src);
         px_[1] = *reinterpret_cast<const f32x4 *>(src + p_rstride);
         px_[2] = *reinterpret_cast<const f32x4 *>(src + 2 * p_rstride);
@@ -208,17 +209,14 @@ __global__ __launch_bounds__(256, 1) void conv3x3_wino4_f32(const ConvArgs a, co
     const unsigned pix_bytes = (unsigned)a.ldo * 4, row_bytes = (unsigned)a.W * pix_bytes;
     const unsigned ppix_bytes = (unsigned)a.pool_ld * 4, prow_bytes = (unsigned)Wp * ppix_bytes;
     f32x4 u[UD][NB];
-    // the loads that open a tile: the U ring, then the raw patches of chunks 0 and 1 (both in flight at once)
+    // the loads that open a tile: the raw patches of chunks 0 and 1 straight into LDS, then the U ring
     auto open_tile = [&]() {
+        raw_dma(0, 0);
+        raw_dma(1, 1);
 #pragma unroll
         for (int p = 0; p < UD; ++p)
 #pragma unroll
             for (int blk = 0; blk < NB; ++blk) u[p][blk] = u_load(0, p, blk);
-        raw_load(0);
-        const bool c_ok = WINO4_KC + 4 * (tid & 3) < a.Cin;
-#pragma unroll
-        for (int s = 0; s < W4::RAW_ITERS; ++s)
-            raw_reg1[s] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(in_rsrc, c_ok ? raw_voff[s] : 0xFFFFFFFFu, WINO4_KC * 4, 0));
     };
 
     // PERSIST (one-block variant): this workgroup's share of its XCD's logical tile range (the bijective XCD remap of
@@ -246,19 +244,16 @@ __global__ __launch_bounds__(256, 1) void conv3x3_wino4_f32(const ConvArgs a, co
 #pragma unroll
             for (int r = 0; r < 4; ++r) acc[p][blk][r] = init;
         }
-    // prologue: raw patches of chunks 0 and 1 -> LDS, V of chunk 0
-    raw_store(0);
-#pragma unroll
-    for (int s = 0; s < W4::RAW_ITERS; ++s)
-        if (s + 1 < W4::RAW_ITERS || (tid >> 2) + 64 * s < W4::RAWPIX)
-            *reinterpret_cast<f32x4 *>(raw_wr + W4::RAW_FLOATS + s * 64 * RAW_P) = raw_reg1[s];
+    // prologue: the raw patches of chunks 0 and 1 are landing in LDS (and, in the persistent variant, the previous tile's
+    // stores are draining): vmcnt(0), barrier, V of chunk 0
+    __builtin_amdgcn_s_waitcnt(0x0F70);       // vmcnt(0), expcnt / lgkmcnt untouched
     __syncthreads();
     transform_all(0, 0);
     __syncthreads();
 
     // Per chunk c, around its 288 MFMAs (one barrier per chunk):
-    //   positions 0 / 24  : buffer loads of chunk c+2's raw patch / their LDS stores into Raw[c & 1] (whose last reader, the
-    //                       transform of chunk c, ran during chunk c-1)
+    //   position 0        : LDS-DMA loads of chunk c+2's raw patch into Raw[c & 1] (whose last reader, the transform of
+    //                       chunk c, ran during chunk c-1)
     //   positions 2 - 22  : the transform of chunk c+1 (Raw[(c+1) & 1] -> V[(c+1) & 1]) in pieces between the MFMAs
     //   every position    : the V fragment one position ahead, the U ring six positions ahead
     for (int chunk = 0; chunk < nchunks; ++chunk) {
@@ -272,8 +267,7 @@ __global__ __launch_bounds__(256, 1) void conv3x3_wino4_f32(const ConvArgs a, co
             f32x4 avn = av;
             if (p + 1 < 36) avn = *reinterpret_cast<const f32x4 *>(vb + (p + 1) * VPOS);   // V fragment one position ahead
 #ifndef W4_ABL_NO_RAW
-            if (p == 0) raw_load(chunk + 2);
-            if (p == 24) raw_store(chunk & 1);
+            if (p == 0) raw_dma(chunk + 2, chunk & 1);
 #endif
 #ifndef W4_ABL_NO_TRANSFORM
             if (p == 2) piece_load(0, rbuf);
@@ -314,6 +308,8 @@ __global__ __launch_bounds__(256, 1) void conv3x3_wino4_f32(const ConvArgs a, co
             av = avn;
             __builtin_amdgcn_sched_barrier(0);
         }
+        // the DMA of position 0 is older than every U load of this chunk; NB*UD of those are still allowed in flight
+        __builtin_amdgcn_s_waitcnt(0x0F70 | ((NB * UD) & 15) | (((NB * UD) >> 4) << 14));
         __syncthreads();
     }
 
