@@ -138,24 +138,29 @@ def test_conv3x3_wino4_tap_orientation_exact():
     (2, 4, 4, 128, 64),
     (1, 3, 5, 1024, 512),      # ragged, u1.t shape
     (1, 16, 48, 128, 64),
+    (2, 9, 70, 40, 128),       # ragged rows and columns, Cin % 32 != 0, the 4x4 configuration
+    (1, 6, 32, 96, 256),       # the 2x8 configuration
+    (1, 2, 33, 64, 576),       # the 1x16 configuration, two n-tiles, masked channels
 ])
-def test_convT2x2_mfma(B, H, W, Cin, Cout):
+@pytest.mark.parametrize("op", ["convT2x2", "convT2x2_taps"])
+def test_convT2x2_mfma(B, H, W, Cin, Cout, op):
     r = _rng(H * 7 + W + Cin)
     x = r.standard_normal((B, H, W, Cin), dtype=np.float32)
     w = (r.standard_normal((Cin, Cout, 2, 2), dtype=np.float32) / np.sqrt(Cin)).astype(np.float32)
     bias = (0.1 * r.standard_normal(Cout)).astype(np.float32)
-    got = binding.layer_debug("convT2x2", x, w, None, bias)
+    got = binding.layer_debug(op, x, w, None, bias)
     ref = orc.convT2x2(x, w, bias)
     assert not np.isnan(got).any()
     assert np.max(np.abs(got - ref)) < _tol(ref)
 
 
-def test_convT2x2_tap_placement_exact():
+@pytest.mark.parametrize("op", ["convT2x2", "convT2x2_taps"])
+def test_convT2x2_tap_placement_exact(op):
     r = _rng(3)
     x = r.integers(-4, 5, (1, 4, 6, 16)).astype(np.float32)
     w = r.integers(-3, 4, (16, 64, 2, 2)).astype(np.float32)
     bias = r.integers(-2, 3, 64).astype(np.float32)
-    got = binding.layer_debug("convT2x2", x, w, None, bias)
+    got = binding.layer_debug(op, x, w, None, bias)
     assert np.array_equal(got, orc.convT2x2(x, w, bias))
 
 

@@ -143,6 +143,17 @@ void pack_wino4(const float *w, const double *scale, int cin, int cout, float *d
         }
 }
 
+// convT [Cin][Cout][2][2] packed per tap for convT2x2_taps_f32: [ceil(Cin/32)*4][4 taps][cpad][8], zeros elsewhere
+size_t convT_taps_floats(int cin, int cout) { return (size_t)((cin + 31) / 32) * 4 * 4 * convT_taps_cpad(cout) * 8; }
+void pack_convT_taps(const float *w, int cin, int cout, float *dst)
+{
+    const size_t cpad = (size_t)convT_taps_cpad(cout);
+    for (int ci = 0; ci < cin; ++ci)
+        for (int co = 0; co < cout; ++co)
+            for (int tap = 0; tap < 4; ++tap)
+                dst[(((size_t)(ci / 8) * 4 + tap) * cpad + co) * 8 + ci % 8] = w[((size_t)ci * cout + co) * 4 + tap];
+}
+
 // same U, packed for conv3x3_wino16_f32: [Cin/8][8 position pairs][CoutPad][16], element 4*(k/2) + 2*(pos&1) + (k&1)
 void pack_wino16(const float *w, const double *scale, int cin, int cout, float *dst, size_t cpad)
 {
@@ -222,6 +233,12 @@ struct HostWeights {
     std::vector<Off> convT;
     Off head{};
 };
+
+bool convT_taps_enabled()
+{
+    const char *e = std::getenv("MIUNET_CONVT_TAPS");
+    return !(e && e[0] == '0');
+}
 
 bool wino4_enabled()
 {
@@ -332,6 +349,10 @@ int build_host_weights(const mi_unet_config &cfg, int algo, const void *blob, si
                 for (int co = 0; co < cout; ++co)
                     for (int k = 0; k < 4; ++k)
                         out[off.w + ((size_t)(ci / KC) * npad + (size_t)k * cout + co) * KC + ci % KC] = w[((size_t)ci * cout + co) * 4 + k];
+            if (cout % 64 == 0 && convT_taps_enabled()) {      // second packing: the per-tap GEMM kernel (convt_taps.hip)
+                off.w4 = alloc(convT_taps_floats(cin, cout));
+                pack_convT_taps(w, cin, cout, &out[off.w4]);
+            }
         }
         hw.convT.push_back(off);
         rc = add_dconv(cin, cout);
@@ -419,6 +440,7 @@ int build_plan(mi_unet *h, const HostWeights &hw)
         Step t;
         t.kind = Step::CONVT; t.name = "up" + std::to_string(i) + ".t";
         t.a.in = cur; t.a.wpk = W_(hw.convT[ti].w); t.a.bias = W_(hw.convT[ti].shift); t.a.out = h->d_cat[lvl];
+        t.a.wpk4 = hw.convT[ti].w4 ? W_(hw.convT[ti].w4) : nullptr;
         t.a.H = H; t.a.W = Wd; t.a.Cin = cin; t.a.ldc = cin; t.a.Cout = cout;
         t.a.CoutPad = (int)round_up((size_t)4 * cout, NPAD); t.a.ldo = 2 * cout; t.a.co_off = cout; t.a.relu = 0;
         conv_cost(t, H, Wd, cin, cout, 4, true);
@@ -508,7 +530,8 @@ int launch_plan(mi_unet *h, const uint8_t *d_imgs, int B, uint8_t *d_labels, flo
                 // small grids (single images, deep levels) stay on F(2x2,3x3), which can split K
                 // (MIUNET_SPLITK=0 = batch-invariant mode: no split-K workspace, and the choice must not depend on B either)
                 const long long wg4 = (long long)((a.W + 15) / 16) * ((a.H + 15) / 16) * B * ((a.Cout + 127) / 128);
-                if (a.wpk4 != nullptr && (wg4 >= 256 || h->d_ksplit == nullptr)) { kname = "conv3x3_wino4"; e = launch_conv3x3_wino4(a, s); }
+                static const int min_wg4 = [] { const char *e = getenv("MIUNET_WINO4_MIN_WG"); return e ? atoi(e) : 256; }();
+                if (a.wpk4 != nullptr && (wg4 >= min_wg4 || h->d_ksplit == nullptr)) { kname = "conv3x3_wino4"; e = launch_conv3x3_wino4(a, s); }
                 else { kname = "conv3x3_wino"; e = launch_conv3x3_wino(a, s); }
             }
             else { kname = "conv3x3_mfma"; e = launch_conv3x3_mfma(a, s); }
@@ -518,6 +541,7 @@ int launch_plan(mi_unet *h, const uint8_t *d_imgs, int B, uint8_t *d_labels, flo
             ConvArgs a = st.a; a.B = B;
             if (h->algo == MI_UNET_CONV_BF16) { kname = "convT2x2_bf16"; e = launch_convT2x2_bf16(a, s); }
             else if (h->algo == MI_UNET_CONV_FP16) { kname = "convT2x2_fp16"; e = launch_convT2x2_fp16(a, s); }
+            else if (a.wpk4 != nullptr) { kname = "convT2x2_taps"; e = launch_convT2x2_taps(a, s); }
             else { kname = "convT2x2_mfma"; e = launch_convT2x2_mfma(a, s); }
             break;
         }
@@ -967,7 +991,16 @@ int mi_unet_layer_debug(int device, const char *op, const float *in, int B, int 
     std::vector<float> wpk, bias;
     size_t out_n = 0;
     ConvArgs a{};
-    if (o == "conv3x3_wino4") {
+    if (o == "convT2x2_taps") {
+        if (!w || Cout <= 0 || Cin % 4) return fail(MI_UNET_EARG, "layer_debug: conv needs weights and Cin % 4 == 0");
+        wpk.assign(convT_taps_floats(Cin, Cout), 0.f);
+        bias.assign(Cout, 0.f);
+        for (int co = 0; co < Cout; ++co) bias[co] = shift ? shift[co] : 0.f;
+        pack_convT_taps(w, Cin, Cout, wpk.data());
+        out_n = (size_t)B * 4 * H * W * Cout;
+        a.B = B; a.H = H; a.W = W; a.Cin = Cin; a.ldc = Cin; a.Cout = Cout; a.CoutPad = convT_taps_cpad(Cout); a.ldo = Cout; a.co_off = 0;
+        a.relu = relu;
+    } else if (o == "conv3x3_wino4") {
         if (!w || Cout <= 0 || Cin % 4) return fail(MI_UNET_EARG, "layer_debug: conv needs weights and Cin % 4 == 0");
         const int nch = (Cin + WINO4_KC - 1) / WINO4_KC;
         const size_t npad = round_up((size_t)Cout, NPAD);
@@ -1050,9 +1083,10 @@ int mi_unet_layer_debug(int device, const char *op, const float *in, int B, int 
         DBG_TRY(hipMemcpy(d_w, wpk.data(), sizeof(float) * wpk.size(), hipMemcpyHostToDevice));
         DBG_TRY(hipMemcpy(d_b, bias.data(), sizeof(float) * bias.size(), hipMemcpyHostToDevice));
         a.in = d_in; a.wpk = d_w; a.bias = d_b; a.out = d_out;
-        if (o == "conv3x3_wino4") a.wpk4 = d_w;
+        if (o == "conv3x3_wino4" || o == "convT2x2_taps") a.wpk4 = d_w;
         DBG_TRY(o == "conv3x3" ? launch_conv3x3_mfma(a, nullptr)
                 : o == "conv3x3_wino4" ? launch_conv3x3_wino4(a, nullptr)
+                : o == "convT2x2_taps" ? launch_convT2x2_taps(a, nullptr)
                 : o == "conv3x3_wino" ? launch_conv3x3_wino(a, nullptr)
                 : o == "conv3x3_wino16" ? launch_conv3x3_wino16(a, nullptr)
                 : o == "conv3x3_bf16" ? launch_conv3x3_bf16(a, nullptr)

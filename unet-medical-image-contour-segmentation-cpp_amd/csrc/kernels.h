@@ -54,6 +54,10 @@ constexpr int WINO4_KC = 16;
 constexpr int WINO4_SC = 32;
 hipError_t launch_conv3x3_wino4(const ConvArgs &a, hipStream_t s);
 hipError_t launch_convT2x2_mfma(const ConvArgs &a, hipStream_t s);
+// The transposed conv as four per-tap GEMMs sharing one A operand (convt_taps.hip): a.wpk4 holds the weights packed
+// [ceil(Cin/32)*4 chunks of 8][4 taps (dy*2+dx)][convT_taps_cpad(Cout)][8], zero-padded; other fields as above.
+inline int convT_taps_cpad(int cout) { return (cout + NPAD - 1) / NPAD * NPAD; }
+hipError_t launch_convT2x2_taps(const ConvArgs &a, hipStream_t s);
 
 // BASELINE config 3: bf16 operands, fp32 accumulate on v_mfma_f32_32x32x16_bf16.  Activations stay fp32 in HBM and are
 // rounded to bf16 (RNE) while they are staged into LDS; a.wpk holds bf16 weights packed [Cin/32][taps][CoutPad][32].

@@ -238,7 +238,7 @@ def layer_debug(op, x, w=None, scale=None, shift=None, relu=False, device=0):
         w = np.ascontiguousarray(w, np.float32)
         cout = w.shape[0]
         out = np.empty((b, h, ww, cout), np.float32)
-    elif op in ("convT2x2", "convT2x2_bf16", "convT2x2_fp16"):
+    elif op in ("convT2x2", "convT2x2_taps", "convT2x2_bf16", "convT2x2_fp16"):
         w = np.ascontiguousarray(w, np.float32)
         cout = w.shape[1]
         out = np.empty((b, 2 * h, 2 * ww, cout), np.float32)
