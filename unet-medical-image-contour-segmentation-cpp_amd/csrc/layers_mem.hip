@@ -4,46 +4,61 @@
 namespace miunet {
 
 // --------------------------------------------------------------------------------------------------------------------
-// First layer (K = 9*Cin with Cin <= 4: HBM-bound on its output).  One thread = one pixel x 4 output channels; the
-// Cout/4 threads of a pixel write one contiguous NHWC row.  u8 -> fp32 through the host-built 256-entry table so the
-// input equals float(x)/255.0f bit for bit (src/process.cpp:36-39).
+// First layer (K = 9*Cin with Cin <= 4: HBM-bound on its output, 1 GiB at batch 16).  A workgroup owns 64 consecutive
+// pixels of one image row; thread = (pixel slot, 4 output channels) and walks FOUR consecutive pixels, so the 3 x 6 input
+// bytes it needs are loaded and looked up once for all four (4.5 loads per pixel instead of 9) and there is no per-pixel
+// index arithmetic; the Cout/4 threads of a pixel write one contiguous NHWC row (256 bytes at Cout = 64).  u8 -> fp32
+// through the host-built 256-entry table so the input equals float(x)/255.0f bit for bit (src/process.cpp:36-39).
 template <int CIN>
 __global__ __launch_bounds__(256) void conv3x3_first_kernel(const uint8_t *__restrict__ img, const float *__restrict__ lut,
                                                             const float *__restrict__ w, const float *__restrict__ shift,
-                                                            float *__restrict__ out, int B, int H, int W, int Cout,
-                                                            int ldo, int quads)
+                                                            float *__restrict__ out, int H, int W, int Cout, int ldo,
+                                                            int quads, int xblocks)
 {
     __shared__ float s_lut[256];
     s_lut[threadIdx.x] = lut[threadIdx.x];
     __syncthreads();
     const int q = threadIdx.x % quads;            // which 4 couts
     const int pl = threadIdx.x / quads;           // pixel slot in block
-    const int ppb = 256 / quads;
+    const int ppb = 4 * (256 / quads);            // pixels per block (4 per slot)
+    const int xb = blockIdx.x % xblocks;
+    const int row = blockIdx.x / xblocks;         // b * H + y
+    const int y = row % H;
+    const int x0 = xb * ppb + 4 * pl;
+    if (x0 >= W) return;
     f32x4 wr[9 * CIN];
 #pragma unroll
     for (int t = 0; t < 9 * CIN; ++t) wr[t] = *reinterpret_cast<const f32x4 *>(w + (size_t)t * Cout + 4 * q);
     const f32x4 sh = *reinterpret_cast<const f32x4 *>(shift + 4 * q);
-    const long long npix = (long long)B * H * W;
-    for (long long p = (long long)blockIdx.x * ppb + pl; p < npix; p += (long long)gridDim.x * ppb) {
-        const int x = (int)(p % W);
-        const int y = (int)((p / W) % H);
-        const uint8_t *base = img + (size_t)(p - x - (long long)y * W) * CIN;   // image start
+    const uint8_t *rowp = img + (size_t)row * W * CIN;
+    float v[3][6][CIN];                           // rows y-1..y+1, columns x0-1..x0+4
+#pragma unroll
+    for (int r = 0; r < 3; ++r) {
+        const int yy = y + r - 1;
+        const bool yok = yy >= 0 && yy < H;
+#pragma unroll
+        for (int c6 = 0; c6 < 6; ++c6) {
+            const int xx = x0 + c6 - 1;
+            const bool ok = yok && xx >= 0 && xx < W;
+#pragma unroll
+            for (int c = 0; c < CIN; ++c)
+                v[r][c6][c] = ok ? s_lut[rowp[((long long)(r - 1) * W + xx) * CIN + c]] : 0.f;
+        }
+    }
+    float *orow = out + ((size_t)row * W + x0) * ldo + 4 * q;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        if (x0 + i >= W) break;
         f32x4 acc = { 0.f, 0.f, 0.f, 0.f };
 #pragma unroll
-        for (int t = 0; t < 9; ++t) {
-            const int yy = y + t / 3 - 1, xx = x + t % 3 - 1;
-            const bool ok = yy >= 0 && yy < H && xx >= 0 && xx < W;
+        for (int t = 0; t < 9; ++t)               // same tap / channel order as before: bit-identical sums
 #pragma unroll
-            for (int c = 0; c < CIN; ++c) {
-                const float v = ok ? s_lut[base[((size_t)yy * W + xx) * CIN + c]] : 0.f;
-                acc += v * wr[t * CIN + c];
-            }
-        }
+            for (int c = 0; c < CIN; ++c) acc += v[t / 3][i + t % 3][c] * wr[t * CIN + c];
         acc += sh;
         f32x4 r;
         r.x = acc.x > 0.f ? acc.x : 0.f; r.y = acc.y > 0.f ? acc.y : 0.f;
         r.z = acc.z > 0.f ? acc.z : 0.f; r.w = acc.w > 0.f ? acc.w : 0.f;
-        *reinterpret_cast<f32x4 *>(out + (size_t)p * ldo + 4 * q) = r;
+        *reinterpret_cast<f32x4 *>(orow + (size_t)i * ldo) = r;
     }
 }
 
@@ -52,13 +67,13 @@ hipError_t launch_conv3x3_first(const uint8_t *img, const float *lut256, const f
 {
     const int quads = Cout / 4;
     if (Cout % 4 || quads > 256 || 256 % quads || ldo % 4) return hipErrorInvalidValue;
-    const long long npix = (long long)B * H * W;
-    const int ppb = 256 / quads;
-    long long blocks = (npix + ppb - 1) / ppb;
-    if (blocks > 256 * 32) blocks = 256 * 32;
+    const int ppb = 4 * (256 / quads);
+    const int xblocks = (W + ppb - 1) / ppb;
+    const long long blocks = (long long)B * H * xblocks;
+    if (blocks <= 0 || blocks > 0x7FFFFFFFLL) return hipErrorInvalidValue;
     switch (Cin) {
-    case 1: hipLaunchKernelGGL(conv3x3_first_kernel<1>, dim3((unsigned)blocks), dim3(256), 0, s, img, lut256, w, shift, out, B, H, W, Cout, ldo, quads); break;
-    case 3: hipLaunchKernelGGL(conv3x3_first_kernel<3>, dim3((unsigned)blocks), dim3(256), 0, s, img, lut256, w, shift, out, B, H, W, Cout, ldo, quads); break;
+    case 1: hipLaunchKernelGGL(conv3x3_first_kernel<1>, dim3((unsigned)blocks), dim3(256), 0, s, img, lut256, w, shift, out, H, W, Cout, ldo, quads, xblocks); break;
+    case 3: hipLaunchKernelGGL(conv3x3_first_kernel<3>, dim3((unsigned)blocks), dim3(256), 0, s, img, lut256, w, shift, out, H, W, Cout, ldo, quads, xblocks); break;
     default: return hipErrorInvalidValue;
     }
     return hipGetLastError();
