@@ -138,6 +138,40 @@ def test_fused_pooling_is_bit_identical_to_the_pool_kernel(algo, monkeypatch):
     assert np.array_equal(outs[0][0], outs[1][0]) and np.array_equal(outs[0][1], outs[1][1])
 
 
+def test_wino4_fusions_on_small_grids(monkeypatch):
+    """The F(4x4,3x3) kernel normally takes a layer only when its grid fills the chip; MIUNET_WINO4_MIN_WG=1 forces it onto
+    small test images so its own fusions are checked against the stand-alone kernels: pooled maxima from the epilogue
+    (bit-identical: max and +shift/ReLU commute), the 1x1 head + argmax in the last conv's epilogue (same products, a
+    different summation order: logits to 1e-5, labels wherever the top-2 margin exceeds that), the persistent multi-tile
+    walk of the one-block variant (5 x 64 tiles > 256 CUs), and all of it against the oracle."""
+    spec = UNetSpec()
+    blob = pack_weights(spec, synth.make_weights(spec, 78))
+    imgs = synth.make_images(5, 128, 128, 1, 0x2222, "blobs")
+    ref_logits, ref_labels = orc.unet_forward(blob, imgs)
+    monkeypatch.setenv("MIUNET_WINO4_MIN_WG", "1")
+    outs = {}
+    for pool, head in (("1", "1"), ("0", "1"), ("1", "0")):
+        monkeypatch.setenv("MIUNET_FUSE_POOL", pool)
+        monkeypatch.setenv("MIUNET_FUSE_HEAD", head)
+        with binding.Engine(128, 128, max_batch=5) as eng:
+            eng.load_weights(blob)
+            eng.set_profiling(True)
+            labels, logits = eng.infer(imgs, want_logits=True)
+            kernels = [s["kernel"] for s in eng.kernel_stats()]
+        assert ("maxpool2x2" in kernels) == (pool == "0")
+        assert ("head_argmax" in kernels) == (head == "0") and ("conv3x3_wino4+head" in kernels) == (head == "1")
+        assert "conv3x3_wino" not in kernels and "conv3x3_wino4" in kernels
+        check_parity(labels, logits, ref_logits, ref_labels)
+        outs[(pool, head)] = (labels, logits)
+    assert np.array_equal(outs[("1", "1")][1], outs[("0", "1")][1]) and np.array_equal(outs[("1", "1")][0], outs[("0", "1")][0])
+    la, ga = outs[("1", "1")]
+    lb, gb = outs[("1", "0")]
+    assert np.max(np.abs(ga - gb)) < 1e-5
+    srt = np.sort(gb, axis=1)
+    clear = (srt[:, -1] - srt[:, -2]) > 1e-5
+    assert np.array_equal(la[clear], lb[clear])
+
+
 def test_graph_replay_matches_eager(monkeypatch):
     """The forward pass is captured into a hipGraph on the second call of a (buffers, batch) key and replayed afterwards
     (the reference replays a CUDA graph, src/process.cpp:147); results must be bit-identical to eager launches."""

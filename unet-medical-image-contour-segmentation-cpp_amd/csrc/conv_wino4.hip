@@ -67,11 +67,14 @@ struct W4 {
 
 // NB = 16-channel blocks per wave: 2 (workgroup = 128 output channels) or 1 (64 channels, for the Cout = 64 layers: half
 // the MFMA work per transformed tile, but still 1.6x the F(2x2) kernel there).
-template <int NB>
+// HEAD (one-block variant only): the layer feeds the network's 1x1 head; see ConvArgs::head_w.
+template <int NB, bool HEAD>
 __global__ __launch_bounds__(256, 1) void conv3x3_wino4_f32(const ConvArgs a, const int tiles_x, const int tiles_y,
                                                             const int m_tiles, const int nwg)
 {
     constexpr int VROW = W4::VROW, VPOS = W4::VPOS, VBUF = W4::VBUF;
+    constexpr int HEAD_ROW = 64 + 4;          // floats per pixel of the head's LDS tile (conflict-free b128 rows)
+    static_assert(!HEAD || NB == 1, "the fused head needs every channel of a pixel in one workgroup");
     constexpr int UD = NB == 1 ? 9 : 6;       // U prefetch distance in positions (36 % UD == 0); the one-block variant has registers to spare
     extern __shared__ __attribute__((aligned(16))) float lds[];
     float *const Vs = lds;                    // [2][36][16][VROW]
@@ -375,12 +378,16 @@ __global__ __launch_bounds__(256, 1) void conv3x3_wino4_f32(const ConvArgs a, co
                     for (int r = 0; r < 4; ++r) {
                         const float v = fmaxf(y[k][r], relu_lo);
                         y[k][r] = v;
+                        if constexpr (HEAD) {         // pixel (4 kq + i, 4 r + k) of the 16x16 block, channel ncol -> LDS
+                            lds[((4 * kq + i) * 16 + 4 * r + k) * HEAD_ROW + ncol] = v;
+                            continue;
+                        }
                         unsigned voff = vbase;
                         if constexpr (!INTERIOR) voff = row_ok ? vcol[r][k] : 0xFFFFFFFFu;
                         __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), out_rsrc, voff,
                                                               i * row_bytes + (4 * r + k) * pix_bytes, 0);
                     }
-                if (do_pool) {
+                if (!HEAD && do_pool) {
                     f32x4 hm0, hm1;                   // horizontal maxima of this row: pooled columns 2r and 2r + 1
 #pragma unroll
                     for (int r = 0; r < 4; ++r) { hm0[r] = fmaxf(y[0][r], y[1][r]); hm1[r] = fmaxf(y[2][r], y[3][r]); }
@@ -401,8 +408,44 @@ __global__ __launch_bounds__(256, 1) void conv3x3_wino4_f32(const ConvArgs a, co
             }
         }
     };
-    if (e_by0 + 16 <= a.H && e_bx0 + 16 <= a.W) epilogue(std::true_type{});     // workgroup-uniform: no per-pixel predicates
+    if (HEAD || (e_by0 + 16 <= a.H && e_bx0 + 16 <= a.W)) epilogue(std::true_type{});   // workgroup-uniform: no per-pixel predicates
     else epilogue(std::false_type{});
+    if constexpr (HEAD) {
+        // 1x1 head + argmax on the tile: the four waves hold 16 channels each, so the tile crossed LDS above
+        // ([256 pixels][64 + 4 pad], in the V region, which is dead until the next tile's first transform -- behind the
+        // next prologue's barrier); thread = pixel, a fixed summation order, first-max-wins argmax (src/process.cpp:158-170).
+        float *const Wh = lds + 256 * HEAD_ROW;            // [classes][64]
+        if (tid < a.head_classes * 64) Wh[tid] = (tid & 63) < a.Cout ? a.head_w[(tid >> 6) * a.Cout + (tid & 63)] : 0.f;
+        __syncthreads();
+        f32x4 d4[4];                            // four interleaved partial sums per class (packed fma), folded at the end
+#pragma unroll
+        for (int k = 0; k < 4; ++k) d4[k] = f32x4{ 0.f, 0.f, 0.f, 0.f };
+        const float *yrow = lds + tid * HEAD_ROW;
+#pragma unroll
+        for (int c4 = 0; c4 < 16; ++c4) {
+            const f32x4 yv = *reinterpret_cast<const f32x4 *>(yrow + 4 * c4);
+#pragma unroll
+            for (int k = 0; k < 4; ++k)
+                if (k < a.head_classes) d4[k] += yv * *reinterpret_cast<const f32x4 *>(Wh + 64 * k + 4 * c4);
+        }
+        float d[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) d[k] = k < a.head_classes ? ((d4[k].x + d4[k].y) + (d4[k].z + d4[k].w)) + a.head_b[k] : 0.f;
+        const int py = e_by0 + (tid >> 4), px = e_bx0 + (tid & 15);
+        if (py < a.H && px < a.W) {
+            const size_t hw = (size_t)a.H * a.W, pin = (size_t)py * a.W + px;
+            float best = -3.402823466e+38f;
+            int idx = 0;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                if (k < a.head_classes) {
+                    if (a.head_logits != nullptr) a.head_logits[((size_t)e_b * a.head_classes + k) * hw + pin] = d[k];
+                    if (d[k] > best) { best = d[k]; idx = k; }
+                }
+            }
+            a.head_labels[(size_t)e_b * hw + pin] = (uint8_t)idx;
+        }
+    }
     }   // persistent tile loop
 }
 
@@ -418,14 +461,14 @@ static int persistent_cus()
     return cus[dev];
 }
 
-template <int NB>
+template <int NB, bool HEAD>
 static hipError_t launch_wino4_cfg(const ConvArgs &a, hipStream_t s)
 {
     const int tiles_x = (a.W + 15) / 16, tiles_y = (a.H + 15) / 16;
     const int m_tiles = tiles_x * tiles_y * a.B;
     const int n_tiles = (a.Cout + 64 * NB - 1) / (64 * NB);
     const int nwg = m_tiles * n_tiles;
-    auto kern = conv3x3_wino4_f32<NB>;
+    auto kern = conv3x3_wino4_f32<NB, HEAD>;
     if (hipError_t e = ensure_dynamic_lds(kern, W4::LDS_BYTES); e != hipSuccess) return e;
     // one-block variant: persistent, one workgroup per CU (144 KB of LDS each); two-block variant: one tile per workgroup
     const int grid = (NB == 1 && nwg > persistent_cus()) ? persistent_cus() : nwg;
@@ -438,8 +481,13 @@ hipError_t launch_conv3x3_wino4(const ConvArgs &a, hipStream_t s)
     if (a.wpk4 == nullptr || a.Cin % 4 || a.ldc % 4 || a.CoutPad % NPAD) return hipErrorInvalidValue;
     // 128 output channels per workgroup when Cout fills them; 64 for the Cout = 64 layers (and any Cout % 128 in (0, 64])
     const int rem = a.Cout % 128;
-    if (a.Cout >= 128 && (rem == 0 || rem > 64)) return launch_wino4_cfg<2>(a, s);
-    return launch_wino4_cfg<1>(a, s);
+    if (a.head_w != nullptr) {
+        if (a.Cout > 64 || a.head_classes < 1 || a.head_classes > 4 || a.pool_out != nullptr || a.head_labels == nullptr)
+            return hipErrorInvalidValue;
+        return launch_wino4_cfg<1, true>(a, s);
+    }
+    if (a.Cout >= 128 && (rem == 0 || rem > 64)) return launch_wino4_cfg<2, false>(a, s);
+    return launch_wino4_cfg<1, false>(a, s);
 }
 
 }  // namespace miunet

@@ -46,6 +46,7 @@ struct Step {
     int H = 0, W = 0, C = 0, Cout = 0, ld = 0;
     double flops_per_img = 0, bytes_per_img = 0, weight_bytes = 0;
     bool fused_away = false;      // POOL steps whose work is done by the preceding conv's epilogue
+    int head_step = -1;           // CONV: index of the HEAD step this layer feeds (candidate for the fused head), else -1
 };
 
 }  // namespace
@@ -58,6 +59,7 @@ struct mi_unet {
     bool weights_loaded = false;
     int algo = MI_UNET_CONV_DIRECT; // resolved conv3x3 algorithm (MI_UNET_CONV_DIRECT / _WINOGRAD / _WINOGRAD16)
     bool fuse_pool = true;          // MIUNET_FUSE_POOL=0 keeps the stand-alone pooling kernel (A/B and parity checks)
+    int wino4_min_wg = 256;         // MIUNET_WINO4_MIN_WG: smallest grid the F(4x4,3x3) kernel takes (else F(2x2) + split-K)
     // device memory
     float *d_weights = nullptr;     // one blob: every packed tensor (single allocation -> one broadcast / one free)
     size_t weight_floats = 0;
@@ -458,6 +460,15 @@ int build_plan(mi_unet *h, const HostWeights &hw)
     hd.flops_per_img = 2.0 * H * Wd * ch[0] * c.classes;
     hd.bytes_per_img = (double)H * Wd * (4.0 * ch[0] + 1.0);
     h->plan.push_back(hd);
+    // the last conv may run the head in its epilogue (F(4x4) one-block kernel: every channel of a pixel in one workgroup)
+    {
+        const char *fh = getenv("MIUNET_FUSE_HEAD");
+        const int last = (int)h->plan.size() - 1;
+        Step &lc = h->plan[last - 1];
+        if (!(fh && fh[0] == '0') && lc.kind == Step::CONV && lc.a.wpk4 != nullptr && lc.a.Cout <= 64 && c.classes <= 4 &&
+            lc.a.pool_out == nullptr)
+            lc.head_step = last;
+    }
     return 0;
 }
 
@@ -499,8 +510,10 @@ int run_microbatch(mi_unet *h, const uint8_t *d_imgs, int B, uint8_t *d_labels, 
 int launch_plan(mi_unet *h, const uint8_t *d_imgs, int B, uint8_t *d_labels, float *d_logits)
 {
     hipStream_t s = h->stream;
+    bool head_done = false;
     for (Step &st : h->plan) {
         if (st.fused_away) continue;
+        if (st.kind == Step::HEAD && head_done) continue;
         hipEvent_t e0 = nullptr, e1 = nullptr;
         if (h->profiling) {
             while (h->ev_pool.size() < h->ev_used + 2) {
@@ -530,8 +543,18 @@ int launch_plan(mi_unet *h, const uint8_t *d_imgs, int B, uint8_t *d_labels, flo
                 // small grids (single images, deep levels) stay on F(2x2,3x3), which can split K
                 // (MIUNET_SPLITK=0 = batch-invariant mode: no split-K workspace, and the choice must not depend on B either)
                 const long long wg4 = (long long)((a.W + 15) / 16) * ((a.H + 15) / 16) * B * ((a.Cout + 127) / 128);
-                static const int min_wg4 = [] { const char *e = getenv("MIUNET_WINO4_MIN_WG"); return e ? atoi(e) : 256; }();
-                if (a.wpk4 != nullptr && (wg4 >= min_wg4 || h->d_ksplit == nullptr)) { kname = "conv3x3_wino4"; e = launch_conv3x3_wino4(a, s); }
+                const int min_wg4 = h->wino4_min_wg;
+                if (a.wpk4 != nullptr && (wg4 >= min_wg4 || h->d_ksplit == nullptr)) {
+                    kname = "conv3x3_wino4";
+                    if (st.head_step >= 0) {   // fused 1x1 head + argmax: this layer's activations never reach HBM
+                        const Step &hd = h->plan[st.head_step];
+                        a.head_w = hd.w; a.head_b = hd.shift; a.head_classes = hd.Cout;
+                        a.head_logits = d_logits; a.head_labels = d_labels;
+                        head_done = true;
+                        kname = "conv3x3_wino4+head";
+                    }
+                    e = launch_conv3x3_wino4(a, s);
+                }
                 else { kname = "conv3x3_wino"; e = launch_conv3x3_wino(a, s); }
             }
             else { kname = "conv3x3_mfma"; e = launch_conv3x3_mfma(a, s); }
@@ -651,6 +674,7 @@ int mi_unet_create(const mi_unet_config *cfg, mi_unet_t **out)
         h->algo = algo;
         const char *fp = getenv("MIUNET_FUSE_POOL");
         h->fuse_pool = !(fp && !strcmp(fp, "0"));
+        if (const char *mw = getenv("MIUNET_WINO4_MIN_WG")) h->wino4_min_wg = atoi(mw);
         const char *gr = getenv("MIUNET_GRAPH");
         h->use_graph = !(gr && !strcmp(gr, "0"));
     }

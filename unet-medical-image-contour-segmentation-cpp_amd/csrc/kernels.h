@@ -36,6 +36,14 @@ struct ConvArgs {
     float *ksplit_ws;
     size_t ksplit_ws_bytes;
     int ksplit;           // set by the launcher
+    // optional fused 1x1 head + argmax (F(4x4) one-block kernel only, Cout <= 64 so one workgroup holds every channel of
+    // its pixels, no pooling): the post-ReLU tile goes through LDS instead of HBM and `out` is never written.
+    //   head_w [classes][Cout], head_b [classes] (classes <= 4), planar logits [B][classes][H*W] (may be null), u8 labels
+    const float *head_w;
+    const float *head_b;
+    int head_classes;
+    float *head_logits;
+    uint8_t *head_labels;
 };
 
 hipError_t launch_conv3x3_mfma(const ConvArgs &a, hipStream_t s);
