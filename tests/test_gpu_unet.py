@@ -47,9 +47,19 @@ def orc_argmax_batch(logits):
     return np.stack([orc.argmax_planar(l) for l in logits])
 
 
-@pytest.mark.parametrize("algo", ["direct", "winograd", "winograd16"])
+def _algo(algo, monkeypatch):
+    """"wino4" = the default algorithm with the F(4x4,3x3) kernel forced onto every eligible layer whatever its grid size
+    (by default it only takes layers whose grid fills the chip, i.e. none at these test sizes)."""
+    if algo == "wino4":
+        monkeypatch.setenv("MIUNET_WINO4_MIN_WG", "1")
+        return "winograd"
+    return algo
+
+
+@pytest.mark.parametrize("algo", ["direct", "winograd", "winograd16", "wino4"])
 @pytest.mark.parametrize("name", ["unet_b64_l4_64", "unet_b64_l4_48x80", "unet_b16_l3_40x24", "unet_b32_l5_c3_64"])
-def test_against_golden(golden_dir, name, algo):
+def test_against_golden(golden_dir, name, algo, monkeypatch):
+    algo = _algo(algo, monkeypatch)
     spec, blob, imgs, want = load_case(os.path.join(golden_dir, name + ".npz"))
     b, h, w, _ = imgs.shape
     with binding.Engine(h, w, spec.in_ch, spec.base, spec.levels, spec.classes, max_batch=2, conv_algo=algo) as eng:
@@ -59,8 +69,9 @@ def test_against_golden(golden_dir, name, algo):
     assert flips == 0
 
 
-@pytest.mark.parametrize("algo", ["direct", "winograd", "winograd16"])
-def test_against_oracle_128_batch_and_microbatching(algo):
+@pytest.mark.parametrize("algo", ["direct", "winograd", "winograd16", "wino4"])
+def test_against_oracle_128_batch_and_microbatching(algo, monkeypatch):
+    algo = _algo(algo, monkeypatch)
     spec = UNetSpec()
     blob = pack_weights(spec, synth.make_weights(spec, 4321))
     imgs = synth.make_images(5, 128, 128, 1, 0xBEEF, "blobs")
