@@ -269,12 +269,8 @@ __global__ __launch_bounds__(256, 1) void conv3x3_wino4_f32(const ConvArgs a, co
         for (int p = 0; p < 36; ++p) {
             f32x4 avn = av;
             if (p + 1 < 36) avn = *reinterpret_cast<const f32x4 *>(vb + (p + 1) * VPOS);   // V fragment one position ahead
-#ifndef W4_ABL_NO_RAW
             if (p == 0) raw_dma(chunk + 2, chunk & 1);
-#endif
-#ifndef W4_ABL_NO_TRANSFORM
             if (p == 2) piece_load(0, rbuf);
-#endif
             __builtin_amdgcn_sched_barrier(0);        // ... issued BEFORE this position's MFMAs (hipcc would sink them to their use)
             f32x4 bv[NB];
 #pragma unroll
@@ -286,7 +282,6 @@ __global__ __launch_bounds__(256, 1) void conv3x3_wino4_f32(const ConvArgs a, co
                     if (NB == 2 && p >= 32) mfma16_vgpr(acc[p][blk], av[s], bv[blk][s]);
                     else acc[p][blk] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[s], bv[blk][s], acc[p][blk], 0, 0, 0);
                 }
-#ifndef W4_ABL_NO_TRANSFORM
                 if (s == 1) {
                     if (p >= 3 && p < 9) piece_col(p - 3);
                     if (p == 9) piece_prep(0);
@@ -301,13 +296,10 @@ __global__ __launch_bounds__(256, 1) void conv3x3_wino4_f32(const ConvArgs a, co
                     piece_load(p - 2, rbuf);
                     __builtin_amdgcn_sched_barrier(0);
                 }
-#endif
             }
             const int pn = p + UD;                                                              // refill the ring slot
-#ifndef W4_ABL_NO_ULOAD
 #pragma unroll
             for (int blk = 0; blk < NB; ++blk) u[p % UD][blk] = u_load(pn < 36 ? chunk : nxt, pn % 36, blk);
-#endif
             av = avn;
             __builtin_amdgcn_sched_barrier(0);
         }
