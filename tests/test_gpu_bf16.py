@@ -26,6 +26,32 @@ def test_conv3x3_bf16(B, H, W, Cin, Cout):
     assert np.max(np.abs(got - ref)) < 1e-4 * max(1.0, float(np.abs(ref).max()))
 
 
+@pytest.mark.parametrize("op,rnd,ulp", [("conv3x3_bf16", orc.bf16_round, 2.0 ** -8), ("conv3x3_fp16", orc.fp16_round, 2.0 ** -11),
+                                        ("convT2x2_bf16", orc.bf16_round, 2.0 ** -8), ("convT2x2_fp16", orc.fp16_round, 2.0 ** -11)])
+def test_16bit_output_tensors_are_the_rounded_fp32_results(op, rnd, ulp):
+    """Inside the network every activation tensor of the 16-bit pipelines is 16-bit in HBM: the producing kernel rounds its
+    fp32 result once (RNE) -- exactly the rounding its consumer used to apply while staging.  `<op>_lpout` returns that
+    tensor: it must equal round(fp32 result) except where the two fp32 sums (different order) straddle a rounding boundary,
+    and then by one unit in the last place."""
+    r = np.random.default_rng(99)
+    T = op.startswith("convT")
+    x = r.standard_normal((2, 9, 40, 64), dtype=np.float32)          # ragged rows, two column tiles
+    if T:
+        w = (r.standard_normal((64, 64, 2, 2), dtype=np.float32) / 8.0).astype(np.float32)
+        shift = (0.1 * r.standard_normal(64)).astype(np.float32)
+        f32 = binding.layer_debug(op, x, w, None, shift)
+        got = binding.layer_debug(op + "_lpout", x, w, None, shift)
+    else:
+        w = (r.standard_normal((128, 64, 3, 3), dtype=np.float32) * np.sqrt(2.0 / 576)).astype(np.float32)
+        shift = (0.1 * r.standard_normal(128)).astype(np.float32)
+        f32 = binding.layer_debug(op, x, w, None, shift, relu=True)
+        got = binding.layer_debug(op + "_lpout", x, w, None, shift, relu=True)
+    assert not np.isnan(got).any() and got.shape == f32.shape
+    assert np.array_equal(got, rnd(f32))                               # same kernel, same sums: the store only rounds
+    assert np.array_equal(rnd(got), got)                               # values are representable in the 16-bit type
+    assert np.max(np.abs(got - f32)) <= ulp * float(np.abs(f32).max())
+
+
 def test_conv3x3_bf16_exact_on_small_integers():
     r = np.random.default_rng(11)                       # small integers are exact in bf16 and in fp32 sums
     x = r.integers(-4, 5, (1, 10, 36, 32)).astype(np.float32)

@@ -1,4 +1,6 @@
 // conv_lp.hip -- the direct implicit GEMM with 16-bit operands (bf16 / fp16) and fp32 accumulation, gfx950 only.
+#include <type_traits>
+
 #include "kernel_common.h"
 
 namespace miunet {
@@ -7,8 +9,12 @@ namespace miunet {
 // conv_mfma_bf16 -- the same implicit GEMM with bf16 operands and fp32 accumulation (BASELINE config 3).
 // Layout and schedule are those of conv_mfma_f32; what changes:
 //   * a K-chunk is 32 channels; LDS rows hold 32 bf16 + 8 pad = 80 bytes (the same conflict-free stride);
-//   * activations are fp32 in HBM: the loader fetches 2 x 16 bytes per 8 channels and rounds them to bf16
-//     (v_cvt_pk_bf16_f32, round-to-nearest-even) on the way into LDS -- one 16-byte ds_write per 8 channels;
+//   * activations are 16-bit in HBM as well (every tensor but the network's last conv output, which feeds the fp32 head):
+//     the producing kernel rounds its fp32 result once (round-to-nearest-even) instead of every consumer rounding it while
+//     staging -- the same values (rounding commutes with max pooling and is idempotent across the skip connections), half the
+//     HBM and L2 traffic, no conversion VALU in the loader: one 16-byte load and one 16-byte ds_write per 8 channels;
+//   * epilogue: buffer stores on a per-image descriptor (one per-lane byte offset per output-row group, pixel displacement
+//     in the scalar offset) -- 64-bit address arithmetic per store was most of the kernel's instructions at small K;
 //   * v_mfma_f32_32x32x16_bf16 takes A[i][8h + j], j = 0..7 from lane (i, h): exactly one ds_read_b128 per operand per
 //     MFMA, natural k order, 32 cycles per instruction (16x the fp32 rate) -- the kernel is bound by its staging and LDS
 //     traffic and by HBM, not by the matrix pipe.
@@ -33,7 +39,8 @@ __device__ __forceinline__ f32x16 mfma_lp(LpVec<_Float16>::x8 a, LpVec<_Float16>
     return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0);
 }
 
-template <typename T, int TAPS, int TH, int BN, bool NFAST>
+// OUT_LP: the output tensor (and the pooled one) is 16-bit like the input; false = fp32 output (the layer in front of the head)
+template <typename T, int TAPS, int TH, int BN, bool NFAST, bool OUT_LP>
 __global__ __launch_bounds__(256, 2) void conv_mfma_bf16(const ConvArgs a, const int tiles_x, const int tiles_y,
                                                          const int m_tiles, const int nwg)
 {
@@ -63,7 +70,7 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_bf16(const ConvArgs a, const
     const int ty = m % tiles_y;
     const int b = m / tiles_y;
     const int x0 = tx * 32, y0 = ty * TH, n0 = n_tile * BN;
-    const float *in_img = a.in + (size_t)b * a.H * a.W * a.ldc;
+    const T *in_img = reinterpret_cast<const T *>(a.in) + (size_t)b * a.H * a.W * a.ldc;
     const T *wpk = reinterpret_cast<const T *>(a.wpk);
 
     int a_goff[A_ITERS], a_loff[A_ITERS];
@@ -82,19 +89,18 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_bf16(const ConvArgs a, const
     const T *w_base = wpk + ((size_t)n0 + bn) * KC_BF16 + 8 * bq;
     const int b_loff = bn * ROW + 8 * bq;
 
-    f32x4 a_lo[A_ITERS], a_hi[A_ITERS];
+    bf16x8 a_reg[A_ITERS];
     bf16x8 b_reg[B_ITERS];
     auto load_chunk = [&](int chunk) {
         const int c0 = chunk * KC_BF16;
 #pragma unroll
         for (int s = 0; s < A_ITERS; ++s) {
             const int q8 = 8 * ((tid + 256 * s) & 3);
-            f32x4 lo = { 0.f, 0.f, 0.f, 0.f }, hi = { 0.f, 0.f, 0.f, 0.f };
-            if (a_goff[s] >= 0) {
-                if (c0 + q8 < a.Cin) lo = *reinterpret_cast<const f32x4 *>(in_img + a_goff[s] + c0);
-                if (c0 + q8 + 4 < a.Cin) hi = *reinterpret_cast<const f32x4 *>(in_img + a_goff[s] + c0 + 4);
-            }
-            a_lo[s] = lo; a_hi[s] = hi;
+            bf16x8 v;
+#pragma unroll
+            for (int k = 0; k < 8; ++k) v[k] = (T)0.f;
+            if (a_goff[s] >= 0 && c0 + q8 < a.Cin) v = *reinterpret_cast<const bf16x8 *>(in_img + a_goff[s] + c0);
+            a_reg[s] = v;
         }
 #pragma unroll
         for (int it = 0; it < B_ITERS; ++it) {
@@ -105,7 +111,7 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_bf16(const ConvArgs a, const
     auto store_chunk = [&]() {
 #pragma unroll
         for (int s = 0; s < A_ITERS; ++s)
-            if (a_loff[s] >= 0) *reinterpret_cast<bf16x8 *>(As + a_loff[s]) = pack_lp8<T>(a_lo[s], a_hi[s]);
+            if (a_loff[s] >= 0) *reinterpret_cast<bf16x8 *>(As + a_loff[s]) = a_reg[s];
 #pragma unroll
         for (int it = 0; it < B_ITERS; ++it) {
             const int tap = it / B_PARTS, part = it % B_PARTS;
@@ -156,7 +162,30 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_bf16(const ConvArgs a, const
         }
     }
 
-    // ---- epilogue (identical to the fp32 kernel's)
+    // ---- epilogue: + shift, ReLU, (16-bit rounding), buffer stores.  Lane = channel li of block j, register r = pixel
+    // column (r & 3) + 8 (r >> 2) + 4 lh of image row y0 + wave*MT + i.
+    typedef typename std::conditional<OUT_LP, T, float>::type OutT;
+    constexpr unsigned ES = sizeof(OutT);
+    const int OH = (TAPS == 9) ? a.H : 2 * a.H, OW = (TAPS == 9) ? a.W : 2 * a.W;
+    const __amdgpu_buffer_rsrc_t out_rsrc = __builtin_amdgcn_make_buffer_rsrc(
+        reinterpret_cast<OutT *>(a.out) + (size_t)b * OH * OW * a.ldo, 0, (int)((size_t)OH * OW * a.ldo * ES), 0x00020000);
+    const bool do_pool = TAPS == 9 && MT == 2 && a.pool_out != nullptr;
+    const int Hp = a.H >> 1, Wp = a.W >> 1;
+    const __amdgpu_buffer_rsrc_t pool_rsrc = __builtin_amdgcn_make_buffer_rsrc(
+        do_pool ? reinterpret_cast<OutT *>(a.pool_out) + (size_t)b * Hp * Wp * a.pool_ld : reinterpret_cast<OutT *>(a.out), 0,
+        do_pool ? (int)((size_t)Hp * Wp * a.pool_ld * ES) : 0, 0x00020000);
+    const unsigned pix_bytes = (unsigned)a.ldo * ES, ppix_bytes = (unsigned)a.pool_ld * ES;
+    const float relu_lo = a.relu ? 0.f : -3.402823466e+38f;
+    const int yw = y0 + wave * MT;
+    auto store_out = [&](const __amdgpu_buffer_rsrc_t &rs, float v, unsigned voff, unsigned soff) {
+        if constexpr (OUT_LP) {
+            const T t = (T)v;                     // round-to-nearest-even: the rounding the consumer used to do while staging
+            __builtin_amdgcn_raw_buffer_store_b16(__builtin_bit_cast(unsigned short, t), rs, voff, soff, 0);
+        } else {
+            __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), rs, voff, soff, 0);
+        }
+    };
+    const bool interior = x0 + 32 <= a.W && y0 + TH <= a.H;
 #pragma unroll
     for (int j = 0; j < NT; ++j) {
         const int n = n0 + 32 * j + li;
@@ -170,39 +199,35 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_bf16(const ConvArgs a, const
         }
         const bool n_ok = (TAPS == 9) ? (n < a.Cout) : (n < 4 * a.Cout);
         const float sh = n_ok ? a.bias[co] : 0.f;
-        if (TAPS == 9 && MT == 2 && a.pool_out != nullptr) {
-            const int yp = (y0 + wave * MT) >> 1;
+        // per-lane byte offset of (row yw, column x0 + 4 lh) [conv] or of its 2x2 output block's (oy_off, ox_off) pixel [convT]
+        const unsigned vbase = !n_ok ? 0xFFFFFFFFu
+            : (TAPS == 9) ? (unsigned)(((yw * a.W + x0 + 4 * lh) * a.ldo + a.co_off + co) * ES)
+                          : (unsigned)((((2 * yw + oy_off) * OW + 2 * (x0 + 4 * lh) + ox_off) * a.ldo + a.co_off + co) * ES);
+        if (do_pool) {
+            const unsigned pbase = n_ok ? (unsigned)((((yw >> 1) * Wp + ((x0 + 4 * lh) >> 1)) * a.pool_ld + co) * ES) : 0xFFFFFFFFu;
 #pragma unroll
             for (int r = 0; r < 16; r += 2) {
-                const int x = x0 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-                float mx = fmaxf(fmaxf(acc[0][j][r], acc[0][j][r + 1]), fmaxf(acc[MT - 1][j][r], acc[MT - 1][j][r + 1])) + sh;
-                if (a.relu) mx = mx > 0.f ? mx : 0.f;
-                if (n_ok && y0 + wave * MT + 1 < a.H && x + 1 < a.W)
-                    a.pool_out[(((size_t)b * (a.H >> 1) + yp) * (a.W >> 1) + (x >> 1)) * a.pool_ld + co] = mx;
+                const int xr = (r & 3) + 8 * (r >> 2);
+                const float mx = fmaxf(fmaxf(fmaxf(acc[0][j][r], acc[0][j][r + 1]), fmaxf(acc[MT - 1][j][r], acc[MT - 1][j][r + 1])) + sh, relu_lo);
+                const bool ok = interior || (yw + 1 < a.H && x0 + xr + 4 * lh + 1 < a.W);
+                store_out(pool_rsrc, mx, ok ? pbase : 0xFFFFFFFFu, (xr >> 1) * ppix_bytes);
             }
         }
 #pragma unroll
         for (int i = 0; i < MT; ++i) {
-            const int y = y0 + wave * MT + i;
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                const int x = x0 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-                float v = acc[i][j][r] + sh;
-                if (a.relu) v = v > 0.f ? v : 0.f;
-                if (n_ok && y < a.H && x < a.W) {
-                    size_t o;
-                    if (TAPS == 9)
-                        o = (((size_t)b * a.H + y) * a.W + x) * a.ldo + a.co_off + co;
-                    else
-                        o = (((size_t)b * 2 * a.H + 2 * y + oy_off) * (2 * a.W) + 2 * x + ox_off) * a.ldo + a.co_off + co;
-                    a.out[o] = v;
-                }
+                const int xr = (r & 3) + 8 * (r >> 2);
+                const float v = fmaxf(acc[i][j][r] + sh, relu_lo);
+                const bool ok = interior || (yw + i < a.H && x0 + xr + 4 * lh < a.W);
+                const unsigned soff = (TAPS == 9) ? (unsigned)(i * a.W + xr) * pix_bytes : (unsigned)(2 * i * OW + 2 * xr) * pix_bytes;
+                store_out(out_rsrc, v, ok ? vbase : 0xFFFFFFFFu, soff);
             }
         }
     }
 }
 
-template <typename T, int TAPS, int TH, int BN, bool NFAST>
+template <typename T, int TAPS, int TH, int BN, bool NFAST, bool OUT_LP>
 static hipError_t launch_bf16_cfg(const ConvArgs &a, hipStream_t s)
 {
     const int n_total = (TAPS == 9) ? a.Cout : 4 * a.Cout;
@@ -212,7 +237,7 @@ static hipError_t launch_bf16_cfg(const ConvArgs &a, hipStream_t s)
     const int nwg = m_tiles * n_tiles;
     constexpr int HALO = (TAPS == 9) ? 1 : 0;
     constexpr size_t lds = 2 * (size_t)(KC_BF16 + 8) * ((32 + 2 * HALO) * (TH + 2 * HALO) + TAPS * BN);
-    auto kern = conv_mfma_bf16<T, TAPS, TH, BN, NFAST>;
+    auto kern = conv_mfma_bf16<T, TAPS, TH, BN, NFAST, OUT_LP>;
     if (hipError_t e = ensure_dynamic_lds(kern, lds); e != hipSuccess) return e;
     hipLaunchKernelGGL(kern, dim3(nwg), dim3(256), lds, s, a, tiles_x, tiles_y, m_tiles, nwg);
     return hipGetLastError();
@@ -220,26 +245,26 @@ static hipError_t launch_bf16_cfg(const ConvArgs &a, hipStream_t s)
 
 hipError_t launch_conv3x3_bf16(const ConvArgs &a, hipStream_t s)
 {
-    if (a.Cin % 8 || a.ldc % 4 || a.CoutPad % NPAD) return hipErrorInvalidValue;
-    return launch_bf16_cfg<__bf16, 9, 8, 64, false>(a, s);
+    if (a.Cin % 8 || a.ldc % 8 || a.CoutPad % NPAD) return hipErrorInvalidValue;
+    return a.out_lp ? launch_bf16_cfg<__bf16, 9, 8, 64, false, true>(a, s) : launch_bf16_cfg<__bf16, 9, 8, 64, false, false>(a, s);
 }
 
 hipError_t launch_convT2x2_bf16(const ConvArgs &a, hipStream_t s)
 {
-    if (a.Cin % 8 || a.ldc % 4 || a.CoutPad % NPAD) return hipErrorInvalidValue;
-    return launch_bf16_cfg<__bf16, 1, 8, 64, true>(a, s);
+    if (a.Cin % 8 || a.ldc % 8 || a.CoutPad % NPAD) return hipErrorInvalidValue;
+    return a.out_lp ? launch_bf16_cfg<__bf16, 1, 8, 64, true, true>(a, s) : launch_bf16_cfg<__bf16, 1, 8, 64, true, false>(a, s);
 }
 
 hipError_t launch_conv3x3_fp16(const ConvArgs &a, hipStream_t s)
 {
-    if (a.Cin % 8 || a.ldc % 4 || a.CoutPad % NPAD) return hipErrorInvalidValue;
-    return launch_bf16_cfg<_Float16, 9, 8, 64, false>(a, s);
+    if (a.Cin % 8 || a.ldc % 8 || a.CoutPad % NPAD) return hipErrorInvalidValue;
+    return a.out_lp ? launch_bf16_cfg<_Float16, 9, 8, 64, false, true>(a, s) : launch_bf16_cfg<_Float16, 9, 8, 64, false, false>(a, s);
 }
 
 hipError_t launch_convT2x2_fp16(const ConvArgs &a, hipStream_t s)
 {
-    if (a.Cin % 8 || a.ldc % 4 || a.CoutPad % NPAD) return hipErrorInvalidValue;
-    return launch_bf16_cfg<_Float16, 1, 8, 64, true>(a, s);
+    if (a.Cin % 8 || a.ldc % 8 || a.CoutPad % NPAD) return hipErrorInvalidValue;
+    return a.out_lp ? launch_bf16_cfg<_Float16, 1, 8, 64, true, true>(a, s) : launch_bf16_cfg<_Float16, 1, 8, 64, true, false>(a, s);
 }
 
 

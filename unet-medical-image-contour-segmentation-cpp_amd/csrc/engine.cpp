@@ -47,6 +47,7 @@ struct Step {
     double flops_per_img = 0, bytes_per_img = 0, weight_bytes = 0;
     bool fused_away = false;      // POOL steps whose work is done by the preceding conv's epilogue
     int head_step = -1;           // CONV: index of the HEAD step this layer feeds (candidate for the fused head), else -1
+    bool feeds_head = false;      // CONV: its output is the fp32 head's input (stays fp32 in the 16-bit pipelines)
 };
 
 }  // namespace
@@ -205,6 +206,33 @@ uint16_t fp16_bits(float x)
 }
 
 typedef uint16_t (*lp_cvt_fn)(float);
+
+float bf16_to_float(uint16_t b)
+{
+    const uint32_t u = (uint32_t)b << 16;
+    float f;
+    memcpy(&f, &u, 4);
+    return f;
+}
+
+float fp16_to_float(uint16_t h)
+{
+    const uint32_t sign = (uint32_t)(h & 0x8000u) << 16, exp = (h >> 10) & 0x1Fu, man = h & 0x3FFu;
+    uint32_t u;
+    if (exp == 0) {
+        if (man == 0) u = sign;
+        else {                                              // subnormal: renormalise
+            int e = -1;
+            uint32_t m = man;
+            do { ++e; m <<= 1; } while (!(m & 0x400u));
+            u = sign | ((uint32_t)(127 - 15 - e) << 23) | ((m & 0x3FFu) << 13);
+        }
+    } else if (exp == 31) u = sign | 0x7F800000u | (man << 13);
+    else u = sign | ((exp + 127 - 15) << 23) | (man << 13);
+    float f;
+    memcpy(&f, &u, 4);
+    return f;
+}
 
 // conv3x3 (PyTorch [Cout][Cin][3][3], per-channel scale) -> 16-bit [Cin/32][9][CoutPad][32]; dst counts uint16 elements
 void pack_conv_bf16(const float *w, const double *scale, int cin, int cout, uint16_t *dst, size_t cpad, lp_cvt_fn cvt = nullptr)
@@ -465,6 +493,7 @@ int build_plan(mi_unet *h, const HostWeights &hw)
         const char *fh = getenv("MIUNET_FUSE_HEAD");
         const int last = (int)h->plan.size() - 1;
         Step &lc = h->plan[last - 1];
+        if (lc.kind == Step::CONV) lc.feeds_head = true;
         if (!(fh && fh[0] == '0') && lc.kind == Step::CONV && lc.a.wpk4 != nullptr && lc.a.Cout <= 64 && c.classes <= 4 &&
             lc.a.pool_out == nullptr)
             lc.head_step = last;
@@ -510,6 +539,8 @@ int run_microbatch(mi_unet *h, const uint8_t *d_imgs, int B, uint8_t *d_labels, 
 int launch_plan(mi_unet *h, const uint8_t *d_imgs, int B, uint8_t *d_labels, float *d_logits)
 {
     hipStream_t s = h->stream;
+    // 16-bit pipelines: every activation tensor is bf16 / fp16 in HBM except the last conv's output (the fp32 head's input)
+    const int lp_kind = h->algo == MI_UNET_CONV_BF16 ? 1 : h->algo == MI_UNET_CONV_FP16 ? 2 : 0;
     bool head_done = false;
     for (Step &st : h->plan) {
         if (st.fused_away) continue;
@@ -530,11 +561,12 @@ int launch_plan(mi_unet *h, const uint8_t *d_imgs, int B, uint8_t *d_labels, flo
         switch (st.kind) {
         case Step::FIRST:
             kname = "conv3x3_first";
-            e = launch_conv3x3_first(d_imgs, h->d_lut, st.w, st.shift, st.dst, B, st.H, st.W, st.C, st.Cout, st.ld, s);
+            e = launch_conv3x3_first(d_imgs, h->d_lut, st.w, st.shift, st.dst, B, st.H, st.W, st.C, st.Cout, st.ld, lp_kind, s);
             break;
         case Step::CONV: {
             ConvArgs a = st.a; a.B = B;
             a.ksplit_ws = h->d_ksplit; a.ksplit_ws_bytes = h->ksplit_bytes;
+            a.out_lp = (lp_kind != 0 && !st.feeds_head) ? 1 : 0;
             if (h->algo == MI_UNET_CONV_BF16) { kname = "conv3x3_bf16"; e = launch_conv3x3_bf16(a, s); }
             else if (h->algo == MI_UNET_CONV_FP16) { kname = "conv3x3_fp16"; e = launch_conv3x3_fp16(a, s); }
             else if (h->algo == MI_UNET_CONV_WINOGRAD16) { kname = "conv3x3_wino16"; e = launch_conv3x3_wino16(a, s); }
@@ -562,6 +594,7 @@ int launch_plan(mi_unet *h, const uint8_t *d_imgs, int B, uint8_t *d_labels, flo
         }
         case Step::CONVT: {
             ConvArgs a = st.a; a.B = B;
+            a.out_lp = lp_kind != 0 ? 1 : 0;
             if (h->algo == MI_UNET_CONV_BF16) { kname = "convT2x2_bf16"; e = launch_convT2x2_bf16(a, s); }
             else if (h->algo == MI_UNET_CONV_FP16) { kname = "convT2x2_fp16"; e = launch_convT2x2_fp16(a, s); }
             else if (a.wpk4 != nullptr) { kname = "convT2x2_taps"; e = launch_convT2x2_taps(a, s); }
@@ -570,7 +603,8 @@ int launch_plan(mi_unet *h, const uint8_t *d_imgs, int B, uint8_t *d_labels, flo
         }
         case Step::POOL:
             kname = "maxpool2x2";
-            e = launch_maxpool2x2(st.src, st.ld, st.dst, B, st.H, st.W, st.C, s);
+            e = lp_kind ? launch_maxpool2x2_u16(st.src, st.ld, st.dst, B, st.H, st.W, st.C, s)
+                        : launch_maxpool2x2(st.src, st.ld, st.dst, B, st.H, st.W, st.C, s);
             break;
         case Step::HEAD:
             kname = "head_argmax";
@@ -584,7 +618,8 @@ int launch_plan(mi_unet *h, const uint8_t *d_imgs, int B, uint8_t *d_labels, flo
             snprintf(ks.name, sizeof ks.name, "%s", st.name.c_str());
             snprintf(ks.kernel, sizeof ks.kernel, "%s", kname);
             ks.flops = st.flops_per_img * B;
-            ks.bytes = st.bytes_per_img * B + st.weight_bytes;
+            // algorithmic bytes: the 16-bit pipelines move half of them (activations and weights are 2 bytes)
+            ks.bytes = (st.bytes_per_img * B + st.weight_bytes) * ((lp_kind && (st.kind == Step::CONV || st.kind == Step::CONVT)) ? 0.5 : 1.0);
             ks.ms = -1.f;                      // filled by mi_unet_get_kernel_stats
             h->stats.push_back(ks);
         }
@@ -1009,7 +1044,9 @@ int mi_unet_layer_debug(int device, const char *op, const float *in, int B, int 
     if (!op || !in || !out || B <= 0 || H <= 0 || W <= 0 || Cin <= 0) return fail(MI_UNET_EARG, "layer_debug: bad argument");
     if (mi_unet_device_count() <= 0) return fail(MI_UNET_ENODEVICE, "no HIP device visible: libmiunet has no CPU fallback");
     HIP_TRY(hipSetDevice(device));
-    const std::string o(op);
+    std::string o(op);
+    bool lp_out = false;
+    if (o.size() > 6 && o.compare(o.size() - 6, 6, "_lpout") == 0) { lp_out = true; o.resize(o.size() - 6); }
     const size_t in_n = (size_t)B * H * W * Cin;
     float *d_in = nullptr, *d_out = nullptr, *d_w = nullptr, *d_b = nullptr;
     std::vector<float> wpk, bias;
@@ -1094,12 +1131,23 @@ int mi_unet_layer_debug(int device, const char *op, const float *in, int B, int 
     } else {
         return fail(MI_UNET_EARG, "layer_debug: unknown op " + o);
     }
+    const bool lp_in = (o == "conv3x3_bf16" || o == "convT2x2_bf16" || o == "conv3x3_fp16" || o == "convT2x2_fp16");
+    const bool lp_fp16 = (o == "conv3x3_fp16" || o == "convT2x2_fp16");
+    if (lp_out && !lp_in) return fail(MI_UNET_EARG, "layer_debug: _lpout is for the 16-bit conv ops");
+    a.out_lp = lp_out ? 1 : 0;
     int rc = MI_UNET_OK;
     hipError_t e = hipSuccess;
 #define DBG_TRY(expr) do { e = (expr); if (e != hipSuccess) { rc = fail(MI_UNET_EHIP, std::string(#expr) + ": " + hipGetErrorString(e)); goto done; } } while (0)
     DBG_TRY(hipMalloc(&d_in, sizeof(float) * in_n));
     DBG_TRY(hipMalloc(&d_out, sizeof(float) * out_n));
-    DBG_TRY(hipMemcpy(d_in, in, sizeof(float) * in_n, hipMemcpyHostToDevice));
+    if (lp_in) {                                                 // the 16-bit kernels read 16-bit activations: round here (RNE)
+        std::vector<uint16_t> in16(in_n);
+        const lp_cvt_fn cvt = lp_fp16 ? fp16_bits : bf16_bits;
+        for (size_t i = 0; i < in_n; ++i) in16[i] = cvt(in[i]);
+        DBG_TRY(hipMemcpy(d_in, in16.data(), sizeof(uint16_t) * in_n, hipMemcpyHostToDevice));
+    } else {
+        DBG_TRY(hipMemcpy(d_in, in, sizeof(float) * in_n, hipMemcpyHostToDevice));
+    }
     DBG_TRY(hipMemset(d_out, 0xFF, sizeof(float) * out_n));      // NaN poison: unwritten outputs are visible
     if (!wpk.empty()) {
         DBG_TRY(hipMalloc(&d_w, sizeof(float) * wpk.size()));
@@ -1121,7 +1169,13 @@ int mi_unet_layer_debug(int device, const char *op, const float *in, int B, int 
         DBG_TRY(launch_maxpool2x2(d_in, Cin, d_out, B, H, W, Cin, nullptr));
     }
     DBG_TRY(hipDeviceSynchronize());
-    DBG_TRY(hipMemcpy(out, d_out, sizeof(float) * out_n, hipMemcpyDeviceToHost));
+    if (lp_out) {
+        std::vector<uint16_t> out16(out_n);
+        DBG_TRY(hipMemcpy(out16.data(), d_out, sizeof(uint16_t) * out_n, hipMemcpyDeviceToHost));
+        for (size_t i = 0; i < out_n; ++i) out[i] = lp_fp16 ? fp16_to_float(out16[i]) : bf16_to_float(out16[i]);
+    } else {
+        DBG_TRY(hipMemcpy(out, d_out, sizeof(float) * out_n, hipMemcpyDeviceToHost));
+    }
 #undef DBG_TRY
 done:
     if (d_in) (void)hipFree(d_in);

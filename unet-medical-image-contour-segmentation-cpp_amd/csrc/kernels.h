@@ -39,6 +39,9 @@ struct ConvArgs {
     // optional fused 1x1 head + argmax (F(4x4) one-block kernel only, Cout <= 64 so one workgroup holds every channel of
     // its pixels, no pooling): the post-ReLU tile goes through LDS instead of HBM and `out` is never written.
     //   head_w [classes][Cout], head_b [classes] (classes <= 4), planar logits [B][classes][H*W] (may be null), u8 labels
+    // 16-bit kernels (conv_lp.hip): `in` always points at 16-bit activations (bf16 / fp16, NHWC, ldc in elements); out_lp
+    // selects a 16-bit `out` / `pool_out` (everything but the layer in front of the fp32 head)
+    int out_lp;
     const float *head_w;
     const float *head_b;
     int head_classes;
@@ -67,8 +70,8 @@ hipError_t launch_convT2x2_mfma(const ConvArgs &a, hipStream_t s);
 inline int convT_taps_cpad(int cout) { return (cout + NPAD - 1) / NPAD * NPAD; }
 hipError_t launch_convT2x2_taps(const ConvArgs &a, hipStream_t s);
 
-// BASELINE config 3: bf16 operands, fp32 accumulate on v_mfma_f32_32x32x16_bf16.  Activations stay fp32 in HBM and are
-// rounded to bf16 (RNE) while they are staged into LDS; a.wpk holds bf16 weights packed [Cin/32][taps][CoutPad][32].
+// BASELINE config 3: bf16 operands, fp32 accumulate on v_mfma_f32_32x32x16_bf16.  Activations are bf16 in HBM too (rounded
+// once, RNE, by the kernel that produces them); a.wpk holds bf16 weights packed [Cin/32][taps][CoutPad][32].
 constexpr int KC_BF16 = 32;
 hipError_t launch_conv3x3_bf16(const ConvArgs &a, hipStream_t s);
 hipError_t launch_convT2x2_bf16(const ConvArgs &a, hipStream_t s);
@@ -77,11 +80,14 @@ hipError_t launch_conv3x3_fp16(const ConvArgs &a, hipStream_t s);
 hipError_t launch_convT2x2_fp16(const ConvArgs &a, hipStream_t s);
 
 // First layer: u8 image -> (LUT /255) -> conv3x3 (Cin = 1..4) + shift + ReLU.  w is [9][Cin][Cout] (BN scale folded).
+// out_kind: 0 = fp32 output, 1 = bf16, 2 = fp16 (the 16-bit pipelines keep every activation tensor 16-bit in HBM)
 hipError_t launch_conv3x3_first(const uint8_t *img, const float *lut256, const float *w, const float *shift, float *out,
-                                int B, int H, int W, int Cin, int Cout, int ldo, hipStream_t s);
+                                int B, int H, int W, int Cin, int Cout, int ldo, int out_kind, hipStream_t s);
 // Same arithmetic on an fp32 NHWC input (layer_debug / small-Cin fallback is not needed elsewhere).
 
 hipError_t launch_maxpool2x2(const float *in, int ldc, float *out, int B, int H, int W, int C, hipStream_t s);
+// the same on 16-bit post-ReLU tensors (bf16 or fp16: non-negative values order like their bit patterns)
+hipError_t launch_maxpool2x2_u16(const void *in, int ldc, void *out, int B, int H, int W, int C, hipStream_t s);
 
 // 1x1 head + first-max-wins argmax: in [npix][Cin] -> planar logits [B][classes][H*W] (may be null) + u8 labels.
 hipError_t launch_head_argmax(const float *in, int Cin, const float *w, const float *bias, int classes, float *logits,

@@ -9,10 +9,11 @@ namespace miunet {
 // bytes it needs are loaded and looked up once for all four (4.5 loads per pixel instead of 9) and there is no per-pixel
 // index arithmetic; the Cout/4 threads of a pixel write one contiguous NHWC row (256 bytes at Cout = 64).  u8 -> fp32
 // through the host-built 256-entry table so the input equals float(x)/255.0f bit for bit (src/process.cpp:36-39).
-template <int CIN>
+// OT = float, or __bf16 / _Float16 for the 16-bit pipelines (the tensor is then rounded here, once, instead of by its consumer)
+template <int CIN, typename OT>
 __global__ __launch_bounds__(256) void conv3x3_first_kernel(const uint8_t *__restrict__ img, const float *__restrict__ lut,
                                                             const float *__restrict__ w, const float *__restrict__ shift,
-                                                            float *__restrict__ out, int H, int W, int Cout, int ldo,
+                                                            OT *__restrict__ out, int H, int W, int Cout, int ldo,
                                                             int quads, int xblocks)
 {
     __shared__ float s_lut[256];
@@ -45,7 +46,7 @@ __global__ __launch_bounds__(256) void conv3x3_first_kernel(const uint8_t *__res
                 v[r][c6][c] = ok ? s_lut[rowp[((long long)(r - 1) * W + xx) * CIN + c]] : 0.f;
         }
     }
-    float *orow = out + ((size_t)row * W + x0) * ldo + 4 * q;
+    OT *orow = out + ((size_t)row * W + x0) * ldo + 4 * q;
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
         if (x0 + i >= W) break;
@@ -58,12 +59,20 @@ __global__ __launch_bounds__(256) void conv3x3_first_kernel(const uint8_t *__res
         f32x4 r;
         r.x = acc.x > 0.f ? acc.x : 0.f; r.y = acc.y > 0.f ? acc.y : 0.f;
         r.z = acc.z > 0.f ? acc.z : 0.f; r.w = acc.w > 0.f ? acc.w : 0.f;
-        *reinterpret_cast<f32x4 *>(orow + (size_t)i * ldo) = r;
+        if constexpr (sizeof(OT) == 4) {
+            *reinterpret_cast<f32x4 *>(orow + (size_t)i * ldo) = r;
+        } else {
+            typedef OT ot4 __attribute__((ext_vector_type(4)));
+            ot4 t;
+            t[0] = (OT)r.x; t[1] = (OT)r.y; t[2] = (OT)r.z; t[3] = (OT)r.w;
+            *reinterpret_cast<ot4 *>(orow + (size_t)i * ldo) = t;
+        }
     }
 }
 
-hipError_t launch_conv3x3_first(const uint8_t *img, const float *lut256, const float *w, const float *shift, float *out,
-                                int B, int H, int W, int Cin, int Cout, int ldo, hipStream_t s)
+template <typename OT>
+static hipError_t launch_first_t(const uint8_t *img, const float *lut256, const float *w, const float *shift, OT *out,
+                                 int B, int H, int W, int Cin, int Cout, int ldo, hipStream_t s)
 {
     const int quads = Cout / 4;
     if (Cout % 4 || quads > 256 || 256 % quads || ldo % 4) return hipErrorInvalidValue;
@@ -72,11 +81,20 @@ hipError_t launch_conv3x3_first(const uint8_t *img, const float *lut256, const f
     const long long blocks = (long long)B * H * xblocks;
     if (blocks <= 0 || blocks > 0x7FFFFFFFLL) return hipErrorInvalidValue;
     switch (Cin) {
-    case 1: hipLaunchKernelGGL(conv3x3_first_kernel<1>, dim3((unsigned)blocks), dim3(256), 0, s, img, lut256, w, shift, out, H, W, Cout, ldo, quads, xblocks); break;
-    case 3: hipLaunchKernelGGL(conv3x3_first_kernel<3>, dim3((unsigned)blocks), dim3(256), 0, s, img, lut256, w, shift, out, H, W, Cout, ldo, quads, xblocks); break;
+    case 1: hipLaunchKernelGGL((conv3x3_first_kernel<1, OT>), dim3((unsigned)blocks), dim3(256), 0, s, img, lut256, w, shift, out, H, W, Cout, ldo, quads, xblocks); break;
+    case 3: hipLaunchKernelGGL((conv3x3_first_kernel<3, OT>), dim3((unsigned)blocks), dim3(256), 0, s, img, lut256, w, shift, out, H, W, Cout, ldo, quads, xblocks); break;
     default: return hipErrorInvalidValue;
     }
     return hipGetLastError();
+}
+
+// out_kind: 0 = fp32, 1 = bf16, 2 = fp16 output tensor
+hipError_t launch_conv3x3_first(const uint8_t *img, const float *lut256, const float *w, const float *shift, float *out,
+                                int B, int H, int W, int Cin, int Cout, int ldo, int out_kind, hipStream_t s)
+{
+    if (out_kind == 1) return launch_first_t(img, lut256, w, shift, reinterpret_cast<__bf16 *>(out), B, H, W, Cin, Cout, ldo, s);
+    if (out_kind == 2) return launch_first_t(img, lut256, w, shift, reinterpret_cast<_Float16 *>(out), B, H, W, Cin, Cout, ldo, s);
+    return launch_first_t(img, lut256, w, shift, out, B, H, W, Cin, Cout, ldo, s);
 }
 
 // --------------------------------------------------------------------------------------------------------------------
@@ -106,6 +124,46 @@ __global__ __launch_bounds__(256) void maxpool2x2_kernel(const float *__restrict
         }
         *reinterpret_cast<f32x4 *>(out + (size_t)p * (4 * C4) + 4 * c4) = m;
     }
+}
+
+// The 16-bit pipelines pool post-ReLU tensors: non-negative bf16 / fp16 values order like their bit patterns, so the
+// maximum is an integer maximum on 16-bit lanes (8 channels = 16 bytes per thread).
+__global__ __launch_bounds__(256) void maxpool2x2_u16_kernel(const uint16_t *__restrict__ in, int ldc, uint16_t *__restrict__ out,
+                                                             int Ho, int Wo, int C8, long long total)
+{
+    typedef unsigned short u16x8 __attribute__((ext_vector_type(8)));
+    const int W = 2 * Wo;
+    for (long long e = (long long)blockIdx.x * 256 + threadIdx.x; e < total; e += (long long)gridDim.x * 256) {
+        const int c8 = (int)(e % C8);
+        const long long p = e / C8;
+        const int xo = (int)(p % Wo);
+        const long long by = p / Wo;
+        const uint16_t *src = in + ((size_t)(2 * by) * W + 2 * xo) * ldc + 8 * c8;
+        const u16x8 v00 = *reinterpret_cast<const u16x8 *>(src), v01 = *reinterpret_cast<const u16x8 *>(src + ldc);
+        const u16x8 v10 = *reinterpret_cast<const u16x8 *>(src + (size_t)W * ldc), v11 = *reinterpret_cast<const u16x8 *>(src + (size_t)W * ldc + ldc);
+        u16x8 m;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            unsigned short t = v00[k];
+            t = v01[k] > t ? v01[k] : t;
+            t = v10[k] > t ? v10[k] : t;
+            t = v11[k] > t ? v11[k] : t;
+            m[k] = t;
+        }
+        *reinterpret_cast<u16x8 *>(out + (size_t)p * (8 * C8) + 8 * c8) = m;
+    }
+}
+
+hipError_t launch_maxpool2x2_u16(const void *in, int ldc, void *out, int B, int H, int W, int C, hipStream_t s)
+{
+    if (C % 8 || ldc % 8 || H % 2 || W % 2) return hipErrorInvalidValue;
+    const int Ho = H / 2, Wo = W / 2, C8 = C / 8;
+    const long long total = (long long)B * Ho * Wo * C8;
+    long long blocks = (total + 255) / 256;
+    if (blocks > 256 * 16) blocks = 256 * 16;
+    hipLaunchKernelGGL(maxpool2x2_u16_kernel, dim3((unsigned)blocks), dim3(256), 0, s, static_cast<const uint16_t *>(in), ldc,
+                       static_cast<uint16_t *>(out), Ho, Wo, C8, total);
+    return hipGetLastError();
 }
 
 hipError_t launch_maxpool2x2(const float *in, int ldc, float *out, int B, int H, int W, int C, hipStream_t s)

@@ -234,6 +234,9 @@ def layer_debug(op, x, w=None, scale=None, shift=None, relu=False, device=0):
     x = np.ascontiguousarray(x, np.float32)
     b, h, ww, cin = x.shape
     cout = 0
+    full_op = op
+    if op.endswith("_lpout"):         # 16-bit conv ops: the output tensor is 16-bit on the device too (converted back here)
+        op = op[:-6]
     if op in ("conv3x3", "conv3x3_wino", "conv3x3_wino16", "conv3x3_wino4", "conv3x3_bf16", "conv3x3_fp16"):
         w = np.ascontiguousarray(w, np.float32)
         cout = w.shape[0]
@@ -248,6 +251,6 @@ def layer_debug(op, x, w=None, scale=None, shift=None, relu=False, device=0):
         raise ValueError(op)
     scale = None if scale is None else np.ascontiguousarray(scale, np.float32)
     shift = None if shift is None else np.ascontiguousarray(shift, np.float32)
-    _check(lib().mi_unet_layer_debug(device, op.encode(), _ptr(x), b, h, ww, cin, _ptr(w), _ptr(scale), _ptr(shift), cout,
+    _check(lib().mi_unet_layer_debug(device, full_op.encode(), _ptr(x), b, h, ww, cin, _ptr(w), _ptr(scale), _ptr(shift), cout,
                                      int(relu), _ptr(out)))
     return out
