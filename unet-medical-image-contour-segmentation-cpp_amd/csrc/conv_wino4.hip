@@ -116,6 +116,13 @@ __global__ __launch_bounds__(256, 1) void conv3x3_wino4_f32(const ConvArgs a, co
         }
     };
     typedef __attribute__((address_space(3))) void *lds_ptr;
+    auto raw_dma_one = [&](int chunk, int buf, int s) {        // the wave's s-th load of a chunk's patch
+        const int c0 = chunk * WINO4_KC;
+        const bool c_ok = c0 + 4 * (lane & 3) < a.Cin;
+        if (wave + 4 * s < W4::RAW_LOADS)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(in_rsrc, (lds_ptr)(Raw + buf * W4::RAW_FLOATS + (wave + 4 * s) * 16 * WINO4_KC), 16,
+                                                     c_ok ? raw_voff[s] : 0xFFFFFFFFu, c0 * 4, 0, 0);
+    };
     auto raw_dma = [&](int chunk, int buf) {   // global -> LDS directly: no registers, no ds_write; completion = vmcnt
         const int c0 = chunk * WINO4_KC;
         const bool c_ok = c0 + 4 * (lane & 3) < a.Cin;
@@ -269,7 +276,9 @@ __global__ __launch_bounds__(256, 1) void conv3x3_wino4_f32(const ConvArgs a, co
         for (int p = 0; p < 36; ++p) {
             f32x4 avn = av;
             if (p + 1 < 36) avn = *reinterpret_cast<const f32x4 *>(vb + (p + 1) * VPOS);   // V fragment one position ahead
-            if (p == 0) raw_dma(chunk + 2, chunk & 1);
+            // one load every fourth position, not a burst: 16 line misses at a time keep the VMEM queue moving, so the U loads
+            // issued behind each of them are delayed by less than the U ring covers
+            if (p % 4 == 0 && p / 4 < W4::RAW_ITERS) raw_dma_one(chunk + 2, chunk & 1, p / 4);
             if (p == 2) piece_load(0, rbuf);
             __builtin_amdgcn_sched_barrier(0);        // ... issued BEFORE this position's MFMAs (hipcc would sink them to their use)
             f32x4 bv[NB];
