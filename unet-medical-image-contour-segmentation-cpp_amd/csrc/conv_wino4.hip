@@ -254,11 +254,19 @@ __global__ __launch_bounds__(256, 1) void conv3x3_wino4_f32(const ConvArgs a, co
 #pragma unroll
             for (int r = 0; r < 4; ++r) acc[p][blk][r] = init;
         }
-    // prologue: the raw patches of chunks 0 and 1 are landing in LDS (and, in the persistent variant, the previous tile's
-    // stores are draining): vmcnt(0), barrier, V of chunk 0
-    __builtin_amdgcn_s_waitcnt(0x0F70);       // vmcnt(0), expcnt / lgkmcnt untouched
+    // prologue: the raw patches of chunks 0 and 1 are landing in LDS.  Issue order was chunk 0, chunk 1, U ring, so the
+    // first transform only waits for chunk 0 (everything older than the RAW_ITERS + NB*UD youngest loads) and chunk 1 lands
+    // under it.  The persistent variant also has the previous tile's stores in the queue (issued after those loads, vmcnt
+    // does not order stores against loads): it waits for everything.
+    if constexpr (PERSIST) {
+        __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0), expcnt / lgkmcnt untouched
+    } else {
+        constexpr int N1 = W4::RAW_ITERS - 1 + NB * UD;      // wave 3 issues one load fewer per chunk: be exact for it
+        __builtin_amdgcn_s_waitcnt(0x0F70 | (N1 & 15) | ((N1 >> 4) << 14));
+    }
     __syncthreads();
     transform_all(0, 0);
+    if constexpr (!PERSIST) __builtin_amdgcn_s_waitcnt(0x0F70 | ((NB * UD) & 15) | (((NB * UD) >> 4) << 14));
     __syncthreads();
 
     // Per chunk c, around its 288 MFMAs (one barrier per chunk):
