@@ -380,17 +380,47 @@ __global__ __launch_bounds__(64) void k_sort_roots(int *roots, const int *counts
 
 // one lane per (image, contour): follow the border from its start pixel, emit CHAIN_APPROX_SIMPLE points.
 // pass 0 counts points (npts), pass 1 writes them at the offsets computed in between.
-__global__ __launch_bounds__(64) void k_trace(const uint8_t *__restrict__ fg, const int *__restrict__ roots,
-                                              const int *__restrict__ counts, int cap, int H, int W, int B, int *npts,
-                                              const int *__restrict__ offs, int *out_xy, int cap_points, int write)
+// The walk is a chain of dependent pixel probes (2-8 per border step), so the probe latency IS the kernel time: a workgroup
+// = one image first packs the thresholded mask into an LDS bit plane (H*W/8 bytes: 32 KB at 512x512; images past the LDS
+// budget keep probing global memory), then the lanes that own a contour walk it at LDS latency.
+template <bool IN_LDS>
+__global__ __launch_bounds__(256) void k_trace(const uint8_t *__restrict__ fg, const int *__restrict__ roots,
+                                               const int *__restrict__ counts, int cap, int H, int W, int B, int *npts,
+                                               const int *__restrict__ offs, int *out_xy, int cap_points, int write)
 {
-    const int t = blockIdx.x * 64 + threadIdx.x;
-    const int img = t / cap, c = t - img * cap;
-    if (img >= B || c >= counts[img] || counts[img] > cap) return;
+    extern __shared__ unsigned bits[];
+    const int img = blockIdx.x;
     const uint8_t *im = fg + (size_t)img * H * W;
-    auto at = [&](int x, int y) -> bool { return x >= 0 && x < W && y >= 0 && y < H && im[(size_t)y * W + x] != 0; };
+    const int nc = counts[img];
+    if (nc <= 0 || nc > cap) return;                             // workgroup-uniform
+    if constexpr (IN_LDS) {
+        const int nwords = (H * W + 31) >> 5;
+        for (int w = threadIdx.x; w < nwords; w += 256) {
+            unsigned m = 0;
+            const int base = w << 5;
+            if (base + 32 <= H * W && (((uintptr_t)(im + base)) & 15) == 0) {
+                const uint4 q0 = *reinterpret_cast<const uint4 *>(im + base), q1 = *reinterpret_cast<const uint4 *>(im + base + 16);
+                const unsigned ws[8] = { q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, q1.z, q1.w };
+#pragma unroll
+                for (int k = 0; k < 8; ++k)
+#pragma unroll
+                    for (int b4 = 0; b4 < 4; ++b4) m |= (((ws[k] >> (8 * b4)) & 0xFFu) != 0 ? 1u : 0u) << (4 * k + b4);
+            } else {
+                for (int k = 0; k < 32 && base + k < H * W; ++k) m |= (im[base + k] != 0 ? 1u : 0u) << k;
+            }
+            bits[w] = m;
+        }
+        __syncthreads();
+    }
+    auto at = [&](int x, int y) -> bool {
+        if (x < 0 || x >= W || y < 0 || y >= H) return false;
+        const int p = y * W + x;
+        if constexpr (IN_LDS) return (bits[p >> 5] >> (p & 31)) & 1u;
+        else return im[p] != 0;
+    };
     const int DX[8] = { 1, 1, 0, -1, -1, -1, 0, 1 };            // 0 = E, then counter-clockwise on screen (y grows down)
     const int DY[8] = { 0, -1, -1, -1, 0, 1, 1, 1 };
+    for (int c = threadIdx.x; c < nc; c += 256) {               // lanes own contours (a handful after postprocess_mask)
     const int start = roots[(size_t)img * cap + c];
     const int x0 = start % W, y0 = start / W;
     int *dst = nullptr;
@@ -427,6 +457,7 @@ __global__ __launch_bounds__(64) void k_trace(const uint8_t *__restrict__ fg, co
         }
     }
     if (!write) npts[(size_t)img * cap + c] = n;
+    }
 }
 
 // per image: exclusive scan of the point counts -> out_start, and the verdict (count or -1 on overflow)
@@ -489,10 +520,20 @@ hipError_t launch_extract_contours(const uint8_t *masks, int B, int H, int W, in
     hipLaunchKernelGGL(ct::k_zero_counts, dim3((B + 255) / 256), b, 0, s, counts, B);
     hipLaunchKernelGGL(ct::k_collect, g, b, 0, s, fparent, bparent, minx, miny, maxx, maxy, roots, counts, cap_contours, H, W, n);
     hipLaunchKernelGGL(ct::k_sort_roots, dim3((B + 63) / 64), dim3(64), 0, s, roots, counts, cap_contours, B);
-    const dim3 gt((unsigned)(((long long)B * cap_contours + 63) / 64)), bt(64);
-    hipLaunchKernelGGL(ct::k_trace, gt, bt, 0, s, fg, roots, counts, cap_contours, H, W, B, npts, out_start, out_xy, cap_points, 0);
-    hipLaunchKernelGGL(ct::k_offsets, dim3((B + 63) / 64), dim3(64), 0, s, npts, counts, cap_contours, cap_points, B, out_start, out_count);
-    hipLaunchKernelGGL(ct::k_trace, gt, bt, 0, s, fg, roots, counts, cap_contours, H, W, B, npts, out_start, out_xy, cap_points, 1);
+    // one workgroup per image; the mask as an LDS bit plane when it fits
+    const size_t plane = (((size_t)H * W + 31) / 32) * 4;
+    const bool in_lds = plane <= 128 * 1024;
+    const dim3 gt((unsigned)B), bt(256);
+    for (int pass = 0; pass < 2; ++pass) {
+        if (in_lds) {
+            if (hipError_t e = ensure_dynamic_lds(ct::k_trace<true>, plane); e != hipSuccess) return e;
+            hipLaunchKernelGGL(ct::k_trace<true>, gt, bt, plane, s, fg, roots, counts, cap_contours, H, W, B, npts, out_start, out_xy, cap_points, pass);
+        } else {
+            hipLaunchKernelGGL(ct::k_trace<false>, gt, bt, 0, s, fg, roots, counts, cap_contours, H, W, B, npts, out_start, out_xy, cap_points, pass);
+        }
+        if (pass == 0)
+            hipLaunchKernelGGL(ct::k_offsets, dim3((B + 63) / 64), dim3(64), 0, s, npts, counts, cap_contours, cap_points, B, out_start, out_count);
+    }
     return hipGetLastError();
 }
 
