@@ -530,6 +530,16 @@ __global__ __launch_bounds__(256) void wino_splitk_reduce(const ConvArgs a, long
     }
 }
 
+// second half of a split-K layer (either Winograd kernel): a.ksplit slabs [slice][B][H][W][Cout] in a.ksplit_ws -> a.out
+hipError_t launch_wino_splitk_reduce(const ConvArgs &a, hipStream_t s)
+{
+    const long long total = (long long)a.B * ((a.H + 1) / 2) * ((a.W + 1) / 2) * (a.Cout / 4);
+    long long blocks = (total + 255) / 256;
+    if (blocks > 2048) blocks = 2048;
+    hipLaunchKernelGGL(wino_splitk_reduce, dim3((unsigned)blocks), dim3(256), 0, s, a, total);
+    return hipGetLastError();
+}
+
 template <int WM, int WN>
 static hipError_t launch_wino_cfg(const ConvArgs &a0, hipStream_t s)
 {

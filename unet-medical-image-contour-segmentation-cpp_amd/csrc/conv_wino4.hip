@@ -68,7 +68,10 @@ struct W4 {
 // NB = 16-channel blocks per wave: 2 (workgroup = 128 output channels) or 1 (64 channels, for the Cout = 64 layers: half
 // the MFMA work per transformed tile, but still 1.6x the F(2x2) kernel there).
 // HEAD (one-block variant only): the layer feeds the network's 1x1 head; see ConvArgs::head_w.
-template <int NB, bool HEAD>
+// SPLITK: the grid carries a.ksplit workgroups per tile, each walks one slice of the K chunks and writes its raw 4x4
+// outputs into slab [slice][B][H][W][Cout] of a.ksplit_ws; wino_splitk_reduce (conv_wino.hip) sums the slabs in slice order
+// (deterministic) and applies shift / ReLU / pooling.  For grids that cannot fill the chip (single images, deep levels).
+template <int NB, bool HEAD, bool SPLITK>
 __global__ __launch_bounds__(256, 1) void conv3x3_wino4_f32(const ConvArgs a, const int tiles_x, const int tiles_y,
                                                             const int m_tiles, const int nwg)
 {
@@ -94,7 +97,9 @@ __global__ __launch_bounds__(256, 1) void conv3x3_wino4_f32(const ConvArgs a, co
     // stage 1: raw halo patch, one 16-channel chunk at a time, global -> registers -> LDS (4 lanes = one pixel's 64
     // bytes; zero padding, channels past Cin and dead slots through the buffer range check: voffset 0xFFFFFFFF reads zeros)
     unsigned raw_voff[W4::RAW_ITERS];
+    int ks = 0;                               // K slice of this workgroup (SPLITK)
     auto setup_tile = [&](int L) {
+        if constexpr (SPLITK) { ks = L % a.ksplit; L /= a.ksplit; }
         const int n_tile = L / m_tiles;
         int m = L - n_tile * m_tiles;
         const int tx = m % tiles_x; m /= tiles_x;
@@ -212,27 +217,34 @@ __global__ __launch_bounds__(256, 1) void conv3x3_wino4_f32(const ConvArgs a, co
     };
     const float *const v_rd = Vs + j16 * VROW + 4 * kq;                       // + buf*VBUF + pos*VPOS
 
-    const int nchunks = all_chunks;
-    const float relu_lo = a.relu ? 0.f : -3.402823466e+38f;
+    int c_begin = 0, nchunks = all_chunks;    // this workgroup's K range [c_begin, nchunks)
+    // SPLITK: raw partial sums into this slice's slab [B][H][W][Cout]; shift, ReLU and pooling belong to the reduce kernel
+    const float relu_lo = (a.relu && !SPLITK) ? 0.f : -3.402823466e+38f;
     const int Hp = a.H >> 1, Wp = a.W >> 1;
-    const bool do_pool = a.pool_out != nullptr;
-    const unsigned pix_bytes = (unsigned)a.ldo * 4, row_bytes = (unsigned)a.W * pix_bytes;
+    const bool do_pool = !SPLITK && a.pool_out != nullptr;
+    const int ld_e = SPLITK ? a.Cout : a.ldo, co_e = SPLITK ? 0 : a.co_off;
+    const unsigned pix_bytes = (unsigned)ld_e * 4, row_bytes = (unsigned)a.W * pix_bytes;
     const unsigned ppix_bytes = (unsigned)a.pool_ld * 4, prow_bytes = (unsigned)Wp * ppix_bytes;
     f32x4 u[UD][NB];
     // the loads that open a tile: the raw patches of chunks 0 and 1 straight into LDS, then the U ring
     auto open_tile = [&]() {
-        raw_dma(0, 0);
-        raw_dma(1, 1);
+        if constexpr (SPLITK) {
+            const int per_slice = (all_chunks + a.ksplit - 1) / a.ksplit;
+            c_begin = ks * per_slice;
+            nchunks = c_begin + per_slice < all_chunks ? c_begin + per_slice : all_chunks;
+        }
+        raw_dma(c_begin, 0);
+        raw_dma(c_begin + 1, 1);
 #pragma unroll
         for (int p = 0; p < UD; ++p)
 #pragma unroll
-            for (int blk = 0; blk < NB; ++blk) u[p][blk] = u_load(0, p, blk);
+            for (int blk = 0; blk < NB; ++blk) u[p][blk] = u_load(c_begin, p, blk);
     };
 
     // PERSIST (one-block variant): this workgroup's share of its XCD's logical tile range (the bijective XCD remap of
     // kernel_common.h, walked with a stride).  The two-block variant has no registers left to hold a second tile's opening
     // loads across its epilogue: one tile per workgroup there (the loop below runs once and folds away).
-    constexpr bool PERSIST = NB == 1;
+    constexpr bool PERSIST = NB == 1 && !SPLITK;
     const int G = gridDim.x, xcd = blockIdx.x & 7;
     const int slot = PERSIST ? (int)(blockIdx.x >> 3) : 0;
     const int slots = PERSIST ? (G >> 3) + (xcd < (G & 7) ? 1 : 0) : 1;
@@ -250,7 +262,7 @@ __global__ __launch_bounds__(256, 1) void conv3x3_wino4_f32(const ConvArgs a, co
 #pragma unroll
         for (int blk = 0; blk < NB; ++blk) {
             // position (xi, nu) = (1, 1) starts at the shift: A^T e_1 e_1^T A is the all-ones tile, so the bias add is free
-            const float init = (p == 7 && ncol0 + 16 * blk < a.Cout) ? a.bias[ncol0 + 16 * blk] : 0.f;
+            const float init = (!SPLITK && p == 7 && ncol0 + 16 * blk < a.Cout) ? a.bias[ncol0 + 16 * blk] : 0.f;
 #pragma unroll
             for (int r = 0; r < 4; ++r) acc[p][blk][r] = init;
         }
@@ -274,11 +286,12 @@ __global__ __launch_bounds__(256, 1) void conv3x3_wino4_f32(const ConvArgs a, co
     //                       chunk c, ran during chunk c-1)
     //   positions 2 - 22  : the transform of chunk c+1 (Raw[(c+1) & 1] -> V[(c+1) & 1]) in pieces between the MFMAs
     //   every position    : the V fragment one position ahead, the U ring six positions ahead
-    for (int chunk = 0; chunk < nchunks; ++chunk) {
+    for (int chunk = c_begin; chunk < nchunks; ++chunk) {
         const int nxt = (chunk + 1 < nchunks) ? chunk + 1 : chunk;          // the last chunk prefetches itself: straight-line code
-        const int rbuf = (chunk + 1) & 1;
-        const float *vb = v_rd + (chunk & 1) * VBUF;
-        float *const wr = v_wr_a + ((chunk + 1) & 1) * VBUF;
+        const int par = (chunk - c_begin) & 1;                              // buffer parity of this chunk
+        const int rbuf = par ^ 1;
+        const float *vb = v_rd + par * VBUF;
+        float *const wr = v_wr_a + (par ^ 1) * VBUF;
         f32x4 av = *reinterpret_cast<const f32x4 *>(vb);
 #pragma unroll
         for (int p = 0; p < 36; ++p) {
@@ -286,7 +299,7 @@ __global__ __launch_bounds__(256, 1) void conv3x3_wino4_f32(const ConvArgs a, co
             if (p + 1 < 36) avn = *reinterpret_cast<const f32x4 *>(vb + (p + 1) * VPOS);   // V fragment one position ahead
             // one load every fourth position, not a burst: 16 line misses at a time keep the VMEM queue moving, so the U loads
             // issued behind each of them are delayed by less than the U ring covers
-            if (p % 4 == 0 && p / 4 < W4::RAW_ITERS) raw_dma_one(chunk + 2, chunk & 1, p / 4);
+            if (p % 4 == 0 && p / 4 < W4::RAW_ITERS) raw_dma_one(chunk + 2, par, p / 4);
             if (p == 2) piece_load(0, rbuf);
             __builtin_amdgcn_sched_barrier(0);        // ... issued BEFORE this position's MFMAs (hipcc would sink them to their use)
             f32x4 bv[NB];
@@ -338,7 +351,8 @@ __global__ __launch_bounds__(256, 1) void conv3x3_wino4_f32(const ConvArgs a, co
         }
     }
     const __amdgpu_buffer_rsrc_t out_rsrc = __builtin_amdgcn_make_buffer_rsrc(
-        a.out + (size_t)e_b * a.H * a.W * a.ldo, 0, a.H * a.W * a.ldo * 4, 0x00020000);
+        (SPLITK ? a.ksplit_ws + (size_t)ks * a.B * a.H * a.W * a.Cout : a.out) + (size_t)e_b * a.H * a.W * ld_e, 0,
+        a.H * a.W * ld_e * 4, 0x00020000);
     const __amdgpu_buffer_rsrc_t pool_rsrc = __builtin_amdgcn_make_buffer_rsrc(
         do_pool ? a.pool_out + (size_t)e_b * Hp * Wp * a.pool_ld : a.out, 0, do_pool ? Hp * Wp * a.pool_ld * 4 : 0, 0x00020000);
     const int oy = e_by0 + 4 * kq;
@@ -348,7 +362,7 @@ __global__ __launch_bounds__(256, 1) void conv3x3_wino4_f32(const ConvArgs a, co
         for (int blk = 0; blk < NB; ++blk) {
             const int ncol = e_ncol0 + 16 * blk;
             const bool n_ok = ncol < a.Cout;
-            const unsigned vbase = n_ok ? (unsigned)((oy * a.W + e_bx0) * a.ldo + a.co_off + ncol) * 4 : 0xFFFFFFFFu;
+            const unsigned vbase = n_ok ? (unsigned)((oy * a.W + e_bx0) * ld_e + co_e + ncol) * 4 : 0xFFFFFFFFu;
             const unsigned pbase = n_ok ? (unsigned)(((oy >> 1) * Wp + (e_bx0 >> 1)) * a.pool_ld + ncol) * 4 : 0xFFFFFFFFu;
             unsigned vcol[4][4], pcol[4][2];          // edge workgroups: per-column offsets (dead columns -> dropped stores)
             if constexpr (!INTERIOR) {
@@ -471,13 +485,32 @@ static int persistent_cus()
 }
 
 template <int NB, bool HEAD>
-static hipError_t launch_wino4_cfg(const ConvArgs &a, hipStream_t s)
+static hipError_t launch_wino4_cfg(const ConvArgs &a0, hipStream_t s)
 {
+    ConvArgs a = a0;
     const int tiles_x = (a.W + 15) / 16, tiles_y = (a.H + 15) / 16;
     const int m_tiles = tiles_x * tiles_y * a.B;
     const int n_tiles = (a.Cout + 64 * NB - 1) / (64 * NB);
     const int nwg = m_tiles * n_tiles;
-    auto kern = conv3x3_wino4_f32<NB, HEAD>;
+    // split K when the (tile, channel) grid alone leaves most CUs idle: every slice keeps at least four chunks
+    a.ksplit = 1;
+    const int chunks = (a.Cin + WINO4_KC - 1) / WINO4_KC;
+    if (!HEAD && a.ksplit_ws != nullptr && nwg <= 128 && chunks >= 8 && a.Cout % 4 == 0 && a.ldo % 4 == 0 && a.co_off % 4 == 0) {
+        int ks = 256 / nwg;
+        if (ks > 8) ks = 8;
+        if (ks > chunks / 4) ks = chunks / 4;
+        while (ks > 1 && (size_t)ks * a.B * a.H * a.W * a.Cout * sizeof(float) > a.ksplit_ws_bytes) --ks;
+        while (ks > 1 && (ks - 1) * ((chunks + ks - 1) / ks) >= chunks) --ks;      // no empty slice
+        a.ksplit = ks;
+    }
+    if (a.ksplit > 1) {
+        auto kern = conv3x3_wino4_f32<NB, false, true>;
+        if (hipError_t e = ensure_dynamic_lds(kern, W4::LDS_BYTES); e != hipSuccess) return e;
+        const int grid = nwg * a.ksplit;
+        hipLaunchKernelGGL(kern, dim3(grid), dim3(256), W4::LDS_BYTES, s, a, tiles_x, tiles_y, m_tiles, grid);
+        return launch_wino_splitk_reduce(a, s);
+    }
+    auto kern = conv3x3_wino4_f32<NB, HEAD, false>;
     if (hipError_t e = ensure_dynamic_lds(kern, W4::LDS_BYTES); e != hipSuccess) return e;
     // one-block variant: persistent, one workgroup per CU (144 KB of LDS each); two-block variant: one tile per workgroup
     const int grid = (NB == 1 && nwg > persistent_cus()) ? persistent_cus() : nwg;

@@ -61,6 +61,7 @@ struct mi_unet {
     int algo = MI_UNET_CONV_DIRECT; // resolved conv3x3 algorithm (MI_UNET_CONV_DIRECT / _WINOGRAD / _WINOGRAD16)
     bool fuse_pool = true;          // MIUNET_FUSE_POOL=0 keeps the stand-alone pooling kernel (A/B and parity checks)
     int wino4_min_wg = 256;         // MIUNET_WINO4_MIN_WG: smallest grid the F(4x4,3x3) kernel takes (else F(2x2) + split-K)
+    bool wino4_splitk = true;       // MIUNET_WINO4_SPLITK=0: small grids go to the F(2x2) kernel's split-K instead
     // device memory
     float *d_weights = nullptr;     // one blob: every packed tensor (single allocation -> one broadcast / one free)
     size_t weight_floats = 0;
@@ -585,7 +586,9 @@ int launch_plan(mi_unet *h, const uint8_t *d_imgs, int B, uint8_t *d_labels, flo
                 // (MIUNET_SPLITK=0 = batch-invariant mode: no split-K workspace, and the choice must not depend on B either)
                 const long long wg4 = (long long)((a.W + 15) / 16) * ((a.H + 15) / 16) * B * ((a.Cout + 127) / 128);
                 const int min_wg4 = h->wino4_min_wg;
-                if (a.wpk4 != nullptr && (wg4 >= min_wg4 || h->d_ksplit == nullptr)) {
+                // ... or whose grid is so small that the launcher splits K (<= 128 workgroups, >= 8 chunks of 16 channels)
+                const bool split4 = h->wino4_splitk && h->d_ksplit != nullptr && wg4 <= 128 && a.Cin >= 128 && st.head_step < 0;
+                if (a.wpk4 != nullptr && (wg4 >= min_wg4 || h->d_ksplit == nullptr || split4)) {
                     kname = "conv3x3_wino4";
                     if (st.head_step >= 0) {   // fused 1x1 head + argmax: this layer's activations never reach HBM
                         const Step &hd = h->plan[st.head_step];
@@ -719,6 +722,7 @@ int mi_unet_create(const mi_unet_config *cfg, mi_unet_t **out)
         const char *fp = getenv("MIUNET_FUSE_POOL");
         h->fuse_pool = !(fp && !strcmp(fp, "0"));
         if (const char *mw = getenv("MIUNET_WINO4_MIN_WG")) h->wino4_min_wg = atoi(mw);
+        if (const char *sk4 = getenv("MIUNET_WINO4_SPLITK")) h->wino4_splitk = sk4[0] != '0';
         const char *gr = getenv("MIUNET_GRAPH");
         h->use_graph = !(gr && !strcmp(gr, "0"));
     }

@@ -64,6 +64,7 @@ hipError_t launch_conv3x3_wino16(const ConvArgs &a, hipStream_t s);
 constexpr int WINO4_KC = 16;
 constexpr int WINO4_SC = 32;
 hipError_t launch_conv3x3_wino4(const ConvArgs &a, hipStream_t s);
+hipError_t launch_wino_splitk_reduce(const ConvArgs &a, hipStream_t s);   // sums a.ksplit slabs of a.ksplit_ws into a.out
 hipError_t launch_convT2x2_mfma(const ConvArgs &a, hipStream_t s);
 // The transposed conv as four per-tap GEMMs sharing one A operand (convt_taps.hip): a.wpk4 holds the weights packed
 // [ceil(Cin/32)*4 chunks of 8][4 taps (dy*2+dx)][convT_taps_cpad(Cout)][8], zero-padded; other fields as above.
