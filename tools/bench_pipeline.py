@@ -55,6 +55,14 @@ def main():
         for p in paths:
             hostlib.process_single_image(p, 2048, 1536, out)
         ts = time.perf_counter() - t0
+        # directory mode over 4 chunks: reading chunk k+1, the device work of chunk k and the artefacts of chunk k-1 overlap
+        many = []
+        for j in range(4 * B):
+            q = os.path.join(d, f"dir{j:03d}.raw")
+            os.symlink(paths[j % B], q)
+            many.append(q)
+        t0 = time.perf_counter(); nm = hostlib.process_image_batch(many, [2048] * len(many), [1536] * len(many), out); tm = time.perf_counter() - t0
+        print(f"  facade process_image_batch over {len(many)} files (4 chunks, pipelined): {tm / len(many) * 1e3:.2f} ms/image ({nm} ok)")
         hostlib.cleanup_resources()
         for root, _, files in os.walk(os.path.join(d, "log")):
             for f in files:

@@ -6,6 +6,8 @@
 #include <chrono>
 #include <cstdlib>
 #include <filesystem>
+#include <future>
+#include <memory>
 #include <iostream>
 #include <mutex>
 #include <sstream>
@@ -158,7 +160,186 @@ bool device_postprocess_requested()
 
 }  // namespace
 
-// Device-first form of the pipeline for N images at once (the reference loops files one by one, src/main.cpp:148-164):
+// ---- directory mode as a three-stage pipeline over chunks of max_batch images (all-device route):
+//        read the files of chunk k+1  ||  device: chunk k (mi_unet_segment_raw16)  ||  PNG / JSON artefacts of chunk k-1
+// Each stage is internally parallel over its images (a few host threads; the device call is one micro-batch); console and
+// log text is collected per image and emitted in file order, chunk after chunk, by the calling thread.
+namespace {
+
+struct ChunkIn {
+    size_t first = 0, count = 0;                       // range of the caller's lists
+    std::vector<std::vector<uint16_t>> raws;           // per file of the range (empty = unreadable)
+    std::vector<std::string> read_err;
+    long long read_ms = 0;
+};
+
+struct ChunkOut {
+    std::vector<size_t> idx;                           // files of the range that were read (offsets into the range)
+    std::vector<uint8_t> tiles, labels;
+    std::vector<int32_t> xy, start, cnt;
+    long long device_ms = 0;
+};
+
+struct ChunkText {
+    std::vector<std::string> con, err, lg;             // per read file: console, stderr, log text
+    int ok = 0;
+    long long art_ms = 0;
+};
+
+constexpr int kCapPoints = 1 << 15, kCapContours = 64;     // postprocess keeps components >= 6 % of the tile: <= 16
+
+int io_threads_for(size_t n) { return (int)std::max<size_t>(1, std::min<size_t>(n, 8)); }   // a few I/O threads, never the whole machine
+
+ChunkIn read_chunk(const std::vector<std::string> &paths, const std::vector<int> &widths, const std::vector<int> &heights,
+                   size_t first, size_t count)
+{
+    ChunkIn in;
+    in.first = first; in.count = count;
+    in.raws.resize(count); in.read_err.resize(count);
+    const auto t0 = std::chrono::high_resolution_clock::now();
+    const int nt = io_threads_for(count);
+#pragma omp parallel for schedule(dynamic) num_threads(nt)
+    for (long long k = 0; k < (long long)count; ++k) {
+        try {
+            in.raws[k] = Preprocess::read_raw16(paths[first + k], widths[first + k], heights[first + k]);
+        } catch (const std::exception &e) {
+            in.read_err[k] = std::string("Processing error: ") + e.what() + " (" + paths[first + k] + ")";
+            in.raws[k].clear();
+        }
+    }
+    in.read_ms = std::chrono::duration_cast<std::chrono::milliseconds>(std::chrono::high_resolution_clock::now() - t0).count();
+    return in;
+}
+
+ChunkOut device_chunk(const ChunkIn &in, const std::vector<int> &widths, const std::vector<int> &heights)
+{
+    ChunkOut out;
+    std::vector<const uint16_t *> ptrs;
+    std::vector<int> ws, hs;
+    for (size_t k = 0; k < in.count; ++k)
+        if (in.read_err[k].empty()) {
+            out.idx.push_back(k);
+            ptrs.push_back(in.raws[k].data()); ws.push_back(widths[in.first + k]); hs.push_back(heights[in.first + k]);
+        }
+    if (out.idx.empty()) return out;
+    const size_t hw = (size_t)g_cfg.height * g_cfg.width, m = out.idx.size();
+    out.tiles.resize(hw * m); out.labels.resize(hw * m);
+    out.xy.resize(m * kCapPoints * 2); out.start.resize(m * (kCapContours + 1)); out.cnt.resize(m);
+    const auto t0 = std::chrono::high_resolution_clock::now();
+    {
+        std::lock_guard<std::mutex> lk(g_infer_mutex);
+        if (mi_unet_segment_raw16(g_engine, ptrs.data(), ws.data(), hs.data(), (int)m, out.tiles.data(), out.labels.data(),
+                                  out.xy.data(), kCapPoints, out.start.data(), kCapContours, out.cnt.data()) != MI_UNET_OK)
+            throw std::runtime_error(std::string("Inference failed: ") + mi_unet_last_error());
+    }
+    out.device_ms = std::chrono::duration_cast<std::chrono::milliseconds>(std::chrono::high_resolution_clock::now() - t0).count();
+    return out;
+}
+
+ChunkText artefact_chunk(const ChunkIn &in, const ChunkOut &out, const std::vector<std::string> &paths, const std::vector<int> &widths,
+                         const std::vector<int> &heights, const std::string &output_dir)
+{
+    const size_t m = out.idx.size(), hw = (size_t)g_cfg.height * g_cfg.width;
+    ChunkText tx;
+    tx.con.resize(m); tx.err.resize(m); tx.lg.resize(m);
+    std::vector<char> done(m, 0);
+    const auto t0 = std::chrono::high_resolution_clock::now();
+    const int nt = io_threads_for(m);
+#pragma omp parallel for schedule(dynamic) num_threads(nt)
+    for (long long k = 0; k < (long long)m; ++k) {
+        const size_t i = in.first + out.idx[k];
+        std::ostringstream con, lg;
+        try {
+            const std::string base_name = fs::path(paths[i]).stem().string();
+            lg << "\n=== Processing Image: " << fs::path(paths[i]).filename().string() << " ===" << std::endl;
+            Image8 tile(g_cfg.height, g_cfg.width, 1), vis(g_cfg.height, g_cfg.width, 1);
+            std::copy(out.tiles.begin() + k * hw, out.tiles.begin() + (k + 1) * hw, tile.data.begin());
+            std::copy(out.labels.begin() + k * hw, out.labels.begin() + (k + 1) * hw, vis.data.begin());
+            if (!Preprocess::write_preprocess_outputs(tile, paths[i], output_dir + "/" + base_name + "_normalized.png",
+                                                      output_dir + "/" + base_name + "_original_sizes.json", widths[i], heights[i]))
+                throw std::runtime_error("Preprocessing failed");
+            if (!medseg::write_png(output_dir + "/" + base_name + "_mask.png", vis, /*level0=*/true))
+                throw std::runtime_error("Failed to save mask");
+            std::vector<medseg::Contour> contours;
+            if (out.cnt[k] < 0) {                      // capacity overflow on the device: fall back to the host tracer
+                contours = Mask2Polygon::extract_contours(vis);
+            } else {
+                const int32_t *st = &out.start[k * (kCapContours + 1)], *pts = &out.xy[k * (size_t)kCapPoints * 2];
+                for (int c = 0; c < out.cnt[k]; ++c) {
+                    medseg::Contour cc;
+                    for (int q = st[c]; q < st[c + 1]; ++q) cc.emplace_back(pts[2 * q], pts[2 * q + 1]);
+                    contours.push_back(std::move(cc));
+                }
+            }
+            Mask2Polygon::write_polygon_outputs(contours, tile, output_dir, base_name, widths[i], heights[i], con);
+            lg << "Processing completed for: " << base_name << std::endl;
+            done[k] = 1;
+        } catch (const std::exception &e) {
+            tx.err[k] = std::string("Processing error: ") + e.what() + "\n";
+            lg << "Processing error: " << e.what() << std::endl;
+        }
+        tx.con[k] = con.str(); tx.lg[k] = lg.str();
+    }
+    for (size_t k = 0; k < m; ++k) tx.ok += done[k];
+    tx.art_ms = std::chrono::duration_cast<std::chrono::milliseconds>(std::chrono::high_resolution_clock::now() - t0).count();
+    return tx;
+}
+
+// the all-device route of process_image_batch; returns the number of images that succeeded
+int process_batch_pipelined(const std::vector<std::string> &paths, const std::vector<int> &widths, const std::vector<int> &heights,
+                            const std::string &output_dir)
+{
+    auto &log_file = get_log_file();
+    const size_t n = paths.size(), step = (size_t)std::max(1, g_cfg.max_batch);
+    int ok = 0;
+    auto emit = [&](const ChunkIn &in, const ChunkOut &out, const ChunkText &tx) {
+        for (size_t k = 0; k < tx.con.size(); ++k) {
+            std::cout << tx.con[k] << std::flush;
+            std::cerr << tx.err[k] << std::flush;
+            if (log_file.is_open()) log_file << tx.lg[k] << std::flush;
+        }
+        if (log_file.is_open())
+            log_file << "Batch read time: " << in.read_ms << " ms for " << in.count << " files; Batch device time: " << out.device_ms
+                     << " ms for " << out.idx.size() << " images; Batch artefact time: " << tx.art_ms << " ms" << std::endl;
+        ok += tx.ok;
+    };
+    struct Stage { ChunkIn in; ChunkOut out; };
+    std::future<ChunkIn> next_read = std::async(std::launch::async, read_chunk, std::cref(paths), std::cref(widths), std::cref(heights),
+                                                (size_t)0, std::min(step, n));
+    std::future<ChunkText> pending_art;
+    std::shared_ptr<Stage> art_stage;                  // keeps the chunk alive while its artefacts are being written
+    for (size_t first = 0; first < n; first += step) {
+        auto st = std::make_shared<Stage>();
+        st->in = next_read.get();
+        if (first + step < n)
+            next_read = std::async(std::launch::async, read_chunk, std::cref(paths), std::cref(widths), std::cref(heights),
+                                   first + step, std::min(step, n - first - step));
+        for (size_t k = 0; k < st->in.count; ++k)
+            if (!st->in.read_err[k].empty()) {
+                std::cerr << st->in.read_err[k] << std::endl;
+                if (log_file.is_open()) log_file << st->in.read_err[k] << std::endl;
+            }
+        try {
+            st->out = device_chunk(st->in, widths, heights);
+        } catch (...) {
+            if (pending_art.valid()) emit(art_stage->in, art_stage->out, pending_art.get());
+            throw;
+        }
+        for (auto &r : st->in.raws) std::vector<uint16_t>().swap(r);      // the RAW images are on the device's side now
+        if (pending_art.valid()) emit(art_stage->in, art_stage->out, pending_art.get());
+        art_stage = st;
+        pending_art = std::async(std::launch::async, [st, &paths, &widths, &heights, &output_dir] {
+            return artefact_chunk(st->in, st->out, paths, widths, heights, output_dir);
+        });
+    }
+    if (pending_art.valid()) emit(art_stage->in, art_stage->out, pending_art.get());
+    return ok;
+}
+
+}  // namespace
+
+// Device-first form of the pipeline for N images at once (the reference loops files one by one, src/main.cpp:148-164).
+// All-device route (default): the chunked three-stage pipeline above.  With MEDSEG_HOST_POSTPROCESS / _CONTOURS = 1:
 // RAW16 -> [device: min/max, bilinear resample, quantise, UNet, argmax] -> per image on the host: PNG/JSON artefacts,
 // postprocess_mask, contours.  Returns the number of images that succeeded.
 int process_image_batch(const std::vector<std::string> &raw_paths, const std::vector<int> &widths,
@@ -170,6 +351,8 @@ int process_image_batch(const std::vector<std::string> &raw_paths, const std::ve
         if (!g_engine) throw std::runtime_error("Engine not initialized");
         const size_t n = raw_paths.size();
         if (widths.size() != n || heights.size() != n) throw std::runtime_error("widths/heights do not match raw_paths");
+        if (n > 0 && device_postprocess_requested() && device_contours_requested())
+            return process_batch_pipelined(raw_paths, widths, heights, output_dir);
         std::vector<std::vector<uint16_t>> raws(n);
         std::vector<const uint16_t *> ptrs;
         std::vector<int> ws, hs;
@@ -201,67 +384,6 @@ int process_image_batch(const std::vector<std::string> &raw_paths, const std::ve
         std::vector<uint8_t> tiles(hw * idx.size()), labels(hw * idx.size());
         const auto t0 = std::chrono::high_resolution_clock::now();
         const bool dev_post = device_postprocess_requested();
-        if (dev_post && device_contours_requested() && !idx.empty()) {
-            // every device-capable stage in ONE call: preprocess, UNet, argmax, postprocess_mask, mask_to_image, contours
-            const int cap_points = 1 << 15, cap_contours = 64;     // postprocess keeps components >= 6 % of the tile: <= 16
-            std::vector<int32_t> xy((size_t)idx.size() * cap_points * 2), start((size_t)idx.size() * (cap_contours + 1)), cnt(idx.size());
-            {
-                std::lock_guard<std::mutex> lk(g_infer_mutex);
-                if (mi_unet_segment_raw16(g_engine, ptrs.data(), ws.data(), hs.data(), (int)idx.size(), tiles.data(), labels.data(),
-                                          xy.data(), cap_points, start.data(), cap_contours, cnt.data()) != MI_UNET_OK)
-                    throw std::runtime_error(std::string("Inference failed: ") + mi_unet_last_error());
-            }
-            const auto ms = std::chrono::duration_cast<std::chrono::milliseconds>(std::chrono::high_resolution_clock::now() - t0).count();
-            if (log_file.is_open()) log_file << "Batch device time: " << ms << " ms for " << idx.size() << " images" << std::endl;
-            // PNG / JSON artefacts of the images are independent: one host thread each, console and log text collected per
-            // image and emitted in file order afterwards (the reference's sequential loop prints in that order)
-            std::vector<std::ostringstream> con(idx.size()), err(idx.size()), lg(idx.size());
-            std::vector<char> done(idx.size(), 0);
-            const auto t_art = std::chrono::high_resolution_clock::now();
-#pragma omp parallel for schedule(dynamic) num_threads(io_threads)
-            for (long long k = 0; k < (long long)idx.size(); ++k) {
-                const size_t i = idx[k];
-                try {
-                    const std::string base_name = fs::path(raw_paths[i]).stem().string();
-                    lg[k] << "\n=== Processing Image: " << fs::path(raw_paths[i]).filename().string() << " ===" << std::endl;
-                    Image8 tile(g_cfg.height, g_cfg.width, 1), vis(g_cfg.height, g_cfg.width, 1);
-                    std::copy(tiles.begin() + k * hw, tiles.begin() + (k + 1) * hw, tile.data.begin());
-                    std::copy(labels.begin() + k * hw, labels.begin() + (k + 1) * hw, vis.data.begin());
-                    if (!Preprocess::write_preprocess_outputs(tile, raw_paths[i], output_dir + "/" + base_name + "_normalized.png",
-                                                              output_dir + "/" + base_name + "_original_sizes.json", widths[i], heights[i]))
-                        throw std::runtime_error("Preprocessing failed");
-                    if (!medseg::write_png(output_dir + "/" + base_name + "_mask.png", vis, /*level0=*/true))
-                        throw std::runtime_error("Failed to save mask");
-                    std::vector<medseg::Contour> contours;
-                    if (cnt[k] < 0) {                      // capacity overflow on the device: fall back to the host tracer
-                        contours = Mask2Polygon::extract_contours(vis);
-                    } else {
-                        const int32_t *st = &start[k * (cap_contours + 1)], *pts = &xy[k * (size_t)cap_points * 2];
-                        for (int c = 0; c < cnt[k]; ++c) {
-                            medseg::Contour cc;
-                            for (int q = st[c]; q < st[c + 1]; ++q) cc.emplace_back(pts[2 * q], pts[2 * q + 1]);
-                            contours.push_back(std::move(cc));
-                        }
-                    }
-                    Mask2Polygon::write_polygon_outputs(contours, tile, output_dir, base_name, widths[i], heights[i], con[k]);
-                    lg[k] << "Processing completed for: " << base_name << std::endl;
-                    done[k] = 1;
-                } catch (const std::exception &e) {
-                    err[k] << "Processing error: " << e.what() << std::endl;
-                    lg[k] << "Processing error: " << e.what() << std::endl;
-                }
-            }
-            for (size_t k = 0; k < idx.size(); ++k) {
-                std::cout << con[k].str() << std::flush;
-                std::cerr << err[k].str() << std::flush;
-                if (log_file.is_open()) log_file << lg[k].str() << std::flush;
-                ok += done[k];
-            }
-            if (log_file.is_open())
-                log_file << "Batch artefact time: " << std::chrono::duration_cast<std::chrono::milliseconds>(std::chrono::high_resolution_clock::now() - t_art).count()
-                         << " ms for " << idx.size() << " images" << std::endl;
-            return ok;
-        }
         {
             std::lock_guard<std::mutex> lk(g_infer_mutex);
             mi_unet_set_postprocess(g_engine, dev_post ? 1 : 0);
