@@ -20,7 +20,8 @@ namespace miunet {
 //   * U fragments are wave-private: 16-byte buffer loads straight from global / L2 with scalar offsets, six positions
 //     ahead in a register ring;
 //   * the raw 18x18 halo patch is staged through a double-buffered LDS image, 16 channels (64 bytes per pixel) at a
-//     time, two chunks ahead of the MFMAs; V = B^T d B is built from it into a double-buffered LDS image
+//     time, two chunks ahead of the MFMAs, by LDS-DMA loads (no staging registers, no ds_write; one load every fourth
+//     position rather than a burst); V = B^T d B is built from it into a double-buffered LDS image
 //     [pos][tile][16 + 4 pad] (80-byte rows: 5i mod 16 is a bijection -> conflict-free ds_read_b128);
 //   * the forward transform is cut by ROWS of B^T: waves 0 and 1 build two rows each (xi = 1,2 and 3,4, which share
 //     their sub-expressions), waves 2 and 3 one row each (xi = 0 and 5); every lane = (tile, channel quad); the pieces
