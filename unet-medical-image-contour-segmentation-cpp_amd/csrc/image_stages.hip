@@ -418,8 +418,11 @@ __global__ __launch_bounds__(256) void k_trace(const uint8_t *__restrict__ fg, c
         if constexpr (IN_LDS) return (bits[p >> 5] >> (p & 31)) & 1u;
         else return im[p] != 0;
     };
-    const int DX[8] = { 1, 1, 0, -1, -1, -1, 0, 1 };            // 0 = E, then counter-clockwise on screen (y grows down)
-    const int DY[8] = { 0, -1, -1, -1, 0, 1, 1, 1 };
+    // direction d: 0 = E, then counter-clockwise on screen (y grows down): DX = {1,1,0,-1,-1,-1,0,1}, DY = {0,-1,-1,-1,0,1,1,1}.
+    // Packed as nibbles of (value + 1): a dynamically indexed array would live in scratch memory, and every probe of the walk
+    // would pay a memory round trip for its offsets.
+    auto DX = [](int d) -> int { return (int)((0x21000122u >> (4 * d)) & 3u) - 1; };
+    auto DY = [](int d) -> int { return (int)((0x22210001u >> (4 * d)) & 3u) - 1; };
     for (int c = threadIdx.x; c < nc; c += 256) {               // lanes own contours (a handful after postprocess_mask)
     const int start = roots[(size_t)img * cap + c];
     const int x0 = start % W, y0 = start / W;
@@ -438,16 +441,16 @@ __global__ __launch_bounds__(256) void k_trace(const uint8_t *__restrict__ fg, c
     int dir = 4, first = -1;                                    // first neighbour: clockwise, starting after west
     for (int k = 0; k < 8; ++k) {
         dir = (dir + 7) & 7;
-        if (at(x0 + DX[dir], y0 + DY[dir])) { first = dir; break; }
+        if (at(x0 + DX(dir), y0 + DY(dir))) { first = dir; break; }
     }
     if (first < 0) {
         emit(x0, y0);                                           // isolated pixel
     } else {
-        const int x1 = x0 + DX[first], y1 = y0 + DY[first];
+        const int x1 = x0 + DX(first), y1 = y0 + DY(first);
         int cx = x0, cy = y0, came = first, last_step = first ^ 4;
         for (long long guard = 0; guard < 4LL * H * W + 16; ++guard) {      // a border has at most 4 visits per pixel
             int s = came, nx, ny;
-            do { ++s; nx = cx + DX[s & 7]; ny = cy + DY[s & 7]; } while (!at(nx, ny));
+            do { ++s; nx = cx + DX(s & 7); ny = cy + DY(s & 7); } while (!at(nx, ny));
             const int step = s & 7;
             if (step != last_step) { emit(cx, cy); last_step = step; }
             const bool closing = (nx == x0 && ny == y0 && cx == x1 && cy == y1);
