@@ -119,6 +119,23 @@ def test_process_image_batch(tmp_path, monkeypatch, host_contours):
             assert red.any() and np.array_equal(ov[~red][:, 0], tile[~red])
         else:
             assert not (out_dir / f"b{k}.json").exists()
+    if host_contours == "0":
+        # more files than one micro-batch: the all-device route walks them as a three-stage pipeline over chunks of 16
+        # (read k+1 || device k || artefacts k-1); every image must come out exactly as in the one-chunk run above
+        out2 = tmp_path / "out2"
+        out2.mkdir()
+        many, mw, mh = [], [], []
+        for j in range(37):
+            q = tmp_path / f"m{j:02d}.raw"
+            os.symlink(paths[j % 3], q)
+            many.append(str(q)); mw.append(sizes[j % 3][1]); mh.append(sizes[j % 3][0])
+        many.insert(20, str(tmp_path / "missing2.raw")); mw.insert(20, 10); mh.insert(20, 10)      # unreadable, second chunk
+        assert hostlib.process_image_batch(many, mw, mh, str(out2)) == 37
+        for j in range(37):
+            for suffix in ("_normalized.png", "_mask.png", "_contour_overlay.png"):
+                assert np.array_equal(np.array(Image.open(out2 / f"m{j:02d}{suffix}")), np.array(Image.open(out_dir / f"b{j % 3}{suffix}"))), (j, suffix)
+            a = json.load(open(out2 / f"m{j:02d}.json")); b = json.load(open(out_dir / f"b{j % 3}.json"))
+            assert a["shapes"] == b["shapes"]
     hostlib.cleanup_resources()
 
 
