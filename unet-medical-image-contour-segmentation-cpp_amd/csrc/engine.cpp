@@ -71,9 +71,14 @@ struct mi_unet {
     uint8_t *d_img = nullptr;       // staging for the host-buffer entry point
     uint8_t *d_labels = nullptr;
     float *d_logits = nullptr;
-    uint16_t *d_raw = nullptr;      // RAW16 staging for mi_unet_infer_raw16 (grown on demand)
-    size_t raw_cap = 0;             // samples
-    uint16_t *h_raw = nullptr;      // pinned
+    // RAW16 staging for mi_unet_infer_raw16: a ring of (pinned host, device) buffer pairs, grown on demand, so the host copy
+    // of image i+1 into its pinned buffer overlaps the PCIe transfer and the preprocessing kernels of image i
+    static constexpr int RAW_RING = 3;
+    uint16_t *d_raw[RAW_RING] = {};
+    uint16_t *h_raw[RAW_RING] = {}; // pinned
+    hipEvent_t raw_done[RAW_RING] = {};   // the slot's transfer and kernels have completed
+    bool raw_busy[RAW_RING] = {};
+    size_t raw_cap = 0;             // samples per slot
     unsigned *d_mnmx = nullptr;     // [max_batch][2]
     float *d_ksplit = nullptr;      // split-K slabs of the Winograd kernel (small batches / deep levels only)
     size_t ksplit_bytes = 0;
@@ -908,21 +913,30 @@ int stage_raw16(mi_unet *h, const uint16_t *const *raws, const int *widths, cons
         const int w = widths[i], ht = heights[i];
         if (!raws[i] || w <= 0 || ht <= 0) return fail(MI_UNET_EARG, "RAW16 input: bad image description");
         const size_t n = (size_t)w * ht;
-        if (n > h->raw_cap) {                    // grow the staging pair (outside any captured region)
+        if (n > h->raw_cap) {                    // grow the staging ring (outside any captured region)
             HIP_TRY(hipStreamSynchronize(s));
-            if (h->d_raw) HIP_TRY(hipFree(h->d_raw));
-            if (h->h_raw) HIP_TRY(hipHostFree(h->h_raw));
-            h->d_raw = nullptr; h->h_raw = nullptr; h->raw_cap = 0;
-            HIP_TRY(hipMalloc(&h->d_raw, n * sizeof(uint16_t)));
-            HIP_TRY(hipHostMalloc(&h->h_raw, n * sizeof(uint16_t), hipHostMallocDefault));
+            for (int r = 0; r < mi_unet::RAW_RING; ++r) {
+                if (h->d_raw[r]) HIP_TRY(hipFree(h->d_raw[r]));
+                if (h->h_raw[r]) HIP_TRY(hipHostFree(h->h_raw[r]));
+                h->d_raw[r] = nullptr; h->h_raw[r] = nullptr; h->raw_busy[r] = false;
+            }
+            h->raw_cap = 0;
+            for (int r = 0; r < mi_unet::RAW_RING; ++r) {
+                HIP_TRY(hipMalloc(&h->d_raw[r], n * sizeof(uint16_t)));
+                HIP_TRY(hipHostMalloc(&h->h_raw[r], n * sizeof(uint16_t), hipHostMallocDefault));
+                if (!h->raw_done[r]) HIP_TRY(hipEventCreateWithFlags(&h->raw_done[r], hipEventDisableTiming));
+            }
             h->raw_cap = n;
         }
-        HIP_TRY(hipStreamSynchronize(s));        // the previous image's kernels must have consumed the staging buffer
-        memcpy(h->h_raw, raws[i], n * sizeof(uint16_t));
-        HIP_TRY(hipMemcpyAsync(h->d_raw, h->h_raw, n * sizeof(uint16_t), hipMemcpyHostToDevice, s));
-        hipError_t e = launch_minmax_u16(h->d_raw, n, h->d_mnmx + 2 * i, s);
-        if (e == hipSuccess) e = launch_resample_u8(h->d_raw, w, ht, h->d_mnmx + 2 * i, h->d_img + i * hw, h->cfg.width, h->cfg.height, s);
+        const int r = i % mi_unet::RAW_RING;
+        if (h->raw_busy[r]) { HIP_TRY(hipEventSynchronize(h->raw_done[r])); h->raw_busy[r] = false; }   // slot consumed
+        memcpy(h->h_raw[r], raws[i], n * sizeof(uint16_t));
+        HIP_TRY(hipMemcpyAsync(h->d_raw[r], h->h_raw[r], n * sizeof(uint16_t), hipMemcpyHostToDevice, s));
+        hipError_t e = launch_minmax_u16(h->d_raw[r], n, h->d_mnmx + 2 * i, s);
+        if (e == hipSuccess) e = launch_resample_u8(h->d_raw[r], w, ht, h->d_mnmx + 2 * i, h->d_img + i * hw, h->cfg.width, h->cfg.height, s);
         if (e != hipSuccess) return fail(MI_UNET_EHIP, std::string("preprocess launch: ") + hipGetErrorString(e));
+        HIP_TRY(hipEventRecord(h->raw_done[r], s));
+        h->raw_busy[r] = true;
     }
     return 0;
 }
@@ -1205,12 +1219,15 @@ void mi_unet_destroy(mi_unet_t *h)
     if (h->own_stream) (void)hipStreamSynchronize(h->own_stream);
     for (int i = 0; i < 8; ++i)
         if (h->d_cat[i]) (void)hipFree(h->d_cat[i]);
-    void *dev[] = { h->d_weights, h->d_lut, h->d_s0, h->d_s1, h->d_img, h->d_labels, h->d_logits, h->d_raw, h->d_mnmx, h->d_cont, h->d_ksplit };
+    void *dev[] = { h->d_weights, h->d_lut, h->d_s0, h->d_s1, h->d_img, h->d_labels, h->d_logits, h->d_raw[0], h->d_raw[1], h->d_raw[2], h->d_mnmx, h->d_cont, h->d_ksplit };
     for (void *p : dev)
         if (p) (void)hipFree(p);
     if (h->h_img) (void)hipHostFree(h->h_img);
     if (h->h_labels) (void)hipHostFree(h->h_labels);
-    if (h->h_raw) (void)hipHostFree(h->h_raw);
+    for (int r = 0; r < mi_unet::RAW_RING; ++r) {
+        if (h->h_raw[r]) (void)hipHostFree(h->h_raw[r]);
+        if (h->raw_done[r]) (void)hipEventDestroy(h->raw_done[r]);
+    }
     hipEvent_t evs[] = { h->tev0, h->tev1 };
     for (hipEvent_t e : evs)
         if (e) (void)hipEventDestroy(e);
