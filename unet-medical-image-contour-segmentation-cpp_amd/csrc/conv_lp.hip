@@ -21,15 +21,6 @@ namespace miunet {
 // The same kernel serves fp16 operands (BASELINE config 5's arithmetic): T = __bf16 or _Float16, 16 bits either way.
 template <typename T> struct LpVec { typedef T x8 __attribute__((ext_vector_type(8))); };
 
-template <typename T>
-__device__ __forceinline__ typename LpVec<T>::x8 pack_lp8(const f32x4 lo, const f32x4 hi)
-{
-    typename LpVec<T>::x8 r;
-    r[0] = (T)lo[0]; r[1] = (T)lo[1]; r[2] = (T)lo[2]; r[3] = (T)lo[3];
-    r[4] = (T)hi[0]; r[5] = (T)hi[1]; r[6] = (T)hi[2]; r[7] = (T)hi[3];
-    return r;
-}
-
 __device__ __forceinline__ f32x16 mfma_lp(LpVec<__bf16>::x8 a, LpVec<__bf16>::x8 b, f32x16 c)
 {
     return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
