@@ -61,6 +61,17 @@ def test_full_size_and_capacity_overflow():
         assert small[i] is None and few[i] is None
 
 
+def test_large_masks_bit_plane_grows_and_falls_back():
+    """The tracer walks an LDS bit plane of the mask: 32 KB at 512x512, 128 KB at 1024x1024 (the kernel's dynamic-LDS
+    opt-in has to grow inside one process), and masks past the LDS budget (1536x1024 = 192 KB) keep probing global memory."""
+    for h, w in ((256, 256), (1024, 1024), (1536, 1024)):
+        masks = np.stack([_blob_mask(31 + s, h, w, 6, 0.5) for s in range(2)])
+        with binding.Engine(h, w, base=16, levels=2, max_batch=2) as eng:
+            got = eng.extract_contours(masks, cap_points=400000, cap_contours=40000)
+        for i in range(2):
+            assert got[i] == orc.find_contours(masks[i]), (h, w, i)
+
+
 def test_segment_raw16_whole_device_half_of_the_pipeline():
     """RAW16 -> tile -> UNet -> argmax -> postprocess_mask -> mask_to_image -> contours, all on the device in one call;
     every output equals the oracle chain run stage by stage."""

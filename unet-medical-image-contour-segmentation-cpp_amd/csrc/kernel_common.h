@@ -23,7 +23,7 @@ __device__ __forceinline__ int xcd_remap(int bid, int nwg)
 template <typename K>
 inline hipError_t ensure_dynamic_lds(K kernel, size_t bytes)
 {
-    struct Slot { const void *fn; bool done[64]; };
+    struct Slot { const void *fn; size_t bytes[64]; };           // largest size opted in so far, per device
     static Slot slots[16] = {};
     const void *fn = reinterpret_cast<const void *>(kernel);
     int dev = 0;
@@ -33,10 +33,10 @@ inline hipError_t ensure_dynamic_lds(K kernel, size_t bytes)
     Slot *sl = nullptr;
     for (Slot &c : slots)
         if (c.fn == fn || c.fn == nullptr) { sl = &c; break; }
-    if (sl != nullptr && sl->fn == fn && sl->done[dev]) return hipSuccess;
+    if (sl != nullptr && sl->fn == fn && sl->bytes[dev] >= bytes) return hipSuccess;
     e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
     if (e != hipSuccess) return e;
-    if (sl != nullptr) { sl->fn = fn; sl->done[dev] = true; }       // table full: just set the attribute every time
+    if (sl != nullptr) { sl->fn = fn; sl->bytes[dev] = bytes; }     // table full: just set the attribute every time
     return hipSuccess;
 }
 
