@@ -31,12 +31,15 @@ __device__ __forceinline__ f32x16 mfma_lp(LpVec<_Float16>::x8 a, LpVec<_Float16>
 }
 
 // OUT_LP: the output tensor (and the pooled one) is 16-bit like the input; false = fp32 output (the layer in front of the head)
-template <typename T, int TAPS, int TH, int BN, bool NFAST, bool OUT_LP>
+// HEAD: the layer feeds the network's fp32 1x1 head + argmax (ConvArgs::head_w): the post-ReLU fp32 tile crosses LDS instead
+// of HBM (the staging images are dead by then), thread = pixel; `out` is never written.  Needs one n-tile (Cout <= BN).
+template <typename T, int TAPS, int TH, int BN, bool NFAST, bool OUT_LP, bool HEAD = false>
 __global__ __launch_bounds__(256, 2) void conv_mfma_bf16(const ConvArgs a, const int tiles_x, const int tiles_y,
                                                          const int m_tiles, const int nwg)
 {
     typedef typename LpVec<T>::x8 bf16x8;
     constexpr int ROW = KC_BF16 + 8;                     // bf16 elements per LDS row (80 bytes)
+    constexpr int HEAD_ROW = 64 + 4;                     // floats per pixel of the fused head's LDS tile
     constexpr int HALO = (TAPS == 9) ? 1 : 0;
     constexpr int PW = 32 + 2 * HALO, PH = TH + 2 * HALO, NPIX = PW * PH;
     constexpr int NA8 = NPIX * (KC_BF16 / 8);            // 8-channel pieces of the A patch
@@ -210,15 +213,51 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_bf16(const ConvArgs a, const
             for (int r = 0; r < 16; ++r) {
                 const int xr = (r & 3) + 8 * (r >> 2);
                 const float v = fmaxf(acc[i][j][r] + sh, relu_lo);
+                if constexpr (HEAD) {                     // pixel (wave*MT + i, xr + 4 lh) of the TH x 32 tile, channel n
+                    lds[((wave * MT + i) * 32 + xr + 4 * lh) * HEAD_ROW + n] = n_ok ? v : 0.f;
+                    continue;
+                }
                 const bool ok = interior || (yw + i < a.H && x0 + xr + 4 * lh < a.W);
                 const unsigned soff = (TAPS == 9) ? (unsigned)(i * a.W + xr) * pix_bytes : (unsigned)(2 * i * OW + 2 * xr) * pix_bytes;
                 store_out(out_rsrc, v, ok ? vbase : 0xFFFFFFFFu, soff);
             }
         }
     }
+    if constexpr (HEAD) {
+        static_assert(TAPS == 9 && TH * 32 == 256 && BN == 64 && !OUT_LP, "one pixel per thread, every channel in the workgroup");
+        float *const Wh = lds + 256 * HEAD_ROW;            // [classes][64]
+        if (tid < a.head_classes * 64) Wh[tid] = (tid & 63) < a.Cout ? a.head_w[(tid >> 6) * a.Cout + (tid & 63)] : 0.f;
+        __syncthreads();
+        f32x4 d4[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) d4[k] = f32x4{ 0.f, 0.f, 0.f, 0.f };
+        const float *yrow = lds + tid * HEAD_ROW;
+#pragma unroll
+        for (int c4 = 0; c4 < 16; ++c4) {
+            const f32x4 yv = *reinterpret_cast<const f32x4 *>(yrow + 4 * c4);
+#pragma unroll
+            for (int k = 0; k < 4; ++k)
+                if (k < a.head_classes) d4[k] += yv * *reinterpret_cast<const f32x4 *>(Wh + 64 * k + 4 * c4);
+        }
+        const int py = y0 + (tid >> 5), px = x0 + (tid & 31);
+        if (py < a.H && px < a.W) {
+            const size_t hw = (size_t)a.H * a.W, pin = (size_t)py * a.W + px;
+            float best = -3.402823466e+38f;
+            int idx = 0;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                if (k < a.head_classes) {
+                    const float d = ((d4[k].x + d4[k].y) + (d4[k].z + d4[k].w)) + a.head_b[k];
+                    if (a.head_logits != nullptr) a.head_logits[((size_t)b * a.head_classes + k) * hw + pin] = d;
+                    if (d > best) { best = d; idx = k; }          // first maximum wins (src/process.cpp:158-170)
+                }
+            }
+            a.head_labels[(size_t)b * hw + pin] = (uint8_t)idx;
+        }
+    }
 }
 
-template <typename T, int TAPS, int TH, int BN, bool NFAST, bool OUT_LP>
+template <typename T, int TAPS, int TH, int BN, bool NFAST, bool OUT_LP, bool HEAD = false>
 static hipError_t launch_bf16_cfg(const ConvArgs &a, hipStream_t s)
 {
     const int n_total = (TAPS == 9) ? a.Cout : 4 * a.Cout;
@@ -228,7 +267,7 @@ static hipError_t launch_bf16_cfg(const ConvArgs &a, hipStream_t s)
     const int nwg = m_tiles * n_tiles;
     constexpr int HALO = (TAPS == 9) ? 1 : 0;
     constexpr size_t lds = 2 * (size_t)(KC_BF16 + 8) * ((32 + 2 * HALO) * (TH + 2 * HALO) + TAPS * BN);
-    auto kern = conv_mfma_bf16<T, TAPS, TH, BN, NFAST, OUT_LP>;
+    auto kern = conv_mfma_bf16<T, TAPS, TH, BN, NFAST, OUT_LP, HEAD>;
     if (hipError_t e = ensure_dynamic_lds(kern, lds); e != hipSuccess) return e;
     hipLaunchKernelGGL(kern, dim3(nwg), dim3(256), lds, s, a, tiles_x, tiles_y, m_tiles, nwg);
     return hipGetLastError();
@@ -237,6 +276,11 @@ static hipError_t launch_bf16_cfg(const ConvArgs &a, hipStream_t s)
 hipError_t launch_conv3x3_bf16(const ConvArgs &a, hipStream_t s)
 {
     if (a.Cin % 8 || a.ldc % 8 || a.CoutPad % NPAD) return hipErrorInvalidValue;
+    if (a.head_w != nullptr) {
+        if (a.out_lp || a.Cout > 64 || a.head_classes < 1 || a.head_classes > 4 || a.pool_out != nullptr || a.head_labels == nullptr)
+            return hipErrorInvalidValue;
+        return launch_bf16_cfg<__bf16, 9, 8, 64, false, false, true>(a, s);
+    }
     return a.out_lp ? launch_bf16_cfg<__bf16, 9, 8, 64, false, true>(a, s) : launch_bf16_cfg<__bf16, 9, 8, 64, false, false>(a, s);
 }
 
@@ -249,6 +293,11 @@ hipError_t launch_convT2x2_bf16(const ConvArgs &a, hipStream_t s)
 hipError_t launch_conv3x3_fp16(const ConvArgs &a, hipStream_t s)
 {
     if (a.Cin % 8 || a.ldc % 8 || a.CoutPad % NPAD) return hipErrorInvalidValue;
+    if (a.head_w != nullptr) {
+        if (a.out_lp || a.Cout > 64 || a.head_classes < 1 || a.head_classes > 4 || a.pool_out != nullptr || a.head_labels == nullptr)
+            return hipErrorInvalidValue;
+        return launch_bf16_cfg<_Float16, 9, 8, 64, false, false, true>(a, s);
+    }
     return a.out_lp ? launch_bf16_cfg<_Float16, 9, 8, 64, false, true>(a, s) : launch_bf16_cfg<_Float16, 9, 8, 64, false, false>(a, s);
 }
 

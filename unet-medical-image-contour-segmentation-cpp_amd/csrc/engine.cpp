@@ -509,7 +509,9 @@ int build_plan(mi_unet *h, const HostWeights &hw)
         const int last = (int)h->plan.size() - 1;
         Step &lc = h->plan[last - 1];
         if (lc.kind == Step::CONV) lc.feeds_head = true;
-        if (!(fh && fh[0] == '0') && lc.kind == Step::CONV && lc.a.wpk4 != nullptr && lc.a.Cout <= 64 && c.classes <= 4 &&
+        const bool lp_algo = h->algo == MI_UNET_CONV_BF16 || h->algo == MI_UNET_CONV_FP16;
+        if (!(fh && fh[0] == '0') && lc.kind == Step::CONV && (lc.a.wpk4 != nullptr || (lp_algo && lc.a.Cout > 32)) && lc.a.Cout <= 64 && c.classes <= 4 &&   // (narrower layers: the
+            // fused head would read a half-empty 64-channel tile; measured slower than the stand-alone kernel at base 32)
             lc.a.pool_out == nullptr)
             lc.head_step = last;
     }
@@ -582,8 +584,14 @@ int launch_plan(mi_unet *h, const uint8_t *d_imgs, int B, uint8_t *d_labels, flo
             ConvArgs a = st.a; a.B = B;
             a.ksplit_ws = h->d_ksplit; a.ksplit_ws_bytes = h->ksplit_bytes;
             a.out_lp = (lp_kind != 0 && !st.feeds_head) ? 1 : 0;
-            if (h->algo == MI_UNET_CONV_BF16) { kname = "conv3x3_bf16"; e = launch_conv3x3_bf16(a, s); }
-            else if (h->algo == MI_UNET_CONV_FP16) { kname = "conv3x3_fp16"; e = launch_conv3x3_fp16(a, s); }
+            if (lp_kind != 0 && st.head_step >= 0) {   // fused 1x1 head + argmax: this layer's activations never reach HBM
+                const Step &hd = h->plan[st.head_step];
+                a.head_w = hd.w; a.head_b = hd.shift; a.head_classes = hd.Cout;
+                a.head_logits = d_logits; a.head_labels = d_labels;
+                head_done = true;
+            }
+            if (h->algo == MI_UNET_CONV_BF16) { kname = head_done ? "conv3x3_bf16+head" : "conv3x3_bf16"; e = launch_conv3x3_bf16(a, s); }
+            else if (h->algo == MI_UNET_CONV_FP16) { kname = head_done ? "conv3x3_fp16+head" : "conv3x3_fp16"; e = launch_conv3x3_fp16(a, s); }
             else if (h->algo == MI_UNET_CONV_WINOGRAD16) { kname = "conv3x3_wino16"; e = launch_conv3x3_wino16(a, s); }
             else if (h->algo == MI_UNET_CONV_WINOGRAD) {
                 // F(4x4,3x3) where it was packed (Cout % 64 == 0) and its 16x16-pixel x 128-channel grid fills the chip;
