@@ -41,9 +41,11 @@ typedef struct mi_unet_config {
     int classes;     /* 3 (src/process.cpp:162) */
     int max_batch;   /* images processed per micro-batch; device buffers are sized for this */
     int device;      /* HIP device ordinal (the reference uses implicit device 0) */
-    int conv_algo;   /* 3x3 convolution algorithm, both exact fp32 arithmetic on v_mfma_f32_32x32x2_f32:
+    int conv_algo;   /* 3x3 convolution algorithm, fp32 arithmetic on the fp32 MFMA unless stated:
                         MI_UNET_CONV_AUTO (environment MIUNET_CONV_ALGO=direct|winograd|winograd16|bf16|fp16, else the default),
-                        MI_UNET_CONV_DIRECT (implicit GEMM, 9 taps), MI_UNET_CONV_WINOGRAD (F(2x2,3x3), 2.25x fewer MACs) */
+                        MI_UNET_CONV_DIRECT (implicit GEMM, 9 taps), MI_UNET_CONV_WINOGRAD (the default: Winograd F(4x4,3x3), 4x
+                        fewer MACs, on every layer whose grid fills the chip or can split K, F(2x2,3x3) on the rest; the
+                        transposed convs as four per-tap GEMMs; head fused into the last conv.  DESIGN.md 4.2-4.4) */
 } mi_unet_config;
 
 #define MI_UNET_CONV_AUTO 0
@@ -51,8 +53,8 @@ typedef struct mi_unet_config {
 #define MI_UNET_CONV_WINOGRAD 2
 #define MI_UNET_CONV_WINOGRAD16 3   /* same algorithm, 8-wave tiling on v_mfma_f32_16x16x4_f32 (two waves per SIMD) */
 #define MI_UNET_CONV_BF16 4         /* BASELINE config 3: bf16 conv operands (weights packed bf16, activations rounded to
-                                       bf16 as they are staged), fp32 accumulate on v_mfma_f32_32x32x16_bf16; activations
-                                       stay fp32 in HBM.  NOT the fp32 metric: logits follow the bf16-operand oracle. */
+                                       bf16 once by the kernel that produces them and kept bf16 in HBM), fp32 accumulate on
+                                       v_mfma_f32_32x32x16_bf16.  NOT the fp32 metric: logits follow the bf16-operand oracle. */
 #define MI_UNET_CONV_FP16 5         /* BASELINE config 5's arithmetic: the same kernels with IEEE half operands
                                        (v_mfma_f32_32x32x16_f16), fp32 accumulate */
 #define MI_UNET_CONV_DEFAULT MI_UNET_CONV_WINOGRAD
