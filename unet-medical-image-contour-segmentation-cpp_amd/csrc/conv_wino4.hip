@@ -39,6 +39,13 @@ __device__ __forceinline__ f32x4 pk_sub(const f32x4 a, const f32x4 b)
     return __builtin_shufflevector(lo, hi, 0, 1, 2, 3);
 }
 
+__device__ __forceinline__ f32x2 pk_sub2(const f32x2 a, const f32x2 b)
+{
+    f32x2 r;
+    asm("v_pk_add_f32 %0, %1, %2 neg_lo:[0,1] neg_hi:[0,1]" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+
 // 72 accumulators of 4 registers do not fit the 256 AGPRs: hipcc then shuttles the overflow through AGPRs around every
 // MFMA (64 v_accvgpr moves per chunk).  The last four positions of the two-block kernel therefore use the VGPR form of the
 // instruction directly; their results are only ever re-read as SrcC of the next MFMA on the same registers (the
@@ -375,57 +382,65 @@ __global__ __launch_bounds__(256, 1) void conv3x3_wino4_f32(const ConvArgs a, co
                     pcol[r][1] = e_bx0 + 4 * r + 3 < a.W ? pbase : 0xFFFFFFFFu;
                 }
             }
-            f32x4 t[4][6];
+            // two tile columns (r = 2 h2, 2 h2 + 1) at a time: the same packed instructions as four at once, half the live
+            // temporaries (the epilogue runs with every accumulator still resident)
 #pragma unroll
-            for (int nu = 0; nu < 6; ++nu) {
-                const f32x4 m0 = acc[nu][blk], m1 = acc[6 + nu][blk], m2 = acc[12 + nu][blk], m3 = acc[18 + nu][blk],
-                            m4 = acc[24 + nu][blk], m5 = acc[30 + nu][blk];
-                const f32x4 s12 = m1 + m2, d12 = pk_sub(m1, m2), s34 = m3 + m4, d34 = pk_sub(m3, m4);
-                t[0][nu] = m0 + s12 + s34;
-                t[1][nu] = d12 + 2.f * d34;
-                t[2][nu] = s12 + 4.f * s34;
-                t[3][nu] = d12 + 8.f * d34 + m5;
-            }
-            f32x4 carry0, carry1;                     // horizontal maxima of the even row, for the 2x2 pooling
+            for (int h2 = 0; h2 < 2; ++h2) {
+                auto half = [&](const f32x4 &v) { return h2 ? v.hi : v.lo; };
+                f32x2 t[4][6];
 #pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                const f32x4 s12 = t[i][1] + t[i][2], d12 = pk_sub(t[i][1], t[i][2]), s34 = t[i][3] + t[i][4], d34 = pk_sub(t[i][3], t[i][4]);
-                f32x4 y[4];
-                y[0] = t[i][0] + s12 + s34;
-                y[1] = d12 + 2.f * d34;
-                y[2] = s12 + 4.f * s34;
-                y[3] = d12 + 8.f * d34 + t[i][5];
-                const bool row_ok = INTERIOR || oy + i < a.H;          // per-lane (kq) row predicate of an edge workgroup
+                for (int nu = 0; nu < 6; ++nu) {
+                    const f32x2 m0 = half(acc[nu][blk]), m1 = half(acc[6 + nu][blk]), m2 = half(acc[12 + nu][blk]),
+                                m3 = half(acc[18 + nu][blk]), m4 = half(acc[24 + nu][blk]), m5 = half(acc[30 + nu][blk]);
+                    const f32x2 s12 = m1 + m2, d12 = pk_sub2(m1, m2), s34 = m3 + m4, d34 = pk_sub2(m3, m4);
+                    t[0][nu] = m0 + s12 + s34;
+                    t[1][nu] = d12 + 2.f * d34;
+                    t[2][nu] = s12 + 4.f * s34;
+                    t[3][nu] = d12 + 8.f * d34 + m5;
+                }
+                f32x2 carry0, carry1;                 // horizontal maxima of the even row, for the 2x2 pooling
 #pragma unroll
-                for (int k = 0; k < 4; ++k)
+                for (int i = 0; i < 4; ++i) {
+                    const f32x2 s12 = t[i][1] + t[i][2], d12 = pk_sub2(t[i][1], t[i][2]), s34 = t[i][3] + t[i][4], d34 = pk_sub2(t[i][3], t[i][4]);
+                    f32x2 y[4];
+                    y[0] = t[i][0] + s12 + s34;
+                    y[1] = d12 + 2.f * d34;
+                    y[2] = s12 + 4.f * s34;
+                    y[3] = d12 + 8.f * d34 + t[i][5];
+                    const bool row_ok = INTERIOR || oy + i < a.H;      // per-lane (kq) row predicate of an edge workgroup
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-                        const float v = fmaxf(y[k][r], relu_lo);
-                        y[k][r] = v;
-                        if constexpr (HEAD) {         // pixel (4 kq + i, 4 r + k) of the 16x16 block, channel ncol -> LDS
-                            lds[((4 * kq + i) * 16 + 4 * r + k) * HEAD_ROW + ncol] = v;
-                            continue;
+                    for (int k = 0; k < 4; ++k)
+#pragma unroll
+                        for (int rr = 0; rr < 2; ++rr) {
+                            const int r = 2 * h2 + rr;
+                            const float v = fmaxf(y[k][rr], relu_lo);
+                            y[k][rr] = v;
+                            if constexpr (HEAD) {     // pixel (4 kq + i, 4 r + k) of the 16x16 block, channel ncol -> LDS
+                                lds[((4 * kq + i) * 16 + 4 * r + k) * HEAD_ROW + ncol] = v;
+                                continue;
+                            }
+                            unsigned voff = vbase;
+                            if constexpr (!INTERIOR) voff = row_ok ? vcol[r][k] : 0xFFFFFFFFu;
+                            __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), out_rsrc, voff,
+                                                                  i * row_bytes + (4 * r + k) * pix_bytes, 0);
                         }
-                        unsigned voff = vbase;
-                        if constexpr (!INTERIOR) voff = row_ok ? vcol[r][k] : 0xFFFFFFFFu;
-                        __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), out_rsrc, voff,
-                                                              i * row_bytes + (4 * r + k) * pix_bytes, 0);
-                    }
-                if (!HEAD && do_pool) {
-                    f32x4 hm0, hm1;                   // horizontal maxima of this row: pooled columns 2r and 2r + 1
+                    if (!HEAD && do_pool) {
+                        f32x2 hm0, hm1;               // horizontal maxima of this row: pooled columns 2r and 2r + 1
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) { hm0[r] = fmaxf(y[0][r], y[1][r]); hm1[r] = fmaxf(y[2][r], y[3][r]); }
-                    if ((i & 1) == 0) { carry0 = hm0; carry1 = hm1; }
-                    else {
+                        for (int rr = 0; rr < 2; ++rr) { hm0[rr] = fmaxf(y[0][rr], y[1][rr]); hm1[rr] = fmaxf(y[2][rr], y[3][rr]); }
+                        if ((i & 1) == 0) { carry0 = hm0; carry1 = hm1; }
+                        else {
 #pragma unroll
-                        for (int r = 0; r < 4; ++r) {
-                            const float p0 = fmaxf(hm0[r], carry0[r]), p1 = fmaxf(hm1[r], carry1[r]);
-                            unsigned v0 = pbase, v1 = pbase;
-                            if constexpr (!INTERIOR) { v0 = row_ok ? pcol[r][0] : 0xFFFFFFFFu; v1 = row_ok ? pcol[r][1] : 0xFFFFFFFFu; }
-                            __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, p0), pool_rsrc, v0,
-                                                                  (i >> 1) * prow_bytes + (2 * r) * ppix_bytes, 0);
-                            __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, p1), pool_rsrc, v1,
-                                                                  (i >> 1) * prow_bytes + (2 * r + 1) * ppix_bytes, 0);
+                            for (int rr = 0; rr < 2; ++rr) {
+                                const int r = 2 * h2 + rr;
+                                const float p0 = fmaxf(hm0[rr], carry0[rr]), p1 = fmaxf(hm1[rr], carry1[rr]);
+                                unsigned v0 = pbase, v1 = pbase;
+                                if constexpr (!INTERIOR) { v0 = row_ok ? pcol[r][0] : 0xFFFFFFFFu; v1 = row_ok ? pcol[r][1] : 0xFFFFFFFFu; }
+                                __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, p0), pool_rsrc, v0,
+                                                                      (i >> 1) * prow_bytes + (2 * r) * ppix_bytes, 0);
+                                __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, p1), pool_rsrc, v1,
+                                                                      (i >> 1) * prow_bytes + (2 * r + 1) * ppix_bytes, 0);
+                            }
                         }
                     }
                 }
