@@ -148,7 +148,51 @@ int mi_unet_get_kernel_stats(mi_unet_t *h, mi_unet_kernel_stat *stats, int cap, 
 int mi_unet_layer_debug(int device, const char *op, const float *in, int B, int H, int W, int Cin, const float *w,
                         const float *scale, const float *shift, int Cout, int relu, float *out);
 
+/* A second context on the SAME device that shares the source engine's weight blob (no second copy, no re-packing) but
+ * owns its activation buffers, stream and graphs -- the counterpart of the reference's per-thread TensorRTContext over one
+ * shared ICudaEngine (include/process.h:13-26, src/process.cpp:15, :69).  max_batch <= 0 keeps the source's.  The weights
+ * stay alive until the last handle that shares them is destroyed, in any order. */
+int mi_unet_clone(const mi_unet_t *src, int max_batch, mi_unet_t **out);
+
 void mi_unet_destroy(mi_unet_t *h);
+
+/* ---- Multi-device group (the slot is the reference's sequential file loop, src/main.cpp:148-164) -------------
+ * One engine handle + one host worker thread per device inside ONE process.  The path shards by image: a batch of B
+ * images is cut into contiguous ranges (rank r of R owns [r*q + min(r, B%R), ...), the first B%R ranks one image more) and
+ * every rank runs its range independently -- no collective inside the forward pass.  Two exchange steps exist:
+ *   weights : parsed, BN-folded and packed ONCE on the host, uploaded to the first device, then sent to the other devices
+ *             device-to-device: ncclBroadcast over xGMI (RCCL, loaded with dlopen when the group spans > 1 distinct device)
+ *             or a peer copy when RCCL is unavailable / two ranks share a device;
+ *   labels  : MI_UNET_GATHER_HOST (default): every rank copies its own range straight into the caller's host buffer (its own
+ *             PCIe link, no collective);  MI_UNET_GATHER_XGMI: grouped ncclSend / ncclRecv of the u8 label maps into the
+ *             first device (7 concurrent point-to-point transfers on an 8-GPU node), then one D2H.
+ * `devices` lists HIP ordinals, one rank each (a repeated ordinal puts two ranks on one GPU: a test configuration, peer-copy
+ * weights, HOST gather only); devices == NULL means ordinals cfg->device .. cfg->device + n_devices - 1, and n_devices <= 0
+ * means every visible device.  cfg->max_batch is per rank.  N > 1 distinct devices has never run on hardware here. */
+typedef struct mi_unet_group mi_unet_group_t;
+#define MI_UNET_GATHER_HOST 0
+#define MI_UNET_GATHER_XGMI 1
+int mi_unet_group_create(const mi_unet_config *cfg, const int *devices, int n_devices, mi_unet_group_t **out);
+int mi_unet_group_size(const mi_unet_group_t *g);
+mi_unet_t *mi_unet_group_handle(mi_unet_group_t *g, int rank);            /* rank's engine (owned by the group) */
+int mi_unet_group_load_weights(mi_unet_group_t *g, const char *path);
+int mi_unet_group_load_weights_from_memory(mi_unet_group_t *g, const void *blob, size_t len);
+int mi_unet_group_set_gather(mi_unet_group_t *g, int mode);               /* EARG when XGMI is asked for without RCCL */
+int mi_unet_group_set_postprocess(mi_unet_group_t *g, int on);
+/* "rccl" or "peer-copy": how the weights reached ranks > 0; and the gather mode in force */
+const char *mi_unet_group_weight_transport(const mi_unet_group_t *g);
+int mi_unet_group_gather(const mi_unet_group_t *g);
+/* Sharded forms of mi_unet_infer_u8 / mi_unet_infer_raw16 / mi_unet_segment_raw16: same arguments, same results, the batch
+ * split across the group's ranks. */
+int mi_unet_group_infer_u8(mi_unet_group_t *g, const uint8_t *imgs, int B, uint8_t *labels, float *logits);
+int mi_unet_group_infer_raw16(mi_unet_group_t *g, const uint16_t *const *raws, const int *widths, const int *heights, int B,
+                              uint8_t *tiles, uint8_t *labels, float *logits);
+int mi_unet_group_segment_raw16(mi_unet_group_t *g, const uint16_t *const *raws, const int *widths, const int *heights, int B,
+                                uint8_t *tiles, uint8_t *masks, int32_t *xy, int cap_points, int32_t *start, int cap_contours,
+                                int32_t *counts);
+void mi_unet_group_destroy(mi_unet_group_t *g);
+/* The split itself (pure host arithmetic, needs no device): rank's range [*lo, *hi) of n_items over `world` ranks. */
+int mi_unet_shard_range(int n_items, int rank, int world, int *lo, int *hi);
 
 /* Message of the last failing call on this thread ("" if none). */
 const char *mi_unet_last_error(void);

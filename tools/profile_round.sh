@@ -1,17 +1,40 @@
 #!/bin/bash
 # Regenerates the judged profile artefacts of a round on the GPU box (run through gpurun from the repo root):
-#   tools/profile_round.sh r01c
-# bench line, per-layer table, rocprofv3 kernel-trace stats of the same bench command, and the two PMC passes
-# (FETCH_SIZE, WRITE_SIZE: separate runs, kernel-trace only) summarised by profiles/summarize_pmc.py.
-set -e
-tag=${1:-r01c}
+#   tools/profile_round.sh r02 [fp32|bf16|all]
+# bench line + per-layer table, rocprofv3 kernel-trace stats of the same bench command, and the PMC passes (FETCH_SIZE,
+# WRITE_SIZE, SQ MFMA-busy group: separate runs, kernel-trace only) summarised by profiles/summarize_pmc.py.
+# The program sits directly behind `--` (the profiler's preloaded library has initialised the GPU by then: no env/bash hop).
+set -e -o pipefail
+tag=${1:-r02}
+what=${2:-all}
 out=gpurun_out/$tag
 mkdir -p $out
 cd /tmp && export TMPDIR=/tmp && cd - > /dev/null
-python bench.py --per-layer > $out/bench.json 2> $out/per_layer.txt
-rocprofv3 --kernel-trace --stats --output-format csv -d $out/trace -o run -- python bench.py --no-cpu-baseline > $out/bench_under_rocprof.json 2> $out/rocprof.log
-rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $out/pmc_fetch -o run -- python bench.py --no-cpu-baseline --steps 3 --warmup 1 > /dev/null 2>> $out/rocprof.log
-rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $out/pmc_write -o run -- python bench.py --no-cpu-baseline --steps 3 --warmup 1 > /dev/null 2>> $out/rocprof.log
-find $out -name "*kernel_stats.csv" -exec cp {} $out/kernel_stats.csv \;
-python profiles/summarize_pmc.py $(find $out/pmc_fetch -name "*counter_collection.csv") $(find $out/pmc_write -name "*counter_collection.csv") $out/pmc_traffic.json > /dev/null
+SQ="SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_MFMA SQ_VALU_MFMA_COEXEC_CYCLES"
+
+passes() {   # $1 = name, rest = bench arguments
+    name=$1; shift
+    rocprofv3 --kernel-trace --stats --output-format csv -d $out/${name}_trace -o run -- python bench.py --no-cpu-baseline --no-extras "$@" > $out/${name}_bench_under_rocprof.json 2> $out/${name}_rocprof.log
+    find $out/${name}_trace -name "*kernel_stats.csv" -exec cp {} $out/${name}_kernel_stats.csv \;
+    echo "$name: kernel trace done"
+    rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $out/${name}_pmc_fetch -o run -- python bench.py --no-cpu-baseline --no-extras --steps 3 --warmup 1 "$@" > /dev/null 2>> $out/${name}_rocprof.log
+    echo "$name: FETCH_SIZE done"
+    rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $out/${name}_pmc_write -o run -- python bench.py --no-cpu-baseline --no-extras --steps 3 --warmup 1 "$@" > /dev/null 2>> $out/${name}_rocprof.log
+    echo "$name: WRITE_SIZE done"
+    rocprofv3 --pmc $SQ --kernel-trace --output-format csv -d $out/${name}_pmc_sq -o run -- python bench.py --no-cpu-baseline --no-extras --steps 3 --warmup 1 "$@" > /dev/null 2>> $out/${name}_rocprof.log
+    echo "$name: SQ done"
+    python profiles/summarize_pmc.py --fetch $(find $out/${name}_pmc_fetch -name "*counter_collection.csv") \
+        --write $(find $out/${name}_pmc_write -name "*counter_collection.csv") --sq $(find $out/${name}_pmc_sq -name "*counter_collection.csv") \
+        --command "python bench.py --no-cpu-baseline --no-extras --steps 3 --warmup 1 $*" --out $out/pmc_${name}.json > /dev/null
+}
+
+if [ "$what" = "fp32" ] || [ "$what" = "all" ]; then
+    python bench.py --per-layer > $out/bench.json 2> $out/per_layer.txt
+    echo "bench done"
+    passes fp32
+fi
+if [ "$what" = "bf16" ] || [ "$what" = "all" ]; then
+    python bench.py --conv-algo bf16 --batch 128 --steps 5 --no-cpu-baseline --no-extras --per-layer > $out/bf16_bench.json 2> $out/bf16_per_layer.txt
+    passes bf16 --conv-algo bf16 --batch 128
+fi
 ls -la $out

@@ -10,10 +10,12 @@
 #include <cstdlib>
 #include <cstring>
 #include <fstream>
+#include <memory>
 #include <string>
 #include <vector>
 
 #include "../../include/mi_unet.h"
+#include "engine_internal.h"
 #include "kernels.h"
 
 using namespace miunet;
@@ -63,7 +65,10 @@ struct mi_unet {
     int wino4_min_wg = 256;         // MIUNET_WINO4_MIN_WG: smallest grid the F(4x4,3x3) kernel takes (else F(2x2) + split-K)
     bool wino4_splitk = true;       // MIUNET_WINO4_SPLITK=0: small grids go to the F(2x2) kernel's split-K instead
     // device memory
-    float *d_weights = nullptr;     // one blob: every packed tensor (single allocation -> one broadcast / one free)
+    // one blob: every packed tensor (single allocation -> one broadcast / one free).  Owned by `weights`, which clones of
+    // this handle share (mi_unet_clone: the reference's engine is shared by its per-thread contexts, src/process.cpp:15, :69)
+    std::shared_ptr<DeviceWeights> weights;
+    float *d_weights = nullptr;     // = weights->d
     size_t weight_floats = 0;
     float *d_lut = nullptr;         // 256 floats: i / 255.0f
     float *d_cat[8]{};              // concat buffers [Bm][h_i][w_i][2*ch_i]
@@ -261,14 +266,6 @@ void pack_convT_bf16(const float *w, int cin, int cout, uint16_t *dst, size_t np
                 dst[((size_t)(ci / KC_BF16) * npad + (size_t)k * cout + co) * KC_BF16 + ci % KC_BF16] =
                     cvt(w[((size_t)ci * cout + co) * 4 + k]);
 }
-
-struct HostWeights {
-    std::vector<float> blob;                    // packed, device layout
-    struct Off { size_t w, shift, w4; };       // w4: F(4x4,3x3) packing of the same layer (0 = none)
-    std::vector<Off> conv;                      // per 3x3 conv in file order (first one = FIRST layer layout)
-    std::vector<Off> convT;
-    Off head{};
-};
 
 // workgroups the per-tap kernel would launch (its tiles are large: MB rows x 32 pixels x up to 512 channels); single images
 // leave the deep levels with a few dozen of them, and the direct kernel's 64-wide column tiles fill the chip better there
@@ -679,6 +676,59 @@ int check_handle(mi_unet *h, bool need_weights)
 
 }  // namespace
 
+namespace miunet {
+
+DeviceWeights::~DeviceWeights()
+{
+    if (d) {
+        int cur = 0;
+        const bool have = hipGetDevice(&cur) == hipSuccess;
+        (void)hipSetDevice(device);
+        (void)hipFree(d);
+        if (have) (void)hipSetDevice(cur);
+    }
+}
+
+int engine_fail(int code, const std::string &msg) { return fail(code, msg); }
+
+int engine_pack_weights(const mi_unet_config &cfg, int algo, const void *blob, size_t len, HostWeights &hw)
+{
+    return build_host_weights(cfg, algo, blob, len, hw);
+}
+
+int engine_adopt_weights(mi_unet_t *h, const HostWeights &hw, bool upload)
+{
+    if (int rc = check_handle(h, false)) return rc;
+    HIP_TRY(hipSetDevice(h->cfg.device));
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    for (auto &g : h->graphs)
+        if (g.exec) (void)hipGraphExecDestroy(g.exec);
+    h->graphs.clear();
+    h->weights_loaded = false;
+    h->weights.reset();
+    h->d_weights = nullptr;
+    auto dw = std::make_shared<DeviceWeights>();
+    dw->device = h->cfg.device;
+    dw->floats = hw.blob.size();
+    HIP_TRY(hipMalloc(&dw->d, sizeof(float) * hw.blob.size()));
+    if (upload) HIP_TRY(hipMemcpy(dw->d, hw.blob.data(), sizeof(float) * hw.blob.size(), hipMemcpyHostToDevice));
+    dw->layout.conv = hw.conv; dw->layout.convT = hw.convT; dw->layout.head = hw.head;
+    h->weights = dw;
+    h->d_weights = dw->d;
+    h->weight_floats = dw->floats;
+    if (int rc = build_plan(h, dw->layout)) return rc;
+    h->weights_loaded = true;
+    return MI_UNET_OK;
+}
+
+float *engine_weight_ptr(mi_unet_t *h) { return h ? h->d_weights : nullptr; }
+size_t engine_weight_floats(const mi_unet_t *h) { return h ? h->weight_floats : 0; }
+int engine_algo(const mi_unet_t *h) { return h->algo; }
+const mi_unet_config &engine_config(const mi_unet_t *h) { return h->cfg; }
+hipStream_t engine_stream(const mi_unet_t *h) { return h->stream; }
+
+}  // namespace miunet
+
 extern "C" {
 
 const char *mi_unet_last_error(void) { return g_err.c_str(); }
@@ -782,17 +832,7 @@ int mi_unet_load_weights_from_memory(mi_unet_t *h, const void *blob, size_t len)
     if (!blob) return fail(MI_UNET_EARG, "null weight blob");
     HostWeights hw;
     if (int rc = build_host_weights(h->cfg, h->algo, blob, len, hw)) return rc;
-    HIP_TRY(hipSetDevice(h->cfg.device));
-    for (auto &g : h->graphs)
-        if (g.exec) (void)hipGraphExecDestroy(g.exec);
-    h->graphs.clear();
-    if (h->d_weights) { HIP_TRY(hipFree(h->d_weights)); h->d_weights = nullptr; }
-    h->weight_floats = hw.blob.size();
-    HIP_TRY(hipMalloc(&h->d_weights, sizeof(float) * hw.blob.size()));
-    HIP_TRY(hipMemcpy(h->d_weights, hw.blob.data(), sizeof(float) * hw.blob.size(), hipMemcpyHostToDevice));
-    if (int rc = build_plan(h, hw)) return rc;
-    h->weights_loaded = true;
-    return MI_UNET_OK;
+    return engine_adopt_weights(h, hw, /*upload=*/true);
 }
 
 int mi_unet_load_weights(mi_unet_t *h, const char *path)
@@ -806,6 +846,26 @@ int mi_unet_load_weights(mi_unet_t *h, const char *path)
     std::vector<char> buf((size_t)sz);
     if (!f.read(buf.data(), sz)) return fail(MI_UNET_EFILE, std::string("cannot read ") + path);
     return mi_unet_load_weights_from_memory(h, buf.data(), buf.size());
+}
+
+int mi_unet_clone(const mi_unet_t *src, int max_batch, mi_unet_t **out)
+{
+    if (!src || !out) return fail(MI_UNET_EARG, "mi_unet_clone: null argument");
+    *out = nullptr;
+    if (!src->weights_loaded || !src->weights) return fail(MI_UNET_ESTATE, "mi_unet_clone: the source engine has no weights yet");
+    mi_unet_config cfg = src->cfg;
+    if (max_batch > 0) cfg.max_batch = max_batch;
+    cfg.conv_algo = src->algo;                       // the resolved algorithm: the shared blob is packed for it
+    mi_unet_t *h = nullptr;
+    if (int rc = mi_unet_create(&cfg, &h)) return rc;
+    h->fuse_pool = src->fuse_pool; h->wino4_min_wg = src->wino4_min_wg; h->wino4_splitk = src->wino4_splitk;
+    h->weights = src->weights;                       // shared: freed with the last handle that holds it
+    h->d_weights = h->weights->d;
+    h->weight_floats = h->weights->floats;
+    if (int rc = build_plan(h, h->weights->layout)) { mi_unet_destroy(h); return rc; }
+    h->weights_loaded = true;
+    *out = h;
+    return MI_UNET_OK;
 }
 
 int mi_unet_infer_u8_device(mi_unet_t *h, const uint8_t *d_imgs, int B, uint8_t *d_labels, float *d_logits)
@@ -1227,7 +1287,7 @@ void mi_unet_destroy(mi_unet_t *h)
     if (h->own_stream) (void)hipStreamSynchronize(h->own_stream);
     for (int i = 0; i < 8; ++i)
         if (h->d_cat[i]) (void)hipFree(h->d_cat[i]);
-    void *dev[] = { h->d_weights, h->d_lut, h->d_s0, h->d_s1, h->d_img, h->d_labels, h->d_logits, h->d_raw[0], h->d_raw[1], h->d_raw[2], h->d_mnmx, h->d_cont, h->d_ksplit };
+    void *dev[] = { h->d_lut, h->d_s0, h->d_s1, h->d_img, h->d_labels, h->d_logits, h->d_raw[0], h->d_raw[1], h->d_raw[2], h->d_mnmx, h->d_cont, h->d_ksplit };
     for (void *p : dev)
         if (p) (void)hipFree(p);
     if (h->h_img) (void)hipHostFree(h->h_img);

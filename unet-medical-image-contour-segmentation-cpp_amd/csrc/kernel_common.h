@@ -2,6 +2,8 @@
 #pragma once
 #include <hip/hip_runtime.h>
 
+#include <mutex>
+
 #include "kernels.h"
 
 namespace miunet {
@@ -25,6 +27,8 @@ inline hipError_t ensure_dynamic_lds(K kernel, size_t bytes)
 {
     struct Slot { const void *fn; size_t bytes[64]; };           // largest size opted in so far, per device
     static Slot slots[16] = {};
+    static std::mutex guard;                                     // engines of different host threads launch concurrently
+    std::lock_guard<std::mutex> lk(guard);
     const void *fn = reinterpret_cast<const void *>(kernel);
     int dev = 0;
     hipError_t e = hipGetDevice(&dev);

@@ -204,7 +204,13 @@ class Engine:
         _check(lib().mi_unet_infer_u8_device(self._h, C.c_void_p(d_imgs_ptr), b, C.c_void_p(d_labels_ptr),
                                              C.c_void_p(d_logits_ptr) if d_logits_ptr else None))
 
-    def set_stream(self, stream_ptr: int):
+    def set_stream(self, stream_ptr: int, reset: bool = False):
+        """Run on the caller's hipStream_t.  Handle 0 is the legacy default stream, which mi_unet_set_stream reads as
+        "restore the engine's own (non-blocking) stream": work on it is NOT ordered against the default stream, so a
+        zero handle is only accepted with reset=True (the caller says that is what they mean)."""
+        if not stream_ptr and not reset:
+            raise ValueError("stream handle 0 = restore the engine's own stream; pass reset=True or a non-default stream "
+                             "(e.g. torch.cuda.Stream(dev).cuda_stream)")
         _check(lib().mi_unet_set_stream(self._h, C.c_void_p(stream_ptr) if stream_ptr else None))
 
     def sync(self):
