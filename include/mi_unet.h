@@ -85,7 +85,12 @@ int mi_unet_infer_u8_device(mi_unet_t *h, const uint8_t *d_imgs, int B, uint8_t 
 /* SURVEY §8f row f1 -- the arithmetic of Preprocess::preprocess_raw (src/preprocess.cpp:65-118) on the device, fused in
  * front of the network: B headerless little-endian u16 RAW images (host pointers; image i is heights[i] x widths[i]) ->
  * exact min/max -> top-left-aligned bilinear resample to the engine's H x W in fp64 -> u8 tiles (bit-exact with the
- * reference's CPU loop) -> UNet -> labels.  tiles (u8 [B][H][W], host) and logits may be NULL.  in_ch must be 1. */
+ * reference's CPU loop) -> UNet -> labels.  tiles (u8 [B][H][W][in_ch], host) and logits may be NULL.
+ * Engines with in_ch = C > 1 (BASELINE config 5: C = 3) take C planes per image: raws / widths / heights then hold B*C
+ * entries, plane c of image i at index i*C + c.  Every plane is preprocessed on its own (own size, own min/max -- exactly
+ * what preprocess_raw would do to it as a file) and becomes channel c of the interleaved tile.  The reference defines only
+ * single-plane RAW (src/preprocess.cpp:86); a caller holding one plane passes its pointer C times, which is the grey ->
+ * B,G,R replication of cv::imread(IMREAD_COLOR) (src/mask2polygon.cpp:117). */
 int mi_unet_infer_raw16(mi_unet_t *h, const uint16_t *const *raws, const int *widths, const int *heights, int B,
                         uint8_t *tiles, uint8_t *labels, float *logits);
 

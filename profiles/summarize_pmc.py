@@ -23,6 +23,7 @@ import hashlib
 import glob
 import json
 import os
+import re
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 SIMDS = 256 * 4
@@ -39,6 +40,17 @@ def kernel_source_sha():
 
 
 def short(name):
+    """kernel name without its argument list; names rocprofv3 left mangled (_ZN6miunet14conv_mfma_bf16I...) still get
+    their namespace::function prefix so that they fall into the right family"""
+    m = re.match(r"_ZN(\d+)([A-Za-z_]\w*)", name)
+    if m:
+        ns = m.group(2)[:int(m.group(1))]
+        rest = m.group(2)[int(m.group(1)):] + name[m.end():]
+        m2 = re.match(r"(\d+)", rest)
+        if m2:
+            n = int(m2.group(1))
+            fn = rest[len(m2.group(1)):len(m2.group(1)) + n]
+            return f"{ns}::{fn}<{rest[len(m2.group(1)) + n:][:40]}>"
     return name.split("(")[0].replace("void ", "").strip()
 
 
@@ -76,6 +88,7 @@ def main():
     ap.add_argument("--sq")
     ap.add_argument("--out", required=True)
     ap.add_argument("--command", default="")
+    ap.add_argument("--sha", default=None, help="source hash of the tree the passes ran on (default: this tree's)")
     a = ap.parse_args()
     out = collections.defaultdict(dict)
     mean = lambda v: sum(v) / len(v)
@@ -108,7 +121,7 @@ def main():
                 if c.get(n):
                     rec[n.lower() + "_per_launch"] = mean(c[n])
             out[k].update(rec)
-    doc = {"kernel_source_sha": kernel_source_sha(), "command": a.command,
+    doc = {"kernel_source_sha": a.sha or kernel_source_sha(), "command": a.command,
            "method": "rocprofv3 --pmc, one counter group per run, --kernel-trace only; FETCH_SIZE doubled (gfx950), "
                      "mfma_busy = SQ_VALU_MFMA_BUSY_CYCLES / (1024 SIMDs x duration x 2.4 GHz)",
            "kernels": out}

@@ -971,13 +971,17 @@ int mi_unet_extract_contours(mi_unet_t *h, const uint8_t *masks, int B, int32_t 
 }  // extern "C"
 
 namespace {
-// upload + min/max + resample `bm` RAW images into h->d_img (one staging buffer: serialised per image)
+// upload + min/max + resample `bm` RAW images into h->d_img.  An engine with in_ch = C > 1 takes C planes per image
+// (plane c of image i at index i*C + c, each with its own size and its own min/max, as if every plane went through
+// preprocess_raw on its own) and interleaves them into the HWC tile the first layer reads; a caller holding one plane per
+// image passes its pointer C times (the grey -> B,G,R replication cv::imread(IMREAD_COLOR) does at src/mask2polygon.cpp:117).
 int stage_raw16(mi_unet *h, const uint16_t *const *raws, const int *widths, const int *heights, int bm)
 {
+    const int C = h->cfg.in_ch;
     const size_t hw = (size_t)h->cfg.height * h->cfg.width;
     hipStream_t s = h->stream;
-    if (!h->d_mnmx) HIP_TRY(hipMalloc(&h->d_mnmx, sizeof(unsigned) * 2 * h->cfg.max_batch));
-    for (int i = 0; i < bm; ++i) {
+    if (!h->d_mnmx) HIP_TRY(hipMalloc(&h->d_mnmx, sizeof(unsigned) * 2 * h->cfg.max_batch * C));
+    for (int i = 0; i < bm * C; ++i) {
         const int w = widths[i], ht = heights[i];
         if (!raws[i] || w <= 0 || ht <= 0) return fail(MI_UNET_EARG, "RAW16 input: bad image description");
         const size_t n = (size_t)w * ht;
@@ -1001,7 +1005,9 @@ int stage_raw16(mi_unet *h, const uint16_t *const *raws, const int *widths, cons
         memcpy(h->h_raw[r], raws[i], n * sizeof(uint16_t));
         HIP_TRY(hipMemcpyAsync(h->d_raw[r], h->h_raw[r], n * sizeof(uint16_t), hipMemcpyHostToDevice, s));
         hipError_t e = launch_minmax_u16(h->d_raw[r], n, h->d_mnmx + 2 * i, s);
-        if (e == hipSuccess) e = launch_resample_u8(h->d_raw[r], w, ht, h->d_mnmx + 2 * i, h->d_img + i * hw, h->cfg.width, h->cfg.height, s);
+        if (e == hipSuccess)
+            e = launch_resample_u8(h->d_raw[r], w, ht, h->d_mnmx + 2 * i, h->d_img + (size_t)(i / C) * hw * C + i % C, h->cfg.width,
+                                   h->cfg.height, C, s);
         if (e != hipSuccess) return fail(MI_UNET_EHIP, std::string("preprocess launch: ") + hipGetErrorString(e));
         HIP_TRY(hipEventRecord(h->raw_done[r], s));
         h->raw_busy[r] = true;
@@ -1017,15 +1023,15 @@ int mi_unet_infer_raw16(mi_unet_t *h, const uint16_t *const *raws, const int *wi
 {
     if (int rc = check_handle(h, true)) return rc;
     if (!raws || !widths || !heights || !labels || B < 0) return fail(MI_UNET_EARG, "mi_unet_infer_raw16: bad argument");
-    if (h->cfg.in_ch != 1) return fail(MI_UNET_EARG, "mi_unet_infer_raw16 needs a single-channel engine");
     HIP_TRY(hipSetDevice(h->cfg.device));
     const size_t hw = (size_t)h->cfg.height * h->cfg.width;
     hipStream_t s = h->stream;
     for (int b0 = 0; b0 < B; b0 += h->cfg.max_batch) {
         const int bm = (B - b0) < h->cfg.max_batch ? (B - b0) : h->cfg.max_batch;
-        if (int rc = stage_raw16(h, raws + b0, widths + b0, heights + b0, bm)) return rc;
+        const size_t C = (size_t)h->cfg.in_ch;
+        if (int rc = stage_raw16(h, raws + b0 * C, widths + b0 * C, heights + b0 * C, bm)) return rc;
         if (int rc = infer_microbatch(h, h->d_img, bm, h->d_labels, logits ? h->d_logits : nullptr)) return rc;
-        if (tiles) HIP_TRY(hipMemcpyAsync(tiles + b0 * hw, h->d_img, bm * hw, hipMemcpyDeviceToHost, s));
+        if (tiles) HIP_TRY(hipMemcpyAsync(tiles + b0 * hw * C, h->d_img, bm * hw * C, hipMemcpyDeviceToHost, s));
         HIP_TRY(hipMemcpyAsync(h->h_labels, h->d_labels, bm * hw, hipMemcpyDeviceToHost, s));
         if (logits)
             HIP_TRY(hipMemcpyAsync(logits + b0 * hw * h->cfg.classes, h->d_logits, sizeof(float) * bm * hw * h->cfg.classes,
@@ -1043,7 +1049,6 @@ int mi_unet_segment_raw16(mi_unet_t *h, const uint16_t *const *raws, const int *
     if (int rc = check_handle(h, true)) return rc;
     if (!raws || !widths || !heights || !masks || !xy || !start || !counts || B < 0 || cap_points <= 0 || cap_contours <= 0)
         return fail(MI_UNET_EARG, "mi_unet_segment_raw16: bad argument");
-    if (h->cfg.in_ch != 1) return fail(MI_UNET_EARG, "mi_unet_segment_raw16 needs a single-channel engine");
     HIP_TRY(hipSetDevice(h->cfg.device));
     const int H = h->cfg.height, W = h->cfg.width;
     const size_t hw = (size_t)H * W;
@@ -1062,7 +1067,8 @@ int mi_unet_segment_raw16(mi_unet_t *h, const uint16_t *const *raws, const int *
             h->cont_cap = need;
         }
         int *d_xy = h->d_cont, *d_start = d_xy + (size_t)bm * cap_points * 2, *d_count = d_start + (size_t)bm * (cap_contours + 1);
-        if (int rc = stage_raw16(h, raws + b0, widths + b0, heights + b0, bm)) return rc;
+        const size_t C = (size_t)h->cfg.in_ch;
+        if (int rc = stage_raw16(h, raws + b0 * C, widths + b0 * C, heights + b0 * C, bm)) return rc;
         if (int rc = run_microbatch(h, h->d_img, bm, h->d_labels, nullptr)) return rc;          // UNet + argmax
         if (int rc = device_postprocess(h, h->d_labels, h->d_labels, bm)) return rc;             // {0, 2}
         uint8_t *d_vis = reinterpret_cast<uint8_t *>(h->d_s0);                                   // s0 is free after the head
@@ -1070,7 +1076,7 @@ int mi_unet_segment_raw16(mi_unet_t *h, const uint16_t *const *raws, const int *
         if (e == hipSuccess)
             e = launch_extract_contours(d_vis, bm, H, W, d_xy, cap_points, d_start, cap_contours, d_count, h->d_s1, s);
         if (e != hipSuccess) return fail(MI_UNET_EHIP, std::string("segment launch: ") + hipGetErrorString(e));
-        if (tiles) HIP_TRY(hipMemcpyAsync(tiles + b0 * hw, h->d_img, bm * hw, hipMemcpyDeviceToHost, s));
+        if (tiles) HIP_TRY(hipMemcpyAsync(tiles + b0 * hw * C, h->d_img, bm * hw * C, hipMemcpyDeviceToHost, s));
         HIP_TRY(hipMemcpyAsync(h->h_labels, d_vis, bm * hw, hipMemcpyDeviceToHost, s));
         HIP_TRY(hipMemcpyAsync(xy + (size_t)b0 * cap_points * 2, d_xy, sizeof(int) * (size_t)bm * cap_points * 2, hipMemcpyDeviceToHost, s));
         HIP_TRY(hipMemcpyAsync(start + (size_t)b0 * (cap_contours + 1), d_start, sizeof(int) * (size_t)bm * (cap_contours + 1), hipMemcpyDeviceToHost, s));

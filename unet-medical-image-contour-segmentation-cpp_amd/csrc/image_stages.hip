@@ -57,7 +57,7 @@ hipError_t launch_minmax_u16(const uint16_t *raw, size_t n, unsigned *mnmx, hipS
 
 __global__ __launch_bounds__(256) void resample_u8_kernel(const uint16_t *__restrict__ raw, int w, int h,
                                                           const unsigned *__restrict__ mnmx, uint8_t *__restrict__ dst,
-                                                          int outW, int outH)
+                                                          int outW, int outH, int dst_stride)
 {
 #pragma clang fp contract(off)
     const int x = blockIdx.x * 64 + (threadIdx.x & 63);
@@ -82,14 +82,15 @@ __global__ __launch_bounds__(256) void resample_u8_kernel(const uint16_t *__rest
     v = __dadd_rn(v, __dmul_rn(__dmul_rn(omdx, dy), v10));
     v = __dadd_rn(v, __dmul_rn(__dmul_rn(dx, dy), v11));
     const double q = __dadd_rn(__dmul_rn(__dsub_rn(v, (double)mn), scale8), 0.5);
-    dst[(size_t)y * outW + x] = (uint8_t)(int)q;
+    dst[((size_t)y * outW + x) * dst_stride] = (uint8_t)(int)q;      // dst_stride > 1: one plane of an interleaved (HWC) tile
 }
 
 hipError_t launch_resample_u8(const uint16_t *raw, int w, int h, const unsigned *mnmx, uint8_t *dst, int outW, int outH,
-                              hipStream_t s)
+                              int dst_stride, hipStream_t s)
 {
-    if (w <= 0 || h <= 0 || outW <= 0 || outH <= 0) return hipErrorInvalidValue;
-    hipLaunchKernelGGL(resample_u8_kernel, dim3((outW + 63) / 64, (outH + 3) / 4), dim3(256), 0, s, raw, w, h, mnmx, dst, outW, outH);
+    if (w <= 0 || h <= 0 || outW <= 0 || outH <= 0 || dst_stride < 1) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(resample_u8_kernel, dim3((outW + 63) / 64, (outH + 3) / 4), dim3(256), 0, s, raw, w, h, mnmx, dst, outW, outH,
+                       dst_stride);
     return hipGetLastError();
 }
 

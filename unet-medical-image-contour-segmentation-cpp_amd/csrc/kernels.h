@@ -99,8 +99,9 @@ hipError_t launch_head_argmax(const float *in, int Cin, const float *w, const fl
 //   resample : top-left aligned 4-tap bilinear in fp64 with the reference's operand order and NO fma contraction,
 //              quantised with (uchar)(int)((v - mn) * (255.0 / (mx - mn)) + 0.5); mx = (u16)(mn + 1) when mn == mx.
 hipError_t launch_minmax_u16(const uint16_t *raw, size_t n, unsigned *mnmx, hipStream_t s);
+// dst_stride = bytes between consecutive output pixels (1 = planar tile; C = plane c of an interleaved HWC tile at dst + c)
 hipError_t launch_resample_u8(const uint16_t *raw, int w, int h, const unsigned *mnmx, uint8_t *dst, int outW, int outH,
-                              hipStream_t s);
+                              int dst_stride, hipStream_t s);
 
 // Device form of postprocess_mask (reference: src/postprocess.cpp:13-79), integer-exact.  Workspace `ws` must hold
 // postprocess_workspace_bytes(B, H, W) bytes; labels_in/out are u8 [B][H][W] (in-place allowed).

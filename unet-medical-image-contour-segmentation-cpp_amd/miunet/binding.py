@@ -17,7 +17,11 @@ EXPORTS = [
     "mi_unet_default_config", "mi_unet_create", "mi_unet_load_weights", "mi_unet_load_weights_from_memory",
     "mi_unet_infer_u8", "mi_unet_infer_u8_device", "mi_unet_infer_raw16", "mi_unet_set_postprocess", "mi_unet_postprocess_masks", "mi_unet_extract_contours", "mi_unet_segment_raw16", "mi_unet_set_stream", "mi_unet_sync", "mi_unet_timer_begin",
     "mi_unet_timer_end", "mi_unet_set_profiling", "mi_unet_get_kernel_stats", "mi_unet_layer_debug", "mi_unet_destroy",
-    "mi_unet_last_error", "mi_unet_device_count",
+    "mi_unet_last_error", "mi_unet_device_count", "mi_unet_clone",
+    "mi_unet_group_create", "mi_unet_group_size", "mi_unet_group_handle", "mi_unet_group_load_weights",
+    "mi_unet_group_load_weights_from_memory", "mi_unet_group_set_gather", "mi_unet_group_set_postprocess",
+    "mi_unet_group_weight_transport", "mi_unet_group_gather", "mi_unet_group_infer_u8", "mi_unet_group_infer_raw16",
+    "mi_unet_group_segment_raw16", "mi_unet_group_destroy", "mi_unet_shard_range",
 ]
 
 
@@ -72,6 +76,26 @@ def lib():
         L.mi_unet_destroy.restype = None
         L.mi_unet_default_config.argtypes = [C.POINTER(Config)]
         L.mi_unet_default_config.restype = None
+        L.mi_unet_clone.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_void_p)]
+        L.mi_unet_group_create.argtypes = [C.POINTER(Config), C.POINTER(C.c_int), C.c_int, C.POINTER(C.c_void_p)]
+        L.mi_unet_group_size.argtypes = [C.c_void_p]
+        L.mi_unet_group_handle.argtypes = [C.c_void_p, C.c_int]
+        L.mi_unet_group_handle.restype = C.c_void_p
+        L.mi_unet_group_load_weights.argtypes = [C.c_void_p, C.c_char_p]
+        L.mi_unet_group_load_weights_from_memory.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t]
+        L.mi_unet_group_set_gather.argtypes = [C.c_void_p, C.c_int]
+        L.mi_unet_group_set_postprocess.argtypes = [C.c_void_p, C.c_int]
+        L.mi_unet_group_weight_transport.argtypes = [C.c_void_p]
+        L.mi_unet_group_weight_transport.restype = C.c_char_p
+        L.mi_unet_group_gather.argtypes = [C.c_void_p]
+        L.mi_unet_group_infer_u8.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]
+        L.mi_unet_group_infer_raw16.argtypes = [C.c_void_p, C.POINTER(C.c_void_p), C.POINTER(C.c_int), C.POINTER(C.c_int), C.c_int,
+                                                C.c_void_p, C.c_void_p, C.c_void_p]
+        L.mi_unet_group_segment_raw16.argtypes = [C.c_void_p, C.POINTER(C.c_void_p), C.POINTER(C.c_int), C.POINTER(C.c_int), C.c_int,
+                                                  C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p]
+        L.mi_unet_group_destroy.argtypes = [C.c_void_p]
+        L.mi_unet_group_destroy.restype = None
+        L.mi_unet_shard_range.argtypes = [C.c_int, C.c_int, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int)]
         _LIB = L
     return _LIB
 
@@ -105,6 +129,15 @@ class Engine:
         self.cfg = Config(height, width, in_ch, base, levels, classes, max_batch, device, self.CONV_ALGOS[conv_algo])
         self._h = C.c_void_p()
         _check(lib().mi_unet_create(C.byref(self.cfg), C.byref(self._h)))
+
+    def clone(self, max_batch=0) -> "Engine":
+        """A second context on the same device sharing this engine's weight blob (mi_unet_clone)."""
+        other = object.__new__(Engine)
+        other.cfg = Config(self.cfg.height, self.cfg.width, self.cfg.in_ch, self.cfg.base, self.cfg.levels, self.cfg.classes,
+                           max_batch if max_batch > 0 else self.cfg.max_batch, self.cfg.device, self.cfg.conv_algo)
+        other._h = C.c_void_p()
+        _check(lib().mi_unet_clone(self._h, max_batch, C.byref(other._h)))
+        return other
 
     def close(self):
         if self._h:
@@ -142,14 +175,26 @@ class Engine:
         _check(lib().mi_unet_infer_u8(self._h, _ptr(imgs), b, _ptr(labels), _ptr(logits)))
         return labels, logits
 
-    def infer_raw16(self, raws, want_tiles=True, want_logits=False):
-        """raws: list of u16 [h_i][w_i] arrays -> (tiles u8 [B,H,W] or None, labels u8 [B,H,W], logits or None)"""
+    def _raw_args(self, raws):
+        """list of u16 planes (in_ch per image, image-major) -> (keep-alive list, pointer / width / height arrays, B)"""
         raws = [np.ascontiguousarray(r, dtype=np.uint16) for r in raws]
-        b, c = len(raws), self.cfg
-        ptrs = (C.c_void_p * b)(*[r.ctypes.data for r in raws])
-        ws = (C.c_int * b)(*[r.shape[1] for r in raws])
-        hs = (C.c_int * b)(*[r.shape[0] for r in raws])
-        tiles = np.empty((b, c.height, c.width), np.uint8) if want_tiles else None
+        n, c = len(raws), self.cfg
+        if n % c.in_ch:
+            raise ValueError(f"{n} planes for an engine with in_ch = {c.in_ch}")
+        ptrs = (C.c_void_p * n)(*[r.ctypes.data for r in raws])
+        ws = (C.c_int * n)(*[r.shape[1] for r in raws])
+        hs = (C.c_int * n)(*[r.shape[0] for r in raws])
+        return raws, ptrs, ws, hs, n // c.in_ch
+
+    def _tile_buf(self, b):
+        c = self.cfg
+        return np.empty((b, c.height, c.width) if c.in_ch == 1 else (b, c.height, c.width, c.in_ch), np.uint8)
+
+    def infer_raw16(self, raws, want_tiles=True, want_logits=False):
+        """raws: list of u16 [h_i][w_i] planes, in_ch per image -> (tiles u8 [B,H,W(,C)] or None, labels u8 [B,H,W], logits or None)"""
+        c = self.cfg
+        raws, ptrs, ws, hs, b = self._raw_args(raws)
+        tiles = self._tile_buf(b) if want_tiles else None
         labels = np.empty((b, c.height, c.width), np.uint8)
         logits = np.empty((b, c.classes, c.height, c.width), np.float32) if want_logits else None
         _check(lib().mi_unet_infer_raw16(self._h, ptrs, ws, hs, b, _ptr(tiles), _ptr(labels), _ptr(logits)))
@@ -182,12 +227,9 @@ class Engine:
 
     def segment_raw16(self, raws, cap_points=8192, cap_contours=64):
         """RAW16 images -> (tiles, mask images 0/255, contours per image) with every stage on the device"""
-        raws = [np.ascontiguousarray(r, dtype=np.uint16) for r in raws]
-        b, c = len(raws), self.cfg
-        ptrs = (C.c_void_p * b)(*[r.ctypes.data for r in raws])
-        ws = (C.c_int * b)(*[r.shape[1] for r in raws])
-        hs = (C.c_int * b)(*[r.shape[0] for r in raws])
-        tiles = np.empty((b, c.height, c.width), np.uint8)
+        c = self.cfg
+        raws, ptrs, ws, hs, b = self._raw_args(raws)
+        tiles = self._tile_buf(b)
         masks = np.empty((b, c.height, c.width), np.uint8)
         xy = np.zeros((b, cap_points, 2), np.int32)
         start = np.zeros((b, cap_contours + 1), np.int32)
@@ -233,6 +275,89 @@ class Engine:
         _check(lib().mi_unet_get_kernel_stats(self._h, arr, cap, C.byref(n)))
         return [dict(name=arr[i].name.decode(), kernel=arr[i].kernel.decode(), flops=arr[i].flops, bytes=arr[i].bytes,
                      ms=arr[i].ms) for i in range(min(n.value, cap))]
+
+
+def shard_range(n_items: int, rank: int, world: int):
+    lo, hi = C.c_int(), C.c_int()
+    _check(lib().mi_unet_shard_range(n_items, rank, world, C.byref(lo), C.byref(hi)))
+    return lo.value, hi.value
+
+
+class Group:
+    """mi_unet_group_*: one engine + worker thread per device in this process, contiguous image shards."""
+
+    GATHER = {"host": 0, "xgmi": 1}
+
+    def __init__(self, height=512, width=512, in_ch=1, base=64, levels=4, classes=3, max_batch=16, devices=None,
+                 n_devices=0, conv_algo="auto"):
+        self.cfg = Config(height, width, in_ch, base, levels, classes, max_batch, 0, Engine.CONV_ALGOS[conv_algo])
+        self._g = C.c_void_p()
+        if devices is not None:
+            arr = (C.c_int * len(devices))(*devices)
+            _check(lib().mi_unet_group_create(C.byref(self.cfg), arr, len(devices), C.byref(self._g)))
+        else:
+            _check(lib().mi_unet_group_create(C.byref(self.cfg), None, n_devices, C.byref(self._g)))
+
+    def close(self):
+        if self._g:
+            lib().mi_unet_group_destroy(self._g)
+            self._g = C.c_void_p()
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    @property
+    def size(self):
+        return int(lib().mi_unet_group_size(self._g))
+
+    @property
+    def weight_transport(self):
+        return lib().mi_unet_group_weight_transport(self._g).decode()
+
+    def load_weights(self, blob: bytes):
+        buf = (C.c_char * len(blob)).from_buffer_copy(blob)
+        _check(lib().mi_unet_group_load_weights_from_memory(self._g, C.cast(buf, C.c_void_p), len(blob)))
+
+    def set_gather(self, mode: str):
+        _check(lib().mi_unet_group_set_gather(self._g, self.GATHER[mode]))
+
+    def set_postprocess(self, on: bool):
+        _check(lib().mi_unet_group_set_postprocess(self._g, int(on)))
+
+    def infer(self, imgs: np.ndarray, want_logits=False):
+        imgs = np.ascontiguousarray(imgs, dtype=np.uint8)
+        b, c = imgs.shape[0], self.cfg
+        labels = np.empty((b, c.height, c.width), np.uint8)
+        logits = np.empty((b, c.classes, c.height, c.width), np.float32) if want_logits else None
+        _check(lib().mi_unet_group_infer_u8(self._g, _ptr(imgs), b, _ptr(labels), _ptr(logits)))
+        return labels, logits
+
+    def segment_raw16(self, raws, cap_points=8192, cap_contours=64):
+        raws = [np.ascontiguousarray(r, dtype=np.uint16) for r in raws]
+        n, c = len(raws), self.cfg
+        b = n // c.in_ch
+        ptrs = (C.c_void_p * n)(*[r.ctypes.data for r in raws])
+        ws = (C.c_int * n)(*[r.shape[1] for r in raws])
+        hs = (C.c_int * n)(*[r.shape[0] for r in raws])
+        tiles = np.empty((b, c.height, c.width) if c.in_ch == 1 else (b, c.height, c.width, c.in_ch), np.uint8)
+        masks = np.empty((b, c.height, c.width), np.uint8)
+        xy = np.zeros((b, cap_points, 2), np.int32)
+        start = np.zeros((b, cap_contours + 1), np.int32)
+        counts = np.zeros(b, np.int32)
+        _check(lib().mi_unet_group_segment_raw16(self._g, ptrs, ws, hs, b, _ptr(tiles), _ptr(masks), _ptr(xy), cap_points, _ptr(start),
+                                                 cap_contours, _ptr(counts)))
+        cont = [None if counts[i] < 0 else
+                [[tuple(p) for p in xy[i, start[i, k]:start[i, k + 1]].tolist()] for k in range(counts[i])] for i in range(b)]
+        return tiles, masks, cont
 
 
 def layer_debug(op, x, w=None, scale=None, shift=None, relu=False, device=0):
