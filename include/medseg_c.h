@@ -34,6 +34,9 @@ void medseg_map_points(const int32_t *xy, int n, double scale_x, double scale_y,
 /* generate_json (src/mask2polygon.cpp:68): writes the document for the given contours */
 int medseg_generate_json(const int32_t *xy, const int32_t *start, int ncontours, const char *json_path, const char *base_name,
                          int original_width, int original_height);
+/* the picture create_overlay_image writes (src/mask2polygon.cpp:114-129): the grey tile replicated to B,G,R with every contour
+ * drawn as a closed red polyline of thickness 1 (cv::drawContours(-1, (0,0,255), 1), LINE_8); bgr_out is w*h*3 bytes */
+int medseg_draw_overlay(const uint8_t *gray, int w, int h, const int32_t *xy, const int32_t *start, int ncontours, uint8_t *bgr_out);
 /* Mask2Polygon::process_single_mask (src/mask2polygon.cpp:134) */
 void medseg_process_single_mask(const char *mask_path, const char *output_dir, const char *json_path, const char *original_png,
                                 const char *base_name);

@@ -93,3 +93,27 @@ def test_segment_raw16_whole_device_half_of_the_pipeline():
         assert cont[i] == orc.find_contours(vis)
         n_with_contours += bool(cont[i])
     assert n_with_contours >= 1
+
+
+def test_three_tracers_agree_on_adversarial_masks():
+    """The device tracer, the host BorderTracer and the oracle's Suzuki-Abe restatement are three independently written
+    border followers.  Shapes built to break one -- 1-pixel spurs, diagonal-only links, nested rings touching the frame,
+    strokes lying on the frame, a comb, a checkerboard -- and dense unsmoothed noise (all of that at once) must give the same
+    point sequences, in the same order, from all three."""
+    from miunet import hostlib
+    from test_host_cpu import _adversarial_masks
+
+    masks = [m for m in _adversarial_masks()]
+    masks[5] = (np.indices((18, 18)).sum(0) % 2 * 255).astype(np.uint8)          # engine sizes are even
+    for m in masks:
+        h, w = m.shape
+        with binding.Engine(h, w, 1, 16, 1, 3, max_batch=1) as eng:
+            got = eng.extract_contours(m[None], cap_points=4 * h * w, cap_contours=h * w)[0]
+        assert got == orc.find_contours(m) == hostlib.extract_contours(m)
+    rng = np.random.default_rng(11)
+    for density in (0.25, 0.5, 0.75):
+        noise = np.stack([(rng.random((32, 48)) < density).astype(np.uint8) * 255 for _ in range(8)])
+        with binding.Engine(32, 48, 1, 16, 1, 3, max_batch=4) as eng:
+            got = eng.extract_contours(noise, cap_points=4 * 32 * 48, cap_contours=32 * 48)
+        for i in range(8):
+            assert got[i] == orc.find_contours(noise[i]) == hostlib.extract_contours(noise[i]), (density, i)

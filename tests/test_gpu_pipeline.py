@@ -166,3 +166,98 @@ def test_cli_directory_mode(tmp_path):
     tile = orc.preprocess_raw(synth.make_raw16(600, 800, seed=51))
     assert np.array_equal(np.array(Image.open(out / "sub" / "b_normalized.png")), tile)
     assert "Resources cleaned up successfully" in text
+
+
+def _oracle_artefacts(blob, raw, tile_size=512, fp16=False, in_ch=1):
+    tile = orc.preprocess_raw(raw, tile_size, tile_size)
+    x = np.repeat(tile[None, :, :, None], in_ch, axis=3)
+    _, labels = orc.unet_forward(blob, x, want_logits=False, fp16=fp16)
+    vis = orc.mask_to_image(orc.postprocess_mask(labels[0]))
+    return tile, vis, orc.find_contours(vis)
+
+
+def test_two_threads_call_process_single_image_concurrently(tmp_path):
+    """The reference keeps one execution context per calling thread (thread_local TensorRTContext, include/process.h:13-26,
+    src/process.cpp:15): here two host threads drive process_single_image at once, each on its own cloned context, and every
+    image must come out exactly as the oracle chain says.  ctypes releases the GIL for the duration of a call."""
+    import threading
+
+    spec = UNetSpec()
+    blob = pack_weights(spec, synth.make_threshold_weights(spec))
+    wpath = tmp_path / "unet.miw"
+    wpath.write_bytes(blob)
+    assert hostlib.initialize_engine(str(wpath), str(tmp_path / "log"))
+    jobs = []
+    for t in range(2):
+        out = tmp_path / f"out{t}"
+        out.mkdir()
+        for k in range(3):
+            raw = synth.make_raw16(600 + 100 * k, 800 + 64 * t, seed=300 + 10 * t + k)
+            p = tmp_path / f"t{t}_{k}.raw"
+            raw.tofile(p)
+            jobs.append((t, str(p), raw, out))
+    results = {}
+
+    def work(t):
+        for (tt, p, raw, out) in jobs:
+            if tt == t:
+                results[p] = hostlib.process_single_image(p, raw.shape[1], raw.shape[0], str(out))
+
+    th = [threading.Thread(target=work, args=(t,)) for t in range(2)]
+    for x in th:
+        x.start()
+    for x in th:
+        x.join()
+    assert all(results[p] for (_, p, _, _) in jobs) and len(results) == 6
+    for (t, p, raw, out) in jobs:
+        base = os.path.splitext(os.path.basename(p))[0]
+        tile, vis, contours = _oracle_artefacts(blob, raw)
+        assert np.array_equal(np.array(Image.open(out / f"{base}_normalized.png")), tile)
+        assert np.array_equal(np.array(Image.open(out / f"{base}_mask.png")), vis)
+        if contours:
+            doc = json.load(open(out / f"{base}.json"))
+            h, w = raw.shape
+            assert [[tuple(q) for q in s["points"]] for s in doc["shapes"]] == [orc.map_points(c, w / 512.0, h / 512.0) for c in contours]
+    hostlib.cleanup_resources()
+    log = open(hostlib.get_log_path()).read()
+    assert log.count("Execution context created for a new thread") == 2
+    # the per-image blocks of the two threads must not interleave: every block is header .. "Processing completed"
+    blocks = [b for b in log.split("\n=== Processing Image: ")[1:]]
+    assert len(blocks) == 6 and all("Inference time: " in b and "Processing completed for: " in b.split("=== Cleaning")[0] for b in blocks)
+
+
+def test_facade_takes_topology_from_the_weight_file_and_tile_size_from_the_environment(tmp_path, monkeypatch):
+    """initialize_engine reads in_ch / base / levels / classes from the MIUNETW1 header and the tile size, micro-batch and
+    arithmetic from MEDSEG_* variables: a 5-level base-32 three-channel fp16 engine at 1024x1024 (BASELINE configs[4]) driven
+    through MedicalSeg::process_single_image and process_image_batch -- the single RAW plane feeds all three channels."""
+    monkeypatch.setenv("MEDSEG_TILE_SIZE", "1024")
+    monkeypatch.setenv("MEDSEG_MAX_BATCH", "2")
+    monkeypatch.setenv("MEDSEG_CONV_ALGO", "fp16")
+    spec = UNetSpec(3, 32, 5, 3)
+    blob = pack_weights(spec, synth.make_threshold_weights(spec))
+    wpath = tmp_path / "unet.miw"
+    wpath.write_bytes(blob)
+    out = tmp_path / "out"
+    out.mkdir()
+    assert hostlib.initialize_engine(str(wpath), str(tmp_path / "log"))
+    log = open(hostlib.get_log_path()).read()
+    assert "in_ch=3 base=32 levels=5 classes=3, tile 1024x1024" in log
+    raws, paths = [], []
+    for k in range(3):
+        raw = synth.make_raw16(1200 + 50 * k, 1500, seed=400 + k)
+        p = tmp_path / f"c{k}.raw"
+        raw.tofile(p)
+        raws.append(raw); paths.append(str(p))
+    assert hostlib.process_single_image(paths[0], 1500, 1200, str(out))
+    assert hostlib.process_image_batch(paths[1:], [1500, 1500], [1250, 1300], str(out)) == 2
+    for k, raw in enumerate(raws):
+        tile, vis, contours = _oracle_artefacts(blob, raw, 1024, fp16=True, in_ch=3)
+        assert np.array_equal(np.array(Image.open(out / f"c{k}_normalized.png")), tile)
+        assert np.array_equal(np.array(Image.open(out / f"c{k}_mask.png")), vis)
+        assert contours, "the structured weights must leave a segment"
+        doc = json.load(open(out / f"c{k}.json"))
+        h, w = raw.shape
+        assert [[tuple(q) for q in s["points"]] for s in doc["shapes"]] == [orc.map_points(c, w / 1024.0, h / 1024.0) for c in contours]
+        sizes = json.load(open(out / f"c{k}_original_sizes.json"))
+        assert sizes[f"c{k}.raw"]["scaled_width"] == 1024 and sizes[f"c{k}.raw"]["scaled_height"] == 1024
+    hostlib.cleanup_resources()

@@ -127,6 +127,97 @@ def test_contours_are_closed_8_connected_loops_on_the_boundary():
                 assert dx == 0 or dy == 0 or dx == dy
 
 
+def _polyline_pixels(c):
+    """independent rasteriser: the closed polyline through the points of a contour as a set of pixels.  Consecutive points of
+    a CHAIN_APPROX_SIMPLE contour are joined by horizontal, vertical or exact 45-degree runs, for which every 8-connected
+    line algorithm (cv::line LINE_8 included) visits the same pixels: n = max(|dx|, |dy|) unit steps."""
+    px = set()
+    for k, (x0, y0) in enumerate(c):
+        x1, y1 = c[(k + 1) % len(c)]
+        n = max(abs(x1 - x0), abs(y1 - y0))
+        assert abs(x1 - x0) in (0, n) and abs(y1 - y0) in (0, n)
+        sx, sy = (x1 > x0) - (x1 < x0), (y1 > y0) - (y1 < y0)
+        for t in range(n + 1):
+            px.add((x0 + t * sx, y0 + t * sy))
+    return px
+
+
+def _adversarial_masks():
+    """shapes that stress a border follower: 1-pixel spurs, diagonal-only links, nested holes, blobs on the frame"""
+    out = []
+    m = np.zeros((24, 24), np.uint8); m[4:12, 4:12] = 255; m[7, 12:18] = 255; m[12:16, 6] = 255; m[1, 1] = 255
+    out.append(m)                                                        # spurs (traversed out and back) + an isolated pixel
+    m = np.zeros((20, 20), np.uint8)
+    for k in range(12):
+        m[3 + k, 2 + k] = 255                                            # a pure diagonal chain
+    m[15:18, 15:18] = 255; m[14, 14] = 255                               # ... linked to a block only through a corner
+    out.append(m)
+    m = np.zeros((40, 40), np.uint8); m[0:40, 0:40] = 255; m[5:35, 5:35] = 0; m[10:30, 10:30] = 255; m[15:25, 15:25] = 0; m[18:22, 18:22] = 255
+    out.append(m)                                                        # nested rings touching the frame: only the outermost border is external
+    m = np.zeros((16, 30), np.uint8); m[0, :] = 255; m[:, 0] = 255; m[15, 10:20] = 255; m[5:9, 29] = 255
+    out.append(m)                                                        # 1-pixel-wide strokes lying on the frame
+    m = np.zeros((18, 18), np.uint8); m[2::2, 2:16] = 255; m[2:16, 2] = 255
+    out.append(m)                                                        # a comb: many parallel spurs off one spine
+    m = (np.indices((17, 17)).sum(0) % 2 * 255).astype(np.uint8)
+    out.append(m)                                                        # checkerboard: one 8-connected component, all links diagonal
+    return out
+
+
+def test_overlay_is_exactly_the_closed_polylines_of_the_contours():
+    """A14 (src/mask2polygon.cpp:114-129): every pixel of the overlay is either the grey tile replicated to B,G,R or pure
+    red, and the red set is EXACTLY the closed 8-connected polylines through the contour points -- checked against an
+    independent rasteriser, including the wrap-around segment, the two-point out-and-back contour and the single point.
+    For a SIMPLE-compressed border that polyline is the border itself: every red pixel is a foreground pixel with a
+    background 4-neighbour (or on the frame)."""
+    rng = np.random.default_rng(5)
+    masks = _adversarial_masks() + [_blob_mask(s, 48, 64) for s in (1, 2, 3)] + [_blob_mask(9, 512, 512)]
+    for m in masks:
+        gray = rng.integers(0, 255, m.shape, dtype=np.uint8)             # never 255: red (0,0,255) cannot occur in the grey picture
+        cs = hostlib.extract_contours(m)
+        ov = hostlib.draw_overlay(gray, cs)
+        red = (ov[..., 0] == 0) & (ov[..., 1] == 0) & (ov[..., 2] == 255)          # B, G, R
+        want = set().union(*[_polyline_pixels(c) for c in cs]) if cs else set()
+        assert {(int(x), int(y)) for y, x in zip(*np.nonzero(red))} == want
+        assert np.array_equal(ov[~red], np.repeat(gray[~red][:, None], 3, axis=1))
+        pad = np.pad(m > 127, 1)
+        for (x, y) in want:
+            assert pad[y + 1, x + 1]
+            assert not (pad[y, x + 1] and pad[y + 2, x + 1] and pad[y + 1, x] and pad[y + 1, x + 2])
+    # hand-written contours: a single point, an out-and-back pair, a triangle with two diagonals
+    gray = np.full((10, 10), 7, np.uint8)
+    ov = hostlib.draw_overlay(gray, [[(2, 3)], [(5, 1), (8, 1)], [(1, 6), (3, 8), (5, 6)]])
+    red = (ov[..., 2] == 255) & (ov[..., 0] == 0)
+    assert {(int(x), int(y)) for y, x in zip(*np.nonzero(red))} == \
+        {(2, 3)} | {(x, 1) for x in range(5, 9)} | {(1, 6), (2, 7), (3, 8), (4, 7), (5, 6)} | {(x, 6) for x in range(1, 6)}
+
+
+def test_contour_implementations_agree_on_adversarial_masks():
+    """the oracle's Suzuki-Abe restatement and the host BorderTracer are two independently written followers; they must
+    agree point for point (start pixel, direction, SIMPLE compression, newest-first order) on shapes built to break one"""
+    for m in _adversarial_masks():
+        a, b = hostlib.extract_contours(m), orc.find_contours(m)
+        assert a == b and len(a) >= 1
+    # known answers on two of them
+    m = _adversarial_masks()[2]                                          # nested rings: ONE external contour, the frame rectangle
+    assert hostlib.extract_contours(m) == [[(0, 0), (0, 39), (39, 39), (39, 0)]]
+    m = _adversarial_masks()[5]                                          # checkerboard: ONE component through diagonal links only
+    assert len(hostlib.extract_contours(m)) == 1
+
+
+@settings(max_examples=120, deadline=None)
+@given(st.integers(0, 2 ** 32 - 1), st.sampled_from([(9, 9), (12, 20), (24, 24)]), st.floats(0.2, 0.8))
+def test_contours_random_dense_noise_vs_oracle(seed, shape, density):
+    """unsmoothed noise: diagonal-only links, 1-pixel components and spurs everywhere, frame contacts on every side"""
+    rng = np.random.default_rng(seed)
+    m = (rng.random(shape) < density).astype(np.uint8) * 255
+    a = hostlib.extract_contours(m)
+    assert a == orc.find_contours(m)
+    if a:
+        gray = np.zeros(shape, np.uint8)
+        red = hostlib.draw_overlay(gray, a)[..., 2] == 255
+        assert {(int(x), int(y)) for y, x in zip(*np.nonzero(red))} == set().union(*[_polyline_pixels(c) for c in a])
+
+
 def test_map_points():
     pts = [(511, 511), (3, 7), (0, 0), (255, 100)]
     for sx, sy in [(4.0, 3.0), (300 / 512.0, 200 / 512.0), (1.0, 1.0), (2047 / 512.0, 1.37)]:

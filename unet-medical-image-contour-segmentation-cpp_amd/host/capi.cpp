@@ -109,6 +109,14 @@ int medseg_generate_json(const int32_t *xy, const int32_t *start, int ncontours,
         return 0;
     } catch (...) { return 1; }
 }
+int medseg_draw_overlay(const uint8_t *gray, int w, int h, const int32_t *xy, const int32_t *start, int ncontours, uint8_t *bgr_out)
+{
+    try {
+        const Image8 r = Mask2Polygon::draw_overlay(wrap(gray, w, h), unflatten(xy, start, ncontours));
+        memcpy(bgr_out, r.data.data(), r.data.size());
+        return 0;
+    } catch (...) { return 1; }
+}
 void medseg_process_single_mask(const char *mask_path, const char *output_dir, const char *json_path, const char *original_png,
                                 const char *base_name)
 {

@@ -1,10 +1,17 @@
 // lifecycle.cpp -- MedicalSeg::initialize_engine / process_single_image / cleanup_resources on top of the C-ABI
 // (include/mi_unet.h).  Reference: src/initialize.cpp:26-91, src/process.cpp:123-262, src/cleanup.cpp:10-64.
-// Same log file name, banner lines, message prefixes and bool/void error conventions; the TensorRT engine, the
-// thread-local execution context and the CUDA graph are replaced by one mi_unet handle.
+// Same log file name, banner lines, message prefixes and bool/void error conventions.  What replaces what:
+//   g_runtime / g_engine (one deserialised TensorRT engine, src/initialize.cpp:20-21)
+//        -> one mi_unet group: an engine handle per visible device, weights packed once and sent device-to-device
+//   thread_local TensorRTContext (exec context + buffers + stream + graph per calling thread, src/process.cpp:15, :45-120)
+//        -> a thread_local clone of the first device's handle (mi_unet_clone: shares the weight blob, owns buffers, stream
+//           and graphs), created lazily on a thread's first single-image call, so concurrent callers do not serialise
+//   the sequential file loop of directory mode (src/main.cpp:148-164)
+//        -> process_image_batch: chunks of max_batch x devices images, sharded over the group
 #include <algorithm>
 #include <chrono>
 #include <cstdlib>
+#include <cstring>
 #include <filesystem>
 #include <future>
 #include <memory>
@@ -27,15 +34,68 @@ using medseg::Image8;
 namespace MedicalSeg {
 
 namespace {
-mi_unet_t *g_engine = nullptr;
-mi_unet_config g_cfg{};
+std::mutex g_state_mutex;          // guards the four below
+mi_unet_group_t *g_group = nullptr;
+mi_unet_config g_cfg{};            // per-rank configuration of the group (tile size, topology, max_batch, algorithm)
+int g_thread_batch = 1;            // micro-batch capacity of a per-thread context
+unsigned long g_generation = 0;    // bumped by every (re)initialisation and cleanup: older thread contexts are stale
 std::ofstream g_log_file;
 std::string g_log_path;
-std::mutex g_infer_mutex;          // a handle serves one caller at a time (the reference's static staging vectors raced)
+std::mutex g_log_mutex;            // the reference's global log stream is written from any thread unguarded
+std::mutex g_batch_mutex;          // the batch routes toggle group-wide state (postprocess flag): one batch call at a time
+
+// The calling thread's context.  Destroyed by cleanup_resources() on that thread (as the reference does, src/cleanup.cpp:16)
+// or when the thread ends; a context of an older engine generation is replaced on its next use.
+struct ThreadContext {
+    mi_unet_t *h = nullptr;
+    unsigned long generation = 0;
+    void release() { if (h) { mi_unet_destroy(h); h = nullptr; } }
+    ~ThreadContext() { release(); }
+};
+thread_local ThreadContext t_context;
+
+int env_int(const char *name, int fallback)
+{
+    const char *v = std::getenv(name);
+    if (!v || !*v) return fallback;
+    char *end = nullptr;
+    const long x = std::strtol(v, &end, 10);
+    return (end && *end == '\0') ? (int)x : fallback;
+}
+
+int env_algo()
+{
+    const char *v = std::getenv("MEDSEG_CONV_ALGO");
+    if (!v) return MI_UNET_CONV_AUTO;
+    const std::string s(v);
+    return s == "direct" ? MI_UNET_CONV_DIRECT : s == "winograd" ? MI_UNET_CONV_WINOGRAD : s == "bf16" ? MI_UNET_CONV_BF16
+         : s == "fp16" ? MI_UNET_CONV_FP16 : MI_UNET_CONV_AUTO;
+}
+
+// topology of a MIUNETW1 file (miunet/spec.py): magic[8], u32 version, in_ch, base, levels, classes
+bool read_weight_header(const std::string &path, mi_unet_config &cfg)
+{
+    std::ifstream f(path, std::ios::binary);
+    unsigned char hdr[28];
+    if (!f.read(reinterpret_cast<char *>(hdr), sizeof hdr) || std::memcmp(hdr, "MIUNETW1", 8) != 0) return false;
+    uint32_t v[5];
+    std::memcpy(v, hdr + 8, sizeof v);
+    if (v[0] != 1) return false;
+    cfg.in_ch = (int)v[1]; cfg.base = (int)v[2]; cfg.levels = (int)v[3]; cfg.classes = (int)v[4];
+    return true;
+}
 }  // namespace
 
+// Engine configuration: the topology comes from the weight file's header, everything the reference hard-codes or leaves to
+// TensorRT comes from the environment --
+//   MEDSEG_TILE_SIZE (or MEDSEG_TILE_W / MEDSEG_TILE_H)  network tile, default 512 (src/process.cpp:70, src/preprocess.cpp:81)
+//   MEDSEG_MAX_BATCH     images per device micro-batch in directory mode, default 16
+//   MEDSEG_THREAD_BATCH  capacity of a per-thread context (single-image calls), default 1
+//   MEDSEG_CONV_ALGO     auto | direct | winograd | bf16 | fp16 (the arithmetic of BASELINE configs 3 and 5)
+//   MEDSEG_DEVICES       number of devices in the group, default every visible one
 bool initialize_engine(const std::string &trt_cache_path, const std::string &log_dir)
 {
+    std::lock_guard<std::mutex> state_lock(g_state_mutex);
     try {
         fs::create_directories(log_dir);
         g_log_path = log_dir + "/segmentation_log.txt";
@@ -51,16 +111,33 @@ bool initialize_engine(const std::string &trt_cache_path, const std::string &log
             g_log_file << "Error: engine weight file not found - " << trt_cache_path << std::endl;
             return false;
         }
-        if (g_engine) { mi_unet_destroy(g_engine); g_engine = nullptr; }
+        if (g_group) { mi_unet_group_destroy(g_group); g_group = nullptr; }
+        ++g_generation;
         mi_unet_default_config(&g_cfg);            // 512x512x1, 3 classes (src/process.cpp:70, :162)
-        g_cfg.max_batch = 16;
-        if (mi_unet_create(&g_cfg, &g_engine) != MI_UNET_OK || mi_unet_load_weights(g_engine, trt_cache_path.c_str()) != MI_UNET_OK) {
+        if (!read_weight_header(trt_cache_path, g_cfg)) {
+            g_log_file << "Error: not a MIUNETW1 weight file - " << trt_cache_path << std::endl;
+            std::cerr << "Initialization error: not a MIUNETW1 weight file" << std::endl;
+            return false;
+        }
+        const int tile = env_int("MEDSEG_TILE_SIZE", 512);
+        g_cfg.width = env_int("MEDSEG_TILE_W", tile);
+        g_cfg.height = env_int("MEDSEG_TILE_H", tile);
+        g_cfg.max_batch = std::max(1, env_int("MEDSEG_MAX_BATCH", 16));
+        g_cfg.conv_algo = env_algo();
+        g_thread_batch = std::max(1, env_int("MEDSEG_THREAD_BATCH", 1));
+        const int n_devices = env_int("MEDSEG_DEVICES", 0);
+        if (mi_unet_group_create(&g_cfg, nullptr, n_devices, &g_group) != MI_UNET_OK ||
+            mi_unet_group_load_weights(g_group, trt_cache_path.c_str()) != MI_UNET_OK) {
             g_log_file << "Error: Failed to initialize MI355X UNet engine: " << mi_unet_last_error() << std::endl;
             std::cerr << "Initialization error: " << mi_unet_last_error() << std::endl;
-            if (g_engine) { mi_unet_destroy(g_engine); g_engine = nullptr; }
+            if (g_group) { mi_unet_group_destroy(g_group); g_group = nullptr; }
             return false;
         }
         g_log_file << "MI355X UNet engine initialized successfully" << std::endl;
+        g_log_file << "  Topology: in_ch=" << g_cfg.in_ch << " base=" << g_cfg.base << " levels=" << g_cfg.levels
+                   << " classes=" << g_cfg.classes << ", tile " << g_cfg.width << "x" << g_cfg.height << std::endl;
+        g_log_file << "  Devices: " << mi_unet_group_size(g_group) << " (weights to ranks > 0 by "
+                   << mi_unet_group_weight_transport(g_group) << "), micro-batch " << g_cfg.max_batch << " per device" << std::endl;
         g_log_file << "  Input size: " << (size_t)g_cfg.height * g_cfg.width * g_cfg.in_ch << " bytes (u8)" << std::endl;
         g_log_file << "  Output size: " << (size_t)g_cfg.height * g_cfg.width << " bytes (classes=" << g_cfg.classes << ")" << std::endl;
         return true;
@@ -71,25 +148,69 @@ bool initialize_engine(const std::string &trt_cache_path, const std::string &log
     }
 }
 
-mi_unet_t *get_engine() { return g_engine; }
+mi_unet_t *get_engine()
+{
+    std::lock_guard<std::mutex> lk(g_state_mutex);
+    return g_group ? mi_unet_group_handle(g_group, 0) : nullptr;
+}
+mi_unet_group_t *get_engine_group() { std::lock_guard<std::mutex> lk(g_state_mutex); return g_group; }
 std::ofstream &get_log_file() { return g_log_file; }
 std::string get_log_path() { return g_log_path; }
+
+// The reference's get_thread_local_context() + initialize_context() (src/process.cpp:17-19, :45-120): the calling thread's
+// own context, created on first use.
+mi_unet_t *get_thread_local_context()
+{
+    std::lock_guard<std::mutex> lk(g_state_mutex);
+    if (!g_group) throw std::runtime_error("Engine not initialized");
+    if (t_context.h && t_context.generation == g_generation) return t_context.h;
+    t_context.release();
+    if (mi_unet_clone(mi_unet_group_handle(g_group, 0), g_thread_batch, &t_context.h) != MI_UNET_OK)
+        throw std::runtime_error(std::string("context creation failed: ") + mi_unet_last_error());
+    t_context.generation = g_generation;
+    {
+        std::lock_guard<std::mutex> ll(g_log_mutex);
+        if (g_log_file.is_open())
+            g_log_file << "Execution context created for a new thread (micro-batch " << g_thread_batch << ")" << std::endl;
+    }
+    return t_context.h;
+}
+
+namespace {
+// single-plane tiles / RAW images feed every input channel of a multi-channel engine: the grey -> B,G,R replication of
+// cv::imread(IMREAD_COLOR) (src/mask2polygon.cpp:117); see mi_unet_infer_raw16 in include/mi_unet.h
+std::vector<uint8_t> interleave_gray(const std::vector<const Image8 *> &imgs, int in_ch)
+{
+    const size_t hw = (size_t)g_cfg.height * g_cfg.width;
+    std::vector<uint8_t> in(hw * in_ch * imgs.size());
+    for (size_t i = 0; i < imgs.size(); ++i) {
+        const Image8 &g = *imgs[i];
+        if (g.rows != g_cfg.height || g.cols != g_cfg.width || g.channels != 1)
+            throw std::runtime_error("Input size must be " + std::to_string(g_cfg.width) + "x" + std::to_string(g_cfg.height) +
+                                     " for fixed context");                                   // src/process.cpp:127
+        uint8_t *dst = in.data() + i * hw * in_ch;
+        if (in_ch == 1) std::copy(g.data.begin(), g.data.end(), dst);
+        else
+            for (size_t p = 0; p < hw; ++p)
+                for (int c = 0; c < in_ch; ++c) dst[p * in_ch + c] = g.data[p];
+    }
+    return in;
+}
+}  // namespace
 
 std::vector<Image8> execute_inference_batch(const std::vector<Image8> &gray_imgs)
 {
     try {
-        if (!g_engine) throw std::runtime_error("Engine not initialized");
+        mi_unet_group_t *group = get_engine_group();
+        if (!group) throw std::runtime_error("Engine not initialized");
         const size_t hw = (size_t)g_cfg.height * g_cfg.width;
-        std::vector<uint8_t> in(hw * gray_imgs.size()), out(hw * gray_imgs.size());
-        for (size_t i = 0; i < gray_imgs.size(); ++i) {
-            const Image8 &g = gray_imgs[i];
-            if (g.rows != g_cfg.height || g.cols != g_cfg.width || g.channels != 1)
-                throw std::runtime_error("Input size must be 512x512 for fixed context");     // src/process.cpp:127
-            std::copy(g.data.begin(), g.data.end(), in.begin() + i * hw);
-        }
+        std::vector<const Image8 *> ptrs;
+        for (const Image8 &g : gray_imgs) ptrs.push_back(&g);
+        const std::vector<uint8_t> in = interleave_gray(ptrs, g_cfg.in_ch);
+        std::vector<uint8_t> out(hw * gray_imgs.size());
         {
-            std::lock_guard<std::mutex> lk(g_infer_mutex);
-            if (mi_unet_infer_u8(g_engine, in.data(), (int)gray_imgs.size(), out.data(), nullptr) != MI_UNET_OK)
+            std::lock_guard<std::mutex> lk(g_batch_mutex);
+            if (mi_unet_group_infer_u8(group, in.data(), (int)gray_imgs.size(), out.data(), nullptr) != MI_UNET_OK)
                 throw std::runtime_error(mi_unet_last_error());
         }
         std::vector<Image8> masks;
@@ -105,9 +226,18 @@ std::vector<Image8> execute_inference_batch(const std::vector<Image8> &gray_imgs
     }
 }
 
+// One tile on the calling thread's own context (src/process.cpp:123-175).
 Image8 execute_inference(const Image8 &gray_img)
 {
-    return execute_inference_batch({ gray_img })[0];
+    try {
+        mi_unet_t *ctx = get_thread_local_context();
+        const std::vector<uint8_t> in = interleave_gray({ &gray_img }, g_cfg.in_ch);
+        Image8 mask(g_cfg.height, g_cfg.width, 1);
+        if (mi_unet_infer_u8(ctx, in.data(), 1, mask.data.data(), nullptr) != MI_UNET_OK) throw std::runtime_error(mi_unet_last_error());
+        return mask;
+    } catch (const std::exception &e) {
+        throw std::runtime_error("Inference failed: " + std::string(e.what()));               // src/process.cpp:173
+    }
 }
 
 Image8 mask_to_image(const Image8 &mask)
@@ -216,22 +346,31 @@ ChunkOut device_chunk(const ChunkIn &in, const std::vector<int> &widths, const s
     ChunkOut out;
     std::vector<const uint16_t *> ptrs;
     std::vector<int> ws, hs;
+    const int C = g_cfg.in_ch;
     for (size_t k = 0; k < in.count; ++k)
         if (in.read_err[k].empty()) {
             out.idx.push_back(k);
-            ptrs.push_back(in.raws[k].data()); ws.push_back(widths[in.first + k]); hs.push_back(heights[in.first + k]);
+            for (int c = 0; c < C; ++c) {      // one plane per file: it feeds every input channel (include/mi_unet.h, mi_unet_infer_raw16)
+                ptrs.push_back(in.raws[k].data()); ws.push_back(widths[in.first + k]); hs.push_back(heights[in.first + k]);
+            }
         }
     if (out.idx.empty()) return out;
     const size_t hw = (size_t)g_cfg.height * g_cfg.width, m = out.idx.size();
+    std::vector<uint8_t> tiles_c(C > 1 ? hw * m * C : 0);
     out.tiles.resize(hw * m); out.labels.resize(hw * m);
     out.xy.resize(m * kCapPoints * 2); out.start.resize(m * (kCapContours + 1)); out.cnt.resize(m);
     const auto t0 = std::chrono::high_resolution_clock::now();
+    mi_unet_group_t *group = get_engine_group();
+    if (!group) throw std::runtime_error("Engine not initialized");
     {
-        std::lock_guard<std::mutex> lk(g_infer_mutex);
-        if (mi_unet_segment_raw16(g_engine, ptrs.data(), ws.data(), hs.data(), (int)m, out.tiles.data(), out.labels.data(),
-                                  out.xy.data(), kCapPoints, out.start.data(), kCapContours, out.cnt.data()) != MI_UNET_OK)
+        std::lock_guard<std::mutex> lk(g_batch_mutex);
+        if (mi_unet_group_segment_raw16(group, ptrs.data(), ws.data(), hs.data(), (int)m, C > 1 ? tiles_c.data() : out.tiles.data(),
+                                        out.labels.data(), out.xy.data(), kCapPoints, out.start.data(), kCapContours,
+                                        out.cnt.data()) != MI_UNET_OK)
             throw std::runtime_error(std::string("Inference failed: ") + mi_unet_last_error());
     }
+    if (C > 1)                                 // the artefact is the grey tile: channel 0 of the replicated planes
+        for (size_t p = 0; p < hw * m; ++p) out.tiles[p] = tiles_c[p * C];
     out.device_ms = std::chrono::duration_cast<std::chrono::milliseconds>(std::chrono::high_resolution_clock::now() - t0).count();
     return out;
 }
@@ -290,7 +429,8 @@ int process_batch_pipelined(const std::vector<std::string> &paths, const std::ve
                             const std::string &output_dir)
 {
     auto &log_file = get_log_file();
-    const size_t n = paths.size(), step = (size_t)std::max(1, g_cfg.max_batch);
+    // a chunk = one micro-batch on every device of the group
+    const size_t n = paths.size(), step = (size_t)std::max(1, g_cfg.max_batch) * (size_t)std::max(1, mi_unet_group_size(get_engine_group()));
     int ok = 0;
     auto emit = [&](const ChunkIn &in, const ChunkOut &out, const ChunkText &tx) {
         for (size_t k = 0; k < tx.con.size(); ++k) {
@@ -321,9 +461,14 @@ int process_batch_pipelined(const std::vector<std::string> &paths, const std::ve
             }
         try {
             st->out = device_chunk(st->in, widths, heights);
-        } catch (...) {
-            if (pending_art.valid()) emit(art_stage->in, art_stage->out, pending_art.get());
-            throw;
+        } catch (const std::exception &e) {
+            // this chunk's images fail (message as process_single_image's); chunks already done keep their successes and
+            // the chunks behind it still run
+            const std::string msg = std::string("Processing error: ") + e.what() + " (files " + std::to_string(first) + ".." +
+                                    std::to_string(first + st->in.count - 1) + " of the batch)";
+            std::cerr << msg << std::endl;
+            if (log_file.is_open()) log_file << msg << std::endl;
+            continue;
         }
         for (auto &r : st->in.raws) std::vector<uint16_t>().swap(r);      // the RAW images are on the device's side now
         if (pending_art.valid()) emit(art_stage->in, art_stage->out, pending_art.get());
@@ -348,7 +493,8 @@ int process_image_batch(const std::vector<std::string> &raw_paths, const std::ve
     auto &log_file = get_log_file();
     int ok = 0;
     try {
-        if (!g_engine) throw std::runtime_error("Engine not initialized");
+        mi_unet_group_t *group = get_engine_group();
+        if (!group) throw std::runtime_error("Engine not initialized");
         const size_t n = raw_paths.size();
         if (widths.size() != n || heights.size() != n) throw std::runtime_error("widths/heights do not match raw_paths");
         if (n > 0 && device_postprocess_requested() && device_contours_requested())
@@ -369,9 +515,11 @@ int process_image_batch(const std::vector<std::string> &raw_paths, const std::ve
                 raws[i].clear();
             }
         }
+        const int C = g_cfg.in_ch;
         for (size_t i = 0; i < n; ++i) {
             if (read_err[i].empty()) {
-                ptrs.push_back(raws[i].data()); ws.push_back(widths[i]); hs.push_back(heights[i]); idx.push_back(i);
+                for (int c = 0; c < C; ++c) { ptrs.push_back(raws[i].data()); ws.push_back(widths[i]); hs.push_back(heights[i]); }
+                idx.push_back(i);
             } else {
                 std::cerr << read_err[i] << std::endl;
                 if (log_file.is_open()) log_file << read_err[i] << std::endl;
@@ -381,16 +529,20 @@ int process_image_batch(const std::vector<std::string> &raw_paths, const std::ve
             log_file << "Batch read time: " << std::chrono::duration_cast<std::chrono::milliseconds>(std::chrono::high_resolution_clock::now() - t_read).count()
                      << " ms for " << n << " files" << std::endl;
         const size_t hw = (size_t)g_cfg.height * g_cfg.width;
-        std::vector<uint8_t> tiles(hw * idx.size()), labels(hw * idx.size());
+        std::vector<uint8_t> tiles(hw * idx.size() * C), labels(hw * idx.size());
         const auto t0 = std::chrono::high_resolution_clock::now();
         const bool dev_post = device_postprocess_requested();
         {
-            std::lock_guard<std::mutex> lk(g_infer_mutex);
-            mi_unet_set_postprocess(g_engine, dev_post ? 1 : 0);
-            const int rc = idx.empty() ? MI_UNET_OK : mi_unet_infer_raw16(g_engine, ptrs.data(), ws.data(), hs.data(), (int)idx.size(),
-                                                                          tiles.data(), labels.data(), nullptr);
-            mi_unet_set_postprocess(g_engine, 0);
+            std::lock_guard<std::mutex> lk(g_batch_mutex);
+            mi_unet_group_set_postprocess(group, dev_post ? 1 : 0);
+            const int rc = idx.empty() ? MI_UNET_OK : mi_unet_group_infer_raw16(group, ptrs.data(), ws.data(), hs.data(), (int)idx.size(),
+                                                                                tiles.data(), labels.data(), nullptr);
+            mi_unet_group_set_postprocess(group, 0);
             if (rc != MI_UNET_OK) throw std::runtime_error(std::string("Inference failed: ") + mi_unet_last_error());
+        }
+        if (C > 1) {                               // keep channel 0 (the planes are replicas): the grey artefact tile
+            for (size_t p = 0; p < hw * idx.size(); ++p) tiles[p] = tiles[p * C];
+            tiles.resize(hw * idx.size());
         }
         const auto ms = std::chrono::duration_cast<std::chrono::milliseconds>(std::chrono::high_resolution_clock::now() - t0).count();
         if (log_file.is_open()) log_file << "Batch inference time: " << ms << " ms for " << idx.size() << " images" << std::endl;
@@ -417,12 +569,19 @@ int process_image_batch(const std::vector<std::string> &raw_paths, const std::ve
     return ok;
 }
 
+// One image on the CALLING THREAD'S own context (the reference's thread_local TensorRTContext, src/process.cpp:15): callers
+// on different threads run concurrently.  The image's log block is collected and written in one piece, so blocks of
+// concurrent images do not interleave (the reference's global stream is written unguarded, src/initialize.cpp:22).
 bool process_single_image(const std::string &raw_path, int width, int height, const std::string &output_dir)
 {
+    std::ostringstream lg;
+    auto flush_log = [&lg] {
+        std::lock_guard<std::mutex> lk(g_log_mutex);
+        if (g_log_file.is_open()) g_log_file << lg.str() << std::flush;
+    };
     try {
-        auto &log_file = get_log_file();
-        if (!g_engine) throw std::runtime_error("Engine not initialized");
-        log_file << "\n=== Processing Image: " << fs::path(raw_path).filename().string() << " ===" << std::endl;
+        mi_unet_t *ctx = get_thread_local_context();           // throws "Engine not initialized"
+        lg << "\n=== Processing Image: " << fs::path(raw_path).filename().string() << " ===" << std::endl;
         const std::string base_name = fs::path(raw_path).stem().string();
         const auto total_start = std::chrono::high_resolution_clock::now();
 
@@ -430,15 +589,27 @@ bool process_single_image(const std::string &raw_path, int width, int height, co
             // the reference's own order: CPU preprocess -> PNG on disk -> read back -> inference (src/process.cpp:211-224)
             const std::string preprocessed_png_path = output_dir + "/" + base_name + "_normalized.png";
             const std::string size_json_path = output_dir + "/" + base_name + "_original_sizes.json";
-            if (!Preprocess::preprocess_raw(raw_path, preprocessed_png_path, size_json_path, width, height))
-                throw std::runtime_error("Preprocessing failed");
+            bool pre_ok;
+            if (g_cfg.width == 512 && g_cfg.height == 512) {
+                pre_ok = Preprocess::preprocess_raw(raw_path, preprocessed_png_path, size_json_path, width, height);
+            } else {                                           // a tile size the reference never had: same arithmetic, engine's size
+                try {
+                    const std::vector<uint16_t> raw = Preprocess::read_raw16(raw_path, width, height);
+                    pre_ok = Preprocess::write_preprocess_outputs(Preprocess::resample_normalize(raw.data(), width, height, g_cfg.width, g_cfg.height),
+                                                                  raw_path, preprocessed_png_path, size_json_path, width, height);
+                } catch (const std::exception &e) {
+                    std::cerr << "preprocess_raw error: " << e.what() << '\n';
+                    pre_ok = false;
+                }
+            }
+            if (!pre_ok) throw std::runtime_error("Preprocessing failed");
             const Image8 gray_img = medseg::read_png(preprocessed_png_path, /*as_color=*/false);
             if (gray_img.empty()) throw std::runtime_error("Failed to read preprocessed image");
             const auto infer_start = std::chrono::high_resolution_clock::now();
             Image8 pred_mask = execute_inference(gray_img);
             const auto infer_ms = std::chrono::duration_cast<std::chrono::milliseconds>(
                                       std::chrono::high_resolution_clock::now() - infer_start).count();
-            log_file << "Inference time: " << infer_ms << " ms" << std::endl;
+            lg << "Inference time: " << infer_ms << " ms" << std::endl;
             finish_image(raw_path, width, height, output_dir, gray_img, std::move(pred_mask), false);
         } else {
             // device-first: min/max + resample + quantise run on the GPU in front of the network; the tile
@@ -450,45 +621,57 @@ bool process_single_image(const std::string &raw_path, int width, int height, co
                 std::cerr << "preprocess_raw error: " << e.what() << '\n';
                 throw std::runtime_error("Preprocessing failed");
             }
-            const uint16_t *rp = raw.data();
+            const int C = g_cfg.in_ch;
+            const std::vector<const uint16_t *> planes(C, raw.data());   // one plane feeds every input channel
+            const std::vector<int> ws(C, width), hs(C, height);
+            const size_t hw = (size_t)g_cfg.height * g_cfg.width;
+            std::vector<uint8_t> tile_c(hw * C);
             Image8 tile(g_cfg.height, g_cfg.width, 1), pred_mask(g_cfg.height, g_cfg.width, 1);
             const auto infer_start = std::chrono::high_resolution_clock::now();
             const bool dev_post = device_postprocess_requested();
-            {
-                std::lock_guard<std::mutex> lk(g_infer_mutex);
-                mi_unet_set_postprocess(g_engine, dev_post ? 1 : 0);
-                const int rc = mi_unet_infer_raw16(g_engine, &rp, &width, &height, 1, tile.data.data(), pred_mask.data.data(), nullptr);
-                mi_unet_set_postprocess(g_engine, 0);
-                if (rc != MI_UNET_OK) throw std::runtime_error(std::string("Inference failed: ") + mi_unet_last_error());
-            }
+            mi_unet_set_postprocess(ctx, dev_post ? 1 : 0);    // the context belongs to this thread: no lock
+            const int rc = mi_unet_infer_raw16(ctx, planes.data(), ws.data(), hs.data(), 1, tile_c.data(), pred_mask.data.data(), nullptr);
+            mi_unet_set_postprocess(ctx, 0);
+            if (rc != MI_UNET_OK) throw std::runtime_error(std::string("Inference failed: ") + mi_unet_last_error());
+            for (size_t p = 0; p < hw; ++p) tile.data[p] = tile_c[p * C];
             const auto infer_ms = std::chrono::duration_cast<std::chrono::milliseconds>(
                                       std::chrono::high_resolution_clock::now() - infer_start).count();
-            log_file << "Inference time: " << infer_ms << " ms" << std::endl;
+            lg << "Inference time: " << infer_ms << " ms" << std::endl;
             finish_image(raw_path, width, height, output_dir, tile, std::move(pred_mask), dev_post);
         }
 
         const auto total_ms = std::chrono::duration_cast<std::chrono::milliseconds>(
                                   std::chrono::high_resolution_clock::now() - total_start).count();
-        log_file << "Total processing time: " << total_ms << " ms" << std::endl;
-        log_file << "Processing completed for: " << base_name << std::endl;
+        lg << "Total processing time: " << total_ms << " ms" << std::endl;
+        lg << "Processing completed for: " << base_name << std::endl;
+        flush_log();
         std::cout << "Total processing time: " << total_ms << " ms" << std::endl;
         return true;
     } catch (const std::exception &e) {
         std::cerr << "Processing error: " << e.what() << std::endl;
-        auto &log_file = get_log_file();
-        if (log_file.is_open()) log_file << "Processing error: " << e.what() << std::endl;
+        lg << "Processing error: " << e.what() << std::endl;
+        flush_log();
         return false;
     }
 }
 
+// Releases the calling thread's context (as the reference does, src/cleanup.cpp:16-35), the engine group and the log.
+// Contexts of other threads notice the generation change and are released on their next use or when their thread ends
+// (they share the weight blob, which lives until the last of them is gone).
 void cleanup_resources()
 {
     try {
-        auto &log_file = get_log_file();
+        std::lock_guard<std::mutex> lk(g_state_mutex);
+        auto &log_file = g_log_file;
         if (log_file.is_open()) log_file << "\n=== Cleaning Up Resources ===" << std::endl;
-        if (g_engine) {
-            mi_unet_destroy(g_engine);         // device buffers, stream, weights
-            g_engine = nullptr;
+        if (t_context.h) {
+            t_context.release();
+            if (log_file.is_open()) log_file << "Execution context destroyed" << std::endl;
+        }
+        ++g_generation;
+        if (g_group) {
+            mi_unet_group_destroy(g_group);         // every device's buffers, streams, worker thread, weights
+            g_group = nullptr;
             if (log_file.is_open()) log_file << "MI355X UNet engine destroyed" << std::endl;
         }
         if (log_file.is_open()) {

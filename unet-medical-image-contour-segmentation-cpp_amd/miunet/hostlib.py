@@ -16,7 +16,7 @@ _i32 = np.ctypeslib.ndpointer(np.int32, flags="C_CONTIGUOUS")
 
 EXPORTS = ["medseg_initialize_engine", "medseg_process_single_image", "medseg_process_image_batch", "medseg_cleanup_resources", "medseg_get_log_path",
            "medseg_preprocess_raw", "medseg_resample_normalize", "medseg_postprocess_mask", "medseg_mask_to_image",
-           "medseg_extract_contours", "medseg_map_points", "medseg_generate_json", "medseg_process_single_mask",
+           "medseg_extract_contours", "medseg_map_points", "medseg_generate_json", "medseg_draw_overlay", "medseg_process_single_mask",
            "medseg_write_png", "medseg_read_png"]
 
 
@@ -39,6 +39,7 @@ def lib():
         L.medseg_map_points.argtypes = [_i32, C.c_int, C.c_double, C.c_double, _i32]
         L.medseg_map_points.restype = None
         L.medseg_generate_json.argtypes = [_i32, _i32, C.c_int, C.c_char_p, C.c_char_p, C.c_int, C.c_int]
+        L.medseg_draw_overlay.argtypes = [_u8, C.c_int, C.c_int, _i32, _i32, C.c_int, _u8]
         L.medseg_process_single_mask.argtypes = [C.c_char_p] * 5
         L.medseg_process_single_mask.restype = None
         L.medseg_write_png.argtypes = [C.c_char_p, _u8, C.c_int, C.c_int, C.c_int, C.c_int]
@@ -103,6 +104,18 @@ def generate_json(contours, json_path, base_name, ow, oh):
     start[1:] = np.cumsum([len(c) for c in contours])
     if lib().medseg_generate_json(np.ascontiguousarray(flat).reshape(-1), start, len(contours), _b(json_path), base_name.encode(), ow, oh):
         raise RuntimeError("generate_json failed")
+
+
+def draw_overlay(gray, contours):
+    """gray u8 [h][w] + contours -> BGR u8 [h][w][3] (the _contour_overlay.png pixels)"""
+    g = np.ascontiguousarray(gray, np.uint8)
+    flat = np.array([p for c in contours for p in c], np.int32).reshape(-1, 2)
+    start = np.zeros(len(contours) + 1, np.int32)
+    start[1:] = np.cumsum([len(c) for c in contours])
+    out = np.empty(g.shape + (3,), np.uint8)
+    if lib().medseg_draw_overlay(g, g.shape[1], g.shape[0], np.ascontiguousarray(flat).reshape(-1), start, len(contours), out.reshape(-1)):
+        raise RuntimeError("draw_overlay failed")
+    return out
 
 
 def process_single_mask(mask_path, output_dir, json_path, original_png, base_name):
