@@ -117,6 +117,33 @@ def test_conv3x3_wino4(B, H, W, Cin, Cout):
     assert np.max(np.abs(got - ref)) < _tol(ref)
 
 
+@pytest.mark.parametrize("B,H,W,Cin,Cout", [
+    (2, 32, 32, 64, 64),       # the 64 -> 64 layers (inc.c2, up4.c2)
+    (1, 21, 35, 128, 64),      # up4.c1's channels, ragged blocks
+    (1, 16, 16, 32, 192),      # three n-tiles of 64
+    (1, 16, 16, 32, 48),       # Cout < 64 (masked columns)
+    (1, 9, 33, 24, 40),        # Cin % 16 != 0 (masked last chunk)
+    (1, 18, 18, 16, 64),       # a single chunk, a 2-pixel rim past the block boundary
+    (2, 16, 32, 48, 64),       # odd chunk count
+])
+def test_conv3x3_wino4s_two_workgroups_per_cu(B, H, W, Cin, Cout):
+    """conv_wino4s.hip (single-buffered, two workgroups per CU) is the arithmetic of the persistent one-block kernel in a
+    different schedule: within tolerance of the oracle, and within fma-contraction noise of that kernel (the compiler
+    contracts the transforms' multiply-adds differently in the two instruction streams)."""
+    r = _rng(B * 1000 + H * 100 + W + Cin + Cout + 7)
+    x = r.standard_normal((B, H, W, Cin), dtype=np.float32)
+    w = (r.standard_normal((Cout, Cin, 3, 3), dtype=np.float32) * np.sqrt(2.0 / (9 * Cin))).astype(np.float32)
+    scale = (1.0 + 0.1 * r.standard_normal(Cout)).astype(np.float32)
+    shift = (0.1 * r.standard_normal(Cout)).astype(np.float32)
+    got = binding.layer_debug("conv3x3_wino4s", x, w, scale, shift, relu=True)
+    ref = np.maximum(orc.conv3x3(x, w) * scale + shift, 0.0)
+    assert not np.isnan(got).any(), "unwritten (NaN-poisoned) outputs"
+    assert np.max(np.abs(got - ref)) < _tol(ref)
+    if Cout <= 64 or Cout % 128 == 64:        # shapes the other entry point also runs as one block (small grid: persistent kernel)
+        other = binding.layer_debug("conv3x3_wino4", x, w, scale, shift, relu=True)
+        assert np.max(np.abs(got - other)) < 2e-5 * max(1.0, float(np.abs(ref).max()))
+
+
 def test_conv3x3_wino4_tap_orientation_exact():
     # G of F(4x4,3x3) has 1/4, 1/6, 1/12, 1/24: a single tap of weight 576 makes every U entry an integer, small-integer
     # inputs keep every intermediate exactly representable, so the result must equal the direct sum bit for bit; single

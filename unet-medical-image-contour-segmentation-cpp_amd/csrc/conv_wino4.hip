@@ -1,7 +1,9 @@
 // conv_wino4.hip -- Winograd F(4x4,3x3) convolution on the fp32 MFMA (v_mfma_f32_16x16x4_f32), gfx950 only.
+#include <cstdlib>
 #include <type_traits>
 
 #include "kernel_common.h"
+#include "wino4_common.h"
 
 namespace miunet {
 
@@ -28,24 +30,6 @@ namespace miunet {
 //     are threaded between the MFMAs of the chunk that precedes their use;
 //   * K order inside a 16-channel chunk: MFMA step s of lane group kq consumes channel 4*kq + s (one ds_read_b128 / one
 //     buffer_load_b128 per lane feeds four MFMA steps).
-// a - b on packed pairs: hipcc scalarises a plain fsub of <4 x float> into four v_sub_f32; two v_pk_add_f32 with a negated
-// operand do the same work in half the issue slots (the matrix pipe shares them)
-typedef float f32x2 __attribute__((ext_vector_type(2)));
-__device__ __forceinline__ f32x4 pk_sub(const f32x4 a, const f32x4 b)
-{
-    f32x2 lo, hi;
-    asm("v_pk_add_f32 %0, %1, %2 neg_lo:[0,1] neg_hi:[0,1]" : "=v"(lo) : "v"(a.lo), "v"(b.lo));
-    asm("v_pk_add_f32 %0, %1, %2 neg_lo:[0,1] neg_hi:[0,1]" : "=v"(hi) : "v"(a.hi), "v"(b.hi));
-    return __builtin_shufflevector(lo, hi, 0, 1, 2, 3);
-}
-
-__device__ __forceinline__ f32x2 pk_sub2(const f32x2 a, const f32x2 b)
-{
-    f32x2 r;
-    asm("v_pk_add_f32 %0, %1, %2 neg_lo:[0,1] neg_hi:[0,1]" : "=v"(r) : "v"(a), "v"(b));
-    return r;
-}
-
 // 72 accumulators of 4 registers do not fit the 256 AGPRs: hipcc then shuttles the overflow through AGPRs around every
 // MFMA (64 v_accvgpr moves per chunk).  The last four positions of the two-block kernel therefore use the VGPR form of the
 // instruction directly; their results are only ever re-read as SrcC of the next MFMA on the same registers (the
@@ -55,23 +39,6 @@ __device__ __forceinline__ void mfma16_vgpr(f32x4 &acc, const float a, const flo
     asm("v_mfma_f32_16x16x4_f32 %0, %1, %2, %0" : "+v"(acc) : "v"(a), "v"(b));
 }
 
-struct W4 {
-    static constexpr int TMB = 16;                          // 4x4 output tiles per workgroup (4 wide x 4 tall)
-    static constexpr int VROW = WINO4_KC + 4;               // padded floats per tile row of V
-    static constexpr int VPOS = TMB * VROW;                 // floats per position
-    static constexpr int VBUF = 36 * VPOS;                  // floats per V buffer
-    static constexpr int RAWPIX = 18 * 18;
-    // the raw patch of one 16-channel chunk is written by LDS-DMA loads (buffer_load_dwordx4 ... lds: 64 lanes x 16 bytes
-    // land CONTIGUOUSLY, no padding possible), so bank spreading comes from the ORDER of the pixel slots instead: a patch
-    // row holds 20 slots of 64 bytes and pixel x = 4a + c sits in slot 5c + a -- the four tiles of a 16-lane group read
-    // x, x+4, x+8, x+12 = consecutive slots = four distinct 16-word bank groups, times four channel quads = all 64 banks.
-    static constexpr int RAW_ROW = 20;                      // pixel slots per patch row (18 live)
-    static constexpr int RAW_SLOTS = 18 * RAW_ROW;          // 360 live slots, written by 23 wave-wide loads of 16 slots
-    static constexpr int RAW_LOADS = (RAW_SLOTS + 15) / 16; // 23
-    static constexpr int RAW_FLOATS = RAW_LOADS * 16 * WINO4_KC;   // buffer padded to whole loads (dead lanes write zeros)
-    static constexpr int RAW_ITERS = (RAW_LOADS + 3) / 4;   // loads per wave (6; wave 3 skips its last)
-    static constexpr size_t LDS_BYTES = sizeof(float) * (2 * VBUF + 2 * RAW_FLOATS);
-};
 
 // NB = 16-channel blocks per wave: 2 (workgroup = 128 output channels) or 1 (64 channels, for the Cout = 64 layers: half
 // the MFMA work per transformed tile, but still 1.6x the F(2x2) kernel there).
@@ -539,6 +506,16 @@ hipError_t launch_conv3x3_wino4(const ConvArgs &a, hipStream_t s)
     if (a.wpk4 == nullptr || a.Cin % 4 || a.ldc % 4 || a.CoutPad % NPAD) return hipErrorInvalidValue;
     // 128 output channels per workgroup when Cout fills them; 64 for the Cout = 64 layers (and any Cout % 128 in (0, 64])
     const int rem = a.Cout % 128;
+    // one-block cases whose grid fills the chip twice over go to the two-workgroups-per-CU kernel (conv_wino4s.hip);
+    // small grids keep the persistent kernel below and its split-K
+    // (MIUNET_WINO4S = 0: never; 2: every one-block case whatever its grid -- for parity tests on small shapes)
+    const char *w4s = getenv("MIUNET_WINO4S");
+    const int staged = w4s ? atoi(w4s) : 1;
+    const long long wg1 = (long long)((a.W + 15) / 16) * ((a.H + 15) / 16) * a.B * ((a.Cout + 63) / 64);
+    const bool one_block = a.head_w != nullptr || !(a.Cout >= 128 && (rem == 0 || rem > 64));
+    // a.ksplit_ws == nullptr is the batch-invariant mode (MIUNET_SPLITK=0): there the choice must not depend on the batch
+    if (one_block && (staged == 2 || (staged == 1 && (wg1 >= 2 * persistent_cus() || a.ksplit_ws == nullptr))))
+        return launch_conv3x3_wino4s(a, s);
     if (a.head_w != nullptr) {
         if (a.Cout > 64 || a.head_classes < 1 || a.head_classes > 4 || a.pool_out != nullptr || a.head_labels == nullptr)
             return hipErrorInvalidValue;

@@ -1162,7 +1162,7 @@ int mi_unet_layer_debug(int device, const char *op, const float *in, int B, int 
         out_n = (size_t)B * 4 * H * W * Cout;
         a.B = B; a.H = H; a.W = W; a.Cin = Cin; a.ldc = Cin; a.Cout = Cout; a.CoutPad = convT_taps_cpad(Cout); a.ldo = Cout; a.co_off = 0;
         a.relu = relu;
-    } else if (o == "conv3x3_wino4") {
+    } else if (o == "conv3x3_wino4" || o == "conv3x3_wino4s") {
         if (!w || Cout <= 0 || Cin % 4) return fail(MI_UNET_EARG, "layer_debug: conv needs weights and Cin % 4 == 0");
         const int nch = (Cin + WINO4_KC - 1) / WINO4_KC;
         const size_t npad = round_up((size_t)Cout, NPAD);
@@ -1256,9 +1256,10 @@ int mi_unet_layer_debug(int device, const char *op, const float *in, int B, int 
         DBG_TRY(hipMemcpy(d_w, wpk.data(), sizeof(float) * wpk.size(), hipMemcpyHostToDevice));
         DBG_TRY(hipMemcpy(d_b, bias.data(), sizeof(float) * bias.size(), hipMemcpyHostToDevice));
         a.in = d_in; a.wpk = d_w; a.bias = d_b; a.out = d_out;
-        if (o == "conv3x3_wino4" || o == "convT2x2_taps") a.wpk4 = d_w;
+        if (o == "conv3x3_wino4" || o == "conv3x3_wino4s" || o == "convT2x2_taps") a.wpk4 = d_w;
         DBG_TRY(o == "conv3x3" ? launch_conv3x3_mfma(a, nullptr)
                 : o == "conv3x3_wino4" ? launch_conv3x3_wino4(a, nullptr)
+                : o == "conv3x3_wino4s" ? launch_conv3x3_wino4s(a, nullptr)
                 : o == "convT2x2_taps" ? launch_convT2x2_taps(a, nullptr)
                 : o == "conv3x3_wino" ? launch_conv3x3_wino(a, nullptr)
                 : o == "conv3x3_wino16" ? launch_conv3x3_wino16(a, nullptr)

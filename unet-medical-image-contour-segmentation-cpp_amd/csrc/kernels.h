@@ -64,6 +64,10 @@ hipError_t launch_conv3x3_wino16(const ConvArgs &a, hipStream_t s);
 constexpr int WINO4_KC = 16;
 constexpr int WINO4_SC = 32;
 hipError_t launch_conv3x3_wino4(const ConvArgs &a, hipStream_t s);
+// The same algorithm for Cout <= 64 per workgroup with single-buffered 70 KB of LDS and <= 256 registers, so that two
+// workgroups share a CU (conv_wino4s.hip); same packing (a.wpk4), bit-identical results, no split-K.  launch_conv3x3_wino4
+// routes its one-block cases here unless MIUNET_WINO4S=0.
+hipError_t launch_conv3x3_wino4s(const ConvArgs &a, hipStream_t s);
 hipError_t launch_wino_splitk_reduce(const ConvArgs &a, hipStream_t s);   // sums a.ksplit slabs of a.ksplit_ws into a.out
 hipError_t launch_convT2x2_mfma(const ConvArgs &a, hipStream_t s);
 // The transposed conv as four per-tap GEMMs sharing one A operand (convt_taps.hip): a.wpk4 holds the weights packed

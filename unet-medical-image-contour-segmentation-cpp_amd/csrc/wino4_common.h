@@ -1,0 +1,45 @@
+// wino4_common.h -- pieces shared by the two Winograd F(4x4,3x3) kernels (conv_wino4.hip, conv_wino4s.hip).  Internal.
+#pragma once
+#include "kernel_common.h"
+
+namespace miunet {
+
+// a - b on packed pairs: hipcc scalarises a plain fsub of <4 x float> into four v_sub_f32; two v_pk_add_f32 with a negated
+// operand do the same work in half the issue slots (the matrix pipe shares them)
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ f32x4 pk_sub(const f32x4 a, const f32x4 b)
+{
+    f32x2 lo, hi;
+    asm("v_pk_add_f32 %0, %1, %2 neg_lo:[0,1] neg_hi:[0,1]" : "=v"(lo) : "v"(a.lo), "v"(b.lo));
+    asm("v_pk_add_f32 %0, %1, %2 neg_lo:[0,1] neg_hi:[0,1]" : "=v"(hi) : "v"(a.hi), "v"(b.hi));
+    return __builtin_shufflevector(lo, hi, 0, 1, 2, 3);
+}
+
+__device__ __forceinline__ f32x2 pk_sub2(const f32x2 a, const f32x2 b)
+{
+    f32x2 r;
+    asm("v_pk_add_f32 %0, %1, %2 neg_lo:[0,1] neg_hi:[0,1]" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+
+
+struct W4 {
+    static constexpr int TMB = 16;                          // 4x4 output tiles per workgroup (4 wide x 4 tall)
+    static constexpr int VROW = WINO4_KC + 4;               // padded floats per tile row of V
+    static constexpr int VPOS = TMB * VROW;                 // floats per position
+    static constexpr int VBUF = 36 * VPOS;                  // floats per V buffer
+    static constexpr int RAWPIX = 18 * 18;
+    // the raw patch of one 16-channel chunk is written by LDS-DMA loads (buffer_load_dwordx4 ... lds: 64 lanes x 16 bytes
+    // land CONTIGUOUSLY, no padding possible), so bank spreading comes from the ORDER of the pixel slots instead: a patch
+    // row holds 20 slots of 64 bytes and pixel x = 4a + c sits in slot 5c + a -- the four tiles of a 16-lane group read
+    // x, x+4, x+8, x+12 = consecutive slots = four distinct 16-word bank groups, times four channel quads = all 64 banks.
+    static constexpr int RAW_ROW = 20;                      // pixel slots per patch row (18 live)
+    static constexpr int RAW_SLOTS = 18 * RAW_ROW;          // 360 live slots, written by 23 wave-wide loads of 16 slots
+    static constexpr int RAW_LOADS = (RAW_SLOTS + 15) / 16; // 23
+    static constexpr int RAW_FLOATS = RAW_LOADS * 16 * WINO4_KC;   // buffer padded to whole loads (dead lanes write zeros)
+    static constexpr int RAW_ITERS = (RAW_LOADS + 3) / 4;   // loads per wave (6; wave 3 skips its last)
+    static constexpr size_t LDS_BYTES = sizeof(float) * (2 * VBUF + 2 * RAW_FLOATS);
+};
+
+}  // namespace miunet
