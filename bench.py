@@ -333,6 +333,12 @@ def main():
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         raise SystemExit(spawn_torchrun(args))
 
+    # stdout carries exactly ONE line, the JSON record: everything libraries print while the bench runs (RCCL's version
+    # banner at the first collective, the facade's per-image lines) goes to stderr instead
+    sys.stdout.flush()
+    json_fd = os.dup(1)
+    os.dup2(2, 1)
+
     import numpy as np
     import torch
 
@@ -504,7 +510,8 @@ def main():
             out["cpu_baseline"] = cpu_baseline(blob, H, W, spec.in_ch, oracle_s)
         else:
             out["cpu_baseline"] = None
-        print(json.dumps(out))
+        sys.stdout.flush()
+        os.write(json_fd, (json.dumps(out) + "\n").encode())
         bad = [k for k in ("parity",) if out.get(k) and not out[k]["ok"]]
         if extras and isinstance(out.get("configs"), list):           # recorded; only the headline and the exact pipeline gate the exit code
             for c in out["configs"]:

@@ -1,4 +1,5 @@
 // convt_taps.hip -- the 2x2 / stride-2 transposed convolution as four GEMMs that share one A operand, gfx950 only.
+#include <cstdlib>
 #include <type_traits>
 
 #include "kernel_common.h"
@@ -32,11 +33,13 @@ struct CTGeom {
     static constexpr size_t LDS_BYTES = sizeof(float) * 2 * A_FLOATS;
 };
 
-template <int MB, int NBK>
-__global__ __launch_bounds__(256, 1) void convT2x2_taps_f32(const ConvArgs a, const int tiles_x, const int tiles_y,
-                                                            const int m_tiles, const int nwg, const int cpad)
+// WPS = waves per SIMD the kernel is built for: 1 = sixteen 32x32 accumulators per wave (256 registers, one workgroup per
+// CU), 2 = eight (two workgroups per CU: one runs its MFMAs while the other waits for its first loads or stores its tile)
+template <int MB, int NBK, int WPS>
+__global__ __launch_bounds__(256, WPS) void convT2x2_taps_f32(const ConvArgs a, const int tiles_x, const int tiles_y,
+                                                              const int m_tiles, const int nwg, const int cpad)
 {
-    static_assert(MB * NBK == 16, "sixteen 32x32 accumulators per wave");
+    static_assert(MB * NBK * WPS == 16, "sixteen (WPS = 1) or eight (WPS = 2) 32x32 accumulators per wave");
     using G = CTGeom<MB>;
     constexpr int A_P = G::A_P;
     constexpr int CPS = CT_SC / CT_KC;
@@ -183,14 +186,14 @@ __global__ __launch_bounds__(256, 1) void convT2x2_taps_f32(const ConvArgs a, co
     else epilogue(std::false_type{});
 }
 
-template <int MB, int NBK>
+template <int MB, int NBK, int WPS = 1>
 static hipError_t launch_taps_cfg(const ConvArgs &a, int cpad, hipStream_t s)
 {
     const int tiles_x = (a.W + 31) / 32, tiles_y = (a.H + MB - 1) / MB;
     const int m_tiles = tiles_x * tiles_y * a.B;
     const int n_tiles = (a.Cout + 32 * NBK - 1) / (32 * NBK);
     const int nwg = m_tiles * n_tiles;
-    auto kern = convT2x2_taps_f32<MB, NBK>;
+    auto kern = convT2x2_taps_f32<MB, NBK, WPS>;
     constexpr size_t lds = CTGeom<MB>::LDS_BYTES;
     if (hipError_t e = ensure_dynamic_lds(kern, lds); e != hipSuccess) return e;
     hipLaunchKernelGGL(kern, dim3(nwg), dim3(256), lds, s, a, tiles_x, tiles_y, m_tiles, nwg, cpad);
@@ -202,6 +205,17 @@ hipError_t launch_convT2x2_taps(const ConvArgs &a, hipStream_t s)
 {
     if (a.wpk4 == nullptr || a.Cin % 4 || a.ldc % 4) return hipErrorInvalidValue;
     const int cpad = convT_taps_cpad(a.Cout);
+    // default: half-size tiles, eight accumulators per wave, TWO workgroups per CU (measured 3-10 % faster than the
+    // sixteen-accumulator tiles on all four layers at batch 16: up1.t 0.501 -> 0.488 ms, up2.t 0.511 -> 0.499, up3.t 0.576 ->
+    // 0.529, up4.t 0.706 -> 0.630; the other eight-accumulator shapes -- <1,8> at Cout 256, <4,2> at 128, and four workgroups
+    // per CU with <2,2> at 64 -- were each within 2 % or slower); MIUNET_CONVT_WPS=1 keeps the large tiles
+    const char *wps = getenv("MIUNET_CONVT_WPS");
+    const int mode = wps ? atoi(wps) : 2;
+    if (mode == 2) {
+        if (a.Cout > 256) return launch_taps_cfg<1, 8, 2>(a, cpad, s);
+        if (a.Cout > 64) return launch_taps_cfg<2, 4, 2>(a, cpad, s);
+        return launch_taps_cfg<4, 2, 2>(a, cpad, s);
+    }
     if (a.Cout > 256) return launch_taps_cfg<1, 16>(a, cpad, s);
     if (a.Cout > 128) return launch_taps_cfg<2, 8>(a, cpad, s);
     if (a.Cout > 64) return launch_taps_cfg<4, 4>(a, cpad, s);
