@@ -43,11 +43,14 @@ LP_PEAK_TFLOPS = 2500.0       # dense bf16 / fp16 MFMA peak (v_mfma_f32_32x32x16
 HBM_PEAK_GBS = 8000.0
 
 # multiplies the MFMA pipe executes per algorithmic (direct-convolution) multiply, by kernel family
-WINOGRAD_REDUCTION = {"conv3x3_wino4": 4.0, "conv3x3_wino": 2.25, "conv3x3_wino16": 2.25}
-CONV_FAMILIES = ("conv3x3_mfma", "conv3x3_wino", "conv3x3_wino16", "conv3x3_wino4", "conv3x3_bf16", "conv3x3_fp16")
+WINOGRAD_REDUCTION = {"conv3x3_wino4": 4.0, "conv3x3_wino4s": 4.0, "conv3x3_wino": 2.25, "conv3x3_wino16": 2.25}
+CONV_FAMILIES = ("conv3x3_mfma", "conv3x3_wino", "conv3x3_wino16", "conv3x3_wino4", "conv3x3_wino4s", "conv3x3_bf16", "conv3x3_fp16")
 ROCPROF_NAME = {"conv3x3_wino": "miunet::conv3x3_wino_f32<*>", "conv3x3_wino16": "miunet::conv3x3_wino16_f32",
-                "conv3x3_wino4": "miunet::conv3x3_wino4_f32<*>", "conv3x3_mfma": "miunet::conv_mfma_f32<*>",
-                "conv3x3_bf16": "miunet::conv_mfma_bf16<*>", "conv3x3_fp16": "miunet::conv_mfma_bf16<*>"}
+                "conv3x3_wino4": "miunet::conv3x3_wino4_f32<*>", "conv3x3_wino4s": "miunet::conv3x3_wino4s_f32<*>",
+                "conv3x3_mfma": "miunet::conv_mfma_f32<*>", "convT2x2_taps": "miunet::convT2x2_taps_f32<*>",
+                "convT2x2_mfma": "miunet::conv_mfma_f32<*>", "conv3x3_first": "miunet::conv3x3_first_kernel<*>",
+                "conv3x3_bf16": "miunet::conv_mfma_bf16<*>", "conv3x3_fp16": "miunet::conv_mfma_bf16<*>",
+                "convT2x2_bf16": "miunet::conv_mfma_bf16<*>", "convT2x2_fp16": "miunet::conv_mfma_bf16<*>"}
 
 
 def family(kernel):
@@ -164,6 +167,21 @@ def roofline_from_stats(stats, spec_macs, ips_per_gpu, tag):
             else "v_mfma_f32_16x16x4_f32" if dom_kernel == "conv3x3_wino4" else "v_mfma_f32_32x32x2_f32")
     pmc, pmc_src = pmc_summary(tag)
     rk = (pmc or {}).get("kernels", {}).get(ROCPROF_NAME.get(dom_kernel, ""), {})
+    # every kernel family of the step, same arithmetic: executed = algorithmic / winograd_reduction (1 for the direct forms)
+    fam = {}
+    for s in stats:
+        e = fam.setdefault(family(s["kernel"]), [0, 0.0, 0.0, 0.0])
+        e[0] += 1; e[1] += s["ms"]; e[2] += s["flops"]; e[3] += s["bytes"]
+    families = []
+    for name, (n, ms, fl, by) in sorted(fam.items(), key=lambda kv: -kv[1][1]):
+        r = WINOGRAD_REDUCTION.get(name, 1.0)
+        pk = LP_PEAK_TFLOPS if (name.endswith("bf16") or name.endswith("fp16")) else FP32_PEAK_TFLOPS
+        c = (pmc or {}).get("kernels", {}).get(ROCPROF_NAME.get(name, ""), {})
+        families.append({"kernel": name, "launches": n, "share_of_device_time": ms / all_ms if all_ms else None,
+                         "avg_launch_ms": ms / n, "algorithmic_tflops": fl / ms / 1e9, "executed_tflops": fl / ms / 1e9 / r,
+                         "frac_of_mfma_peak": fl / ms / 1e9 / r / pk, "algorithmic_gbs": by / ms / 1e6,
+                         "frac_of_hbm_peak": by / ms / 1e6 / HBM_PEAK_GBS,
+                         "mfma_busy_pmc": c.get("mfma_busy"), "hbm_bytes_per_launch_pmc": c.get("hbm_bytes_per_launch")})
     return {
         "bound": "mfma", "kernel": f"{dom_kernel} ({insn})",
         "algorithm": {4.0: "winograd F(4x4,3x3)", 2.25: "winograd F(2x2,3x3)"}.get(red, "direct implicit GEMM"),
@@ -176,6 +194,7 @@ def roofline_from_stats(stats, spec_macs, ips_per_gpu, tag):
         "avg_launch_gflop": dom_flops / max(1, len(dom)) / 1e9,
         "share_of_device_time": dom_ms / all_ms if all_ms else None,
         "whole_net_algorithmic_tflops": 2.0 * spec_macs * ips_per_gpu / 1e12,
+        "families": families,
     }
 
 

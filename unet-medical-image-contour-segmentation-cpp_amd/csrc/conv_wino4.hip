@@ -501,21 +501,26 @@ static hipError_t launch_wino4_cfg(const ConvArgs &a0, hipStream_t s)
     return hipGetLastError();
 }
 
+// one-block cases whose grid fills the chip twice over go to the two-workgroups-per-CU kernel (conv_wino4s.hip); small
+// grids keep the persistent kernel and its split-K
+// (MIUNET_WINO4S = 0: never; 2: every one-block case whatever its grid -- for parity tests on small shapes)
+bool conv3x3_wino4_runs_staged(const ConvArgs &a)
+{
+    const char *w4s = getenv("MIUNET_WINO4S");
+    const int staged = w4s ? atoi(w4s) : 1;
+    const int rem = a.Cout % 128;
+    const long long wg1 = (long long)((a.W + 15) / 16) * ((a.H + 15) / 16) * a.B * ((a.Cout + 63) / 64);
+    const bool one_block = a.head_w != nullptr || !(a.Cout >= 128 && (rem == 0 || rem > 64));
+    // a.ksplit_ws == nullptr is the batch-invariant mode (MIUNET_SPLITK=0): there the choice must not depend on the batch
+    return one_block && (staged == 2 || (staged == 1 && (wg1 >= 2 * persistent_cus() || a.ksplit_ws == nullptr)));
+}
+
 hipError_t launch_conv3x3_wino4(const ConvArgs &a, hipStream_t s)
 {
     if (a.wpk4 == nullptr || a.Cin % 4 || a.ldc % 4 || a.CoutPad % NPAD) return hipErrorInvalidValue;
     // 128 output channels per workgroup when Cout fills them; 64 for the Cout = 64 layers (and any Cout % 128 in (0, 64])
     const int rem = a.Cout % 128;
-    // one-block cases whose grid fills the chip twice over go to the two-workgroups-per-CU kernel (conv_wino4s.hip);
-    // small grids keep the persistent kernel below and its split-K
-    // (MIUNET_WINO4S = 0: never; 2: every one-block case whatever its grid -- for parity tests on small shapes)
-    const char *w4s = getenv("MIUNET_WINO4S");
-    const int staged = w4s ? atoi(w4s) : 1;
-    const long long wg1 = (long long)((a.W + 15) / 16) * ((a.H + 15) / 16) * a.B * ((a.Cout + 63) / 64);
-    const bool one_block = a.head_w != nullptr || !(a.Cout >= 128 && (rem == 0 || rem > 64));
-    // a.ksplit_ws == nullptr is the batch-invariant mode (MIUNET_SPLITK=0): there the choice must not depend on the batch
-    if (one_block && (staged == 2 || (staged == 1 && (wg1 >= 2 * persistent_cus() || a.ksplit_ws == nullptr))))
-        return launch_conv3x3_wino4s(a, s);
+    if (conv3x3_wino4_runs_staged(a)) return launch_conv3x3_wino4s(a, s);
     if (a.head_w != nullptr) {
         if (a.Cout > 64 || a.head_classes < 1 || a.head_classes > 4 || a.pool_out != nullptr || a.head_labels == nullptr)
             return hipErrorInvalidValue;

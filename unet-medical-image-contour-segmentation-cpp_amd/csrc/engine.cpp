@@ -599,14 +599,14 @@ int launch_plan(mi_unet *h, const uint8_t *d_imgs, int B, uint8_t *d_labels, flo
                 // ... or whose grid is so small that the launcher splits K (<= 128 workgroups, >= 8 chunks of 16 channels)
                 const bool split4 = h->wino4_splitk && h->d_ksplit != nullptr && wg4 <= 128 && a.Cin >= 128 && st.head_step < 0;
                 if (a.wpk4 != nullptr && (wg4 >= min_wg4 || h->d_ksplit == nullptr || split4)) {
-                    kname = "conv3x3_wino4";
                     if (st.head_step >= 0) {   // fused 1x1 head + argmax: this layer's activations never reach HBM
                         const Step &hd = h->plan[st.head_step];
                         a.head_w = hd.w; a.head_b = hd.shift; a.head_classes = hd.Cout;
                         a.head_logits = d_logits; a.head_labels = d_labels;
                         head_done = true;
-                        kname = "conv3x3_wino4+head";
                     }
+                    const bool staged = conv3x3_wino4_runs_staged(a);      // conv_wino4s.hip: two workgroups per CU
+                    kname = staged ? (head_done ? "conv3x3_wino4s+head" : "conv3x3_wino4s") : (head_done ? "conv3x3_wino4+head" : "conv3x3_wino4");
                     e = launch_conv3x3_wino4(a, s);
                 }
                 else { kname = "conv3x3_wino"; e = launch_conv3x3_wino(a, s); }

@@ -68,6 +68,7 @@ hipError_t launch_conv3x3_wino4(const ConvArgs &a, hipStream_t s);
 // workgroups share a CU (conv_wino4s.hip); same packing (a.wpk4), bit-identical results, no split-K.  launch_conv3x3_wino4
 // routes its one-block cases here unless MIUNET_WINO4S=0.
 hipError_t launch_conv3x3_wino4s(const ConvArgs &a, hipStream_t s);
+bool conv3x3_wino4_runs_staged(const ConvArgs &a);   // the routing decision of launch_conv3x3_wino4 (for the launch log)
 hipError_t launch_wino_splitk_reduce(const ConvArgs &a, hipStream_t s);   // sums a.ksplit slabs of a.ksplit_ws into a.out
 hipError_t launch_convT2x2_mfma(const ConvArgs &a, hipStream_t s);
 // The transposed conv as four per-tap GEMMs sharing one A operand (convt_taps.hip): a.wpk4 holds the weights packed
