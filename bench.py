@@ -339,6 +339,8 @@ def main():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--batch", type=int, default=16, help="images per GPU per step")
+    ap.add_argument("--global-batch", type=int, default=0, help="strong scaling (BASELINE configs[3]: 512): this many images per "
+                    "step over ALL ranks, contiguous shards of miunet.shard.shard_range; overrides --batch")
     ap.add_argument("--size", type=int, default=512)
     ap.add_argument("--in-ch", type=int, default=1)
     ap.add_argument("--base", type=int, default=64)
@@ -384,6 +386,11 @@ def main():
     spec = UNetSpec(args.in_ch, args.base, args.levels, 3)
     H = W = args.size
     B = args.batch
+    if args.global_batch:
+        if args.global_batch % world:
+            raise SystemExit("--global-batch must be a multiple of the number of ranks (dist.gather wants equal shards)")
+        lo, hi = shard.shard_range(args.global_batch, rank, world)
+        B = hi - lo
     lp_mode = args.conv_algo if args.conv_algo in ("bf16", "fp16") else "fp32"
 
     # ---- weights: rank 0 generates, everybody else receives them over RCCL
@@ -473,12 +480,12 @@ def main():
         is_cfg5 = (spec.in_ch, spec.base, spec.levels, H) == (3, 32, 5, 1024)
         lp = lp_mode != "fp32"
         arith = (lp_mode + " operands / fp32 accumulate") if lp else "fp32"
-        cfg_idx = (2 if lp else 1) if is_cfg1 else 4
+        cfg_idx = (2 if lp else 3 if args.global_batch else 1) if is_cfg1 else 4
         out = {
             "metric": f"images/sec, {H}x{W} UNet {arith} inference (u8 tile -> u8 label map)",
             "value": ips, "unit": "images/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": dt / args.steps * 1e3, "ms_per_image": dt / images * 1e3 * world,
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": lp_mode, "data": "synthetic",
+            "higher_is_better": True, "scaling": "strong" if args.global_batch else "weak", "vs_baseline": None, "dtype": lp_mode, "data": "synthetic",
             "launch_mode": "hipGraph replay (the shipped path; profiling off)",
             "config": {"workload": (f"BASELINE.json configs[{cfg_idx}]: " if (is_cfg1 or is_cfg5) else "") +
                                    f"batch {B} x {H}x{W}x{spec.in_ch} u8 per GPU, {spec.levels}-level UNet base {spec.base}, "

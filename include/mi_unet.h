@@ -184,7 +184,8 @@ int mi_unet_group_load_weights(mi_unet_group_t *g, const char *path);
 int mi_unet_group_load_weights_from_memory(mi_unet_group_t *g, const void *blob, size_t len);
 int mi_unet_group_set_gather(mi_unet_group_t *g, int mode);               /* EARG when XGMI is asked for without RCCL */
 int mi_unet_group_set_postprocess(mi_unet_group_t *g, int on);
-/* "rccl" or "peer-copy": how the weights reached ranks > 0; and the gather mode in force */
+/* how the weights reached ranks > 0 -- "rccl", "peer-copy" or "host-upload", with the reason when a faster transport failed
+ * and the next one was taken -- and the gather mode in force */
 const char *mi_unet_group_weight_transport(const mi_unet_group_t *g);
 int mi_unet_group_gather(const mi_unet_group_t *g);
 /* Sharded forms of mi_unet_infer_u8 / mi_unet_infer_raw16 / mi_unet_segment_raw16: same arguments, same results, the batch

@@ -35,6 +35,20 @@ def test_shard_range_rejects_bad_arguments():
         binding.shard_range(-1, 0, 1)
 
 
+def test_group_scheduling_on_cpu_with_a_stub_backend(tmp_path):
+    """csrc/group_sched.h -- the shard split, the per-rank worker threads and the run-on-every-rank / first-failure logic of
+    the multi-device group -- compiled with g++ against a stub backend and run here: no GPU involved (1, 2, 3 and 8 ranks;
+    empty, ragged and full batches; concurrency; error propagation from a failing rank's own thread)."""
+    import subprocess
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = tmp_path / "group_sched_test"
+    subprocess.check_call(["g++", "-O1", "-std=c++17", "-pthread", "-o", str(exe), os.path.join(root, "tests", "cpu", "group_sched_test.cpp")])
+    r = subprocess.run([str(exe)], capture_output=True, timeout=120)
+    assert r.returncode == 0, r.stdout.decode() + r.stderr.decode()
+    assert b"all group scheduling checks passed" in r.stdout
+
+
 def test_group_without_device_fails_loudly():
     if binding.device_count() > 0:
         pytest.skip("a HIP device is visible")

@@ -525,7 +525,7 @@ int run_microbatch(mi_unet *h, const uint8_t *d_imgs, int B, uint8_t *d_labels, 
     for (auto &g : h->graphs)
         if (g.stream == s && g.imgs == d_imgs && g.labels == d_labels && g.logits == d_logits && g.B == B) ge = &g;
     if (!ge) {
-        if (h->graphs.size() >= 16) {                    // bounded cache: drop the oldest entry
+        if (h->graphs.size() >= 64) {                    // bounded cache (a batch of 512 is 32 micro-batch keys): drop the oldest entry
             if (h->graphs.front().exec) (void)hipGraphExecDestroy(h->graphs.front().exec);
             h->graphs.erase(h->graphs.begin());
         }

@@ -8,7 +8,6 @@
 #include <dlfcn.h>
 #include <hip/hip_runtime.h>
 
-#include <condition_variable>
 #include <cstdlib>
 #include <cstring>
 #include <fstream>
@@ -16,11 +15,11 @@
 #include <mutex>
 #include <set>
 #include <string>
-#include <thread>
 #include <vector>
 
 #include "../../include/mi_unet.h"
 #include "engine_internal.h"
+#include "group_sched.h"
 
 using namespace miunet;
 
@@ -65,56 +64,6 @@ struct Rccl {
     }
 };
 
-// ---- one persistent worker per rank: jobs of one call run concurrently, one per device
-class Worker {
-public:
-    Worker() : th_([this] { loop(); }) {}
-    ~Worker()
-    {
-        { std::lock_guard<std::mutex> lk(m_); stop_ = true; }
-        cv_.notify_all();
-        th_.join();
-    }
-    void submit(std::function<void()> job)
-    {
-        { std::lock_guard<std::mutex> lk(m_); job_ = std::move(job); busy_ = true; }
-        cv_.notify_all();
-    }
-    void wait()
-    {
-        std::unique_lock<std::mutex> lk(m_);
-        cv_.wait(lk, [this] { return !busy_; });
-    }
-
-private:
-    void loop()
-    {
-        std::unique_lock<std::mutex> lk(m_);
-        for (;;) {
-            cv_.wait(lk, [this] { return stop_ || busy_; });
-            if (stop_) return;
-            std::function<void()> job = std::move(job_);
-            lk.unlock();
-            job();
-            lk.lock();
-            busy_ = false;
-            cv_.notify_all();
-        }
-    }
-    std::mutex m_;
-    std::condition_variable cv_;
-    std::function<void()> job_;
-    bool busy_ = false, stop_ = false;
-    std::thread th_;
-};
-
-void shard(int n, int r, int world, int &lo, int &hi)
-{
-    const int q = n / world, rem = n % world;
-    lo = r * q + (r < rem ? r : rem);
-    hi = lo + q + (r < rem ? 1 : 0);
-}
-
 }  // namespace
 
 struct mi_unet_group {
@@ -140,17 +89,10 @@ namespace {
 // run fn(rank) on every rank's worker; first failure (by rank) becomes the caller's last error
 int for_all_ranks(mi_unet_group *g, const std::function<int(int)> &fn)
 {
-    const int R = (int)g->eng.size();
-    std::vector<int> rc(R, 0);
-    std::vector<std::string> msg(R);
-    for (int r = 0; r < R; ++r)
-        g->workers[r]->submit([&, r] {
-            rc[r] = fn(r);
-            if (rc[r]) msg[r] = mi_unet_last_error();      // thread-local in the worker: carry it over
-        });
-    for (int r = 0; r < R; ++r) g->workers[r]->wait();
-    for (int r = 0; r < R; ++r)
-        if (rc[r]) return engine_fail(rc[r], "rank " + std::to_string(r) + " (device " + std::to_string(g->devices[r]) + "): " + msg[r]);
+    std::string msg;
+    int bad_rank = -1;
+    const int rc = run_on_all_ranks(g->workers, fn, [] { return std::string(mi_unet_last_error()); }, bad_rank, msg);
+    if (rc) return engine_fail(rc, "rank " + std::to_string(bad_rank) + " (device " + std::to_string(g->devices[bad_rank]) + "): " + msg);
     return MI_UNET_OK;
 }
 
@@ -183,7 +125,7 @@ extern "C" {
 int mi_unet_shard_range(int n_items, int rank, int world, int *lo, int *hi)
 {
     if (!lo || !hi || n_items < 0 || world < 1 || rank < 0 || rank >= world) return engine_fail(MI_UNET_EARG, "mi_unet_shard_range: bad argument");
-    shard(n_items, rank, world, *lo, *hi);
+    shard_range(n_items, rank, world, *lo, *hi);
     return MI_UNET_OK;
 }
 
@@ -285,23 +227,37 @@ int mi_unet_group_load_weights_from_memory(mi_unet_group_t *g, const void *blob,
         if (int rc = engine_adopt_weights(g->eng[r], hw, /*upload=*/r == 0)) return rc;
     if (R == 1 && g->comms.empty()) return MI_UNET_OK;
     const size_t bytes = sizeof(float) * hw.blob.size();
+    // Transport ladder for ranks > 0: RCCL broadcast over xGMI -> device-to-device peer copies -> one upload per device from
+    // the host blob.  A rung that fails is reported in the transport string and the next one is taken: the weights always
+    // arrive, and a node whose RCCL or peer access is misconfigured still runs.
+    bool done = false;
     if (!g->comms.empty()) {
         // one contiguous broadcast, root = rank 0, every rank on its own engine stream (single-thread group call)
         int rc = g->rccl.GroupStart();
         for (int r = 0; r < R && rc == 0; ++r) {
-            HIP_TRY_G(hipSetDevice(g->devices[r]));
+            if (hipSetDevice(g->devices[r]) != hipSuccess) { rc = -1; break; }
             rc = g->rccl.Broadcast(engine_weight_ptr(g->eng[r]), engine_weight_ptr(g->eng[r]), bytes, Rccl::kUint8, 0, g->comms[r],
                                    engine_stream(g->eng[r]));
         }
         const int rc2 = g->rccl.GroupEnd();
-        if (rc || rc2) return nccl_fail(g, rc ? rc : rc2, "ncclBroadcast(weights)");
-        for (int r = 0; r < R; ++r)
-            if (int e = mi_unet_sync(g->eng[r])) return e;
-        return MI_UNET_OK;
+        bool ok = rc == 0 && rc2 == 0;
+        for (int r = 0; r < R && ok; ++r) ok = mi_unet_sync(g->eng[r]) == MI_UNET_OK;
+        if (ok) { g->transport = "rccl"; done = true; }
+        else g->transport = "peer-copy (ncclBroadcast failed)";
     }
-    for (int r = 1; r < R; ++r) {          // no communicator: device-to-device copies from rank 0's blob
-        HIP_TRY_G(hipSetDevice(g->devices[r]));
-        HIP_TRY_G(hipMemcpyPeer(engine_weight_ptr(g->eng[r]), g->devices[r], engine_weight_ptr(g->eng[0]), g->devices[0], bytes));
+    if (!done) {
+        bool ok = true;
+        for (int r = 1; r < R && ok; ++r)
+            ok = hipSetDevice(g->devices[r]) == hipSuccess &&
+                 hipMemcpyPeer(engine_weight_ptr(g->eng[r]), g->devices[r], engine_weight_ptr(g->eng[0]), g->devices[0], bytes) == hipSuccess;
+        if (ok) done = true;
+        else { (void)hipGetLastError(); g->transport = "host-upload (peer copy failed)"; }
+    }
+    if (!done) {
+        for (int r = 1; r < R; ++r) {
+            HIP_TRY_G(hipSetDevice(g->devices[r]));
+            HIP_TRY_G(hipMemcpy(engine_weight_ptr(g->eng[r]), hw.blob.data(), bytes, hipMemcpyHostToDevice));
+        }
     }
     return MI_UNET_OK;
 }
@@ -328,7 +284,7 @@ int mi_unet_group_infer_u8(mi_unet_group_t *g, const uint8_t *imgs, int B, uint8
         // every rank: pinned staging -> H2D -> forward -> D2H straight into its range of the caller's buffers
         return for_all_ranks(g, [&](int r) {
             int lo, hi;
-            shard(B, r, R, lo, hi);
+            shard_range(B, r, R, lo, hi);
             if (hi == lo) return 0;
             return mi_unet_infer_u8(g->eng[r], imgs + lo * in_px, hi - lo, labels + lo * hw, logits ? logits + lo * lg_px : nullptr);
         });
@@ -344,7 +300,7 @@ int mi_unet_group_infer_u8(mi_unet_group_t *g, const uint8_t *imgs, int B, uint8
     }
     int rc = for_all_ranks(g, [&](int r) {
         int lo, hi;
-        shard(B, r, R, lo, hi);
+        shard_range(B, r, R, lo, hi);
         const size_t n = (size_t)(hi - lo);
         if (int e = grow(g->d_in[r], g->cap_in[r], n * in_px + 1, g->devices[r])) return e;
         if (r != 0) { if (int e = grow(g->d_out[r], g->cap_out[r], n * hw + 1, g->devices[r])) return e; }
@@ -358,7 +314,7 @@ int mi_unet_group_infer_u8(mi_unet_group_t *g, const uint8_t *imgs, int B, uint8
     rc = g->rccl.GroupStart();
     for (int r = 1; r < R && rc == 0; ++r) {
         int lo, hi;
-        shard(B, r, R, lo, hi);
+        shard_range(B, r, R, lo, hi);
         if (hi == lo) continue;
         rc = g->rccl.Send(g->d_out[r], (size_t)(hi - lo) * hw, Rccl::kUint8, 0, g->comms[r], engine_stream(g->eng[r]));
         if (rc == 0) rc = g->rccl.Recv(g->d_out[0] + lo * hw, (size_t)(hi - lo) * hw, Rccl::kUint8, r, g->comms[0], engine_stream(g->eng[0]));
@@ -382,7 +338,7 @@ int mi_unet_group_infer_raw16(mi_unet_group_t *g, const uint16_t *const *raws, c
     const size_t hw = (size_t)g->cfg.height * g->cfg.width;
     return for_all_ranks(g, [&](int r) {
         int lo, hi;
-        shard(B, r, R, lo, hi);
+        shard_range(B, r, R, lo, hi);
         if (hi == lo) return 0;
         return mi_unet_infer_raw16(g->eng[r], raws + (size_t)lo * C, widths + (size_t)lo * C, heights + (size_t)lo * C, hi - lo,
                                    tiles ? tiles + lo * hw * C : nullptr, labels + lo * hw,
@@ -401,7 +357,7 @@ int mi_unet_group_segment_raw16(mi_unet_group_t *g, const uint16_t *const *raws,
     const size_t hw = (size_t)g->cfg.height * g->cfg.width;
     return for_all_ranks(g, [&](int r) {
         int lo, hi;
-        shard(B, r, R, lo, hi);
+        shard_range(B, r, R, lo, hi);
         if (hi == lo) return 0;
         return mi_unet_segment_raw16(g->eng[r], raws + (size_t)lo * C, widths + (size_t)lo * C, heights + (size_t)lo * C, hi - lo,
                                      tiles ? tiles + lo * hw * C : nullptr, masks + lo * hw, xy + (size_t)lo * cap_points * 2, cap_points,

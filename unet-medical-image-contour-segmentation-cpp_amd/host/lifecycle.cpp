@@ -126,8 +126,17 @@ bool initialize_engine(const std::string &trt_cache_path, const std::string &log
         g_cfg.conv_algo = env_algo();
         g_thread_batch = std::max(1, env_int("MEDSEG_THREAD_BATCH", 1));
         const int n_devices = env_int("MEDSEG_DEVICES", 0);
-        if (mi_unet_group_create(&g_cfg, nullptr, n_devices, &g_group) != MI_UNET_OK ||
-            mi_unet_group_load_weights(g_group, trt_cache_path.c_str()) != MI_UNET_OK) {
+        bool up = mi_unet_group_create(&g_cfg, nullptr, n_devices, &g_group) == MI_UNET_OK &&
+                  mi_unet_group_load_weights(g_group, trt_cache_path.c_str()) == MI_UNET_OK;
+        if (!up && n_devices != 1 && mi_unet_device_count() > 1) {
+            // a multi-device group that does not come up must not take single-device operation with it
+            g_log_file << "Warning: multi-device group failed (" << mi_unet_last_error() << "); continuing on device "
+                       << g_cfg.device << " alone" << std::endl;
+            if (g_group) { mi_unet_group_destroy(g_group); g_group = nullptr; }
+            up = mi_unet_group_create(&g_cfg, nullptr, 1, &g_group) == MI_UNET_OK &&
+                 mi_unet_group_load_weights(g_group, trt_cache_path.c_str()) == MI_UNET_OK;
+        }
+        if (!up) {
             g_log_file << "Error: Failed to initialize MI355X UNet engine: " << mi_unet_last_error() << std::endl;
             std::cerr << "Initialization error: " << mi_unet_last_error() << std::endl;
             if (g_group) { mi_unet_group_destroy(g_group); g_group = nullptr; }
