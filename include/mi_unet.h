@@ -178,6 +178,11 @@ typedef struct mi_unet_group mi_unet_group_t;
 #define MI_UNET_GATHER_HOST 0
 #define MI_UNET_GATHER_XGMI 1
 int mi_unet_group_create(const mi_unet_config *cfg, const int *devices, int n_devices, mi_unet_group_t **out);
+/* A second set of contexts over the same devices that shares every rank's weight blob (mi_unet_clone per rank) and owns its
+ * buffers, streams and worker threads: two groups can have two batches in flight at once -- the small serial stages of one
+ * (RAW upload, preprocessing, labelling, the contour walk) overlap the network of the other.  The clone has no RCCL
+ * communicator (host gather only). */
+int mi_unet_group_clone(mi_unet_group_t *src, mi_unet_group_t **out);
 int mi_unet_group_size(const mi_unet_group_t *g);
 mi_unet_t *mi_unet_group_handle(mi_unet_group_t *g, int rank);            /* rank's engine (owned by the group) */
 int mi_unet_group_load_weights(mi_unet_group_t *g, const char *path);

@@ -242,3 +242,36 @@ def test_config5_fp16_batch_2():
     srt = np.sort(ref32, axis=1)
     safe = (srt[:, -1] - srt[:, -2]) > 2e-2
     assert np.array_equal(labels[safe], lab32[safe])
+
+
+@pytest.mark.gpu
+def test_group_clone_is_a_second_lane_with_shared_weights():
+    """mi_unet_group_clone: a second set of contexts over the same devices (the facade's second device lane in directory
+    mode).  Both groups run different batches at the same time from two threads and agree with the single engine; the clone
+    outlives its source."""
+    spec = UNetSpec()
+    blob = pack_weights(spec, synth.make_threshold_weights(spec))
+    sets = [[synth.make_raw16(300 + 16 * i, 420, seed=700 + 10 * t + i) for i in range(3)] for t in range(2)]
+    with binding.Engine(512, 512, max_batch=2) as eng:
+        eng.load_weights(blob)
+        want = [eng.segment_raw16(s) for s in sets]
+    g = binding.Group(512, 512, max_batch=2, devices=[0, 0])
+    g.load_weights(blob)
+    g2 = g.clone()
+    got = [None, None]
+
+    def work(t, grp):
+        for _ in range(3):
+            got[t] = grp.segment_raw16(sets[t])
+
+    th = [threading.Thread(target=work, args=(0, g)), threading.Thread(target=work, args=(1, g2))]
+    for x in th:
+        x.start()
+    for x in th:
+        x.join()
+    g.close()                                                          # the clone keeps the weights alive
+    last = g2.segment_raw16(sets[0])
+    g2.close()
+    for t in range(2):
+        assert np.array_equal(got[t][0], want[t][0]) and np.array_equal(got[t][1], want[t][1]) and got[t][2] == want[t][2]
+    assert np.array_equal(last[1], want[0][1]) and last[2] == want[0][2]

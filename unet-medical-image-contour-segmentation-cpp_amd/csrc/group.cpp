@@ -186,6 +186,27 @@ int mi_unet_group_create(const mi_unet_config *cfg, const int *devices, int n_de
     return MI_UNET_OK;
 }
 
+int mi_unet_group_clone(mi_unet_group_t *src, mi_unet_group_t **out)
+{
+    if (!src || !out) return engine_fail(MI_UNET_EARG, "mi_unet_group_clone: null argument");
+    *out = nullptr;
+    auto *g = new mi_unet_group();
+    g->cfg = src->cfg;
+    g->devices = src->devices;
+    g->transport = src->transport;
+    const size_t R = src->eng.size();
+    for (size_t r = 0; r < R; ++r) {
+        mi_unet_t *h = nullptr;
+        if (int rc = mi_unet_clone(src->eng[r], 0, &h)) { mi_unet_group_destroy(g); return rc; }
+        g->eng.push_back(h);
+        g->workers.emplace_back(new Worker());
+    }
+    g->d_in.assign(R, nullptr); g->d_out.assign(R, nullptr); g->cap_in.assign(R, 0); g->cap_out.assign(R, 0);
+    if (src->postprocess) (void)mi_unet_group_set_postprocess(g, 1);
+    *out = g;
+    return MI_UNET_OK;
+}
+
 int mi_unet_group_size(const mi_unet_group_t *g) { return g ? (int)g->eng.size() : 0; }
 
 mi_unet_t *mi_unet_group_handle(mi_unet_group_t *g, int rank)

@@ -380,7 +380,9 @@ __global__ __launch_bounds__(64) void k_sort_roots(int *roots, const int *counts
 }
 
 // one lane per (image, contour): follow the border from its start pixel, emit CHAIN_APPROX_SIMPLE points.
-// pass 0 counts points (npts), pass 1 writes them at the offsets computed in between.
+// pass 0 counts points (npts) -- and already WRITES contour 0, whose offset is 0 whatever the counts are; pass 1 writes the
+// others at the offsets computed in between and returns at once for images with a single contour (the usual case behind
+// postprocess_mask, which keeps components of at least 6 % of the tile).
 // The walk is a chain of dependent pixel probes (2-8 per border step), so the probe latency IS the kernel time: a workgroup
 // = one image first packs the thresholded mask into an LDS bit plane (H*W/8 bytes: 32 KB at 512x512; images past the LDS
 // budget keep probing global memory), then the lanes that own a contour walk it at LDS latency.
@@ -394,8 +396,10 @@ __global__ __launch_bounds__(256) void k_trace(const uint8_t *__restrict__ fg, c
     const uint8_t *im = fg + (size_t)img * H * W;
     const int nc = counts[img];
     if (nc <= 0 || nc > cap) return;                             // workgroup-uniform
+    if (write && nc == 1) return;                                // contour 0 was written by the count pass
     if constexpr (IN_LDS) {
         const int nwords = (H * W + 31) >> 5;
+        if (threadIdx.x == 0) bits[nwords] = 0;                  // one word past the plane: the 64-bit windows below may touch it
         for (int w = threadIdx.x; w < nwords; w += 256) {
             unsigned m = 0;
             const int base = w << 5;
@@ -425,24 +429,56 @@ __global__ __launch_bounds__(256) void k_trace(const uint8_t *__restrict__ fg, c
     auto DX = [](int d) -> int { return (int)((0x21000122u >> (4 * d)) & 3u) - 1; };
     auto DY = [](int d) -> int { return (int)((0x22210001u >> (4 * d)) & 3u) - 1; };
     for (int c = threadIdx.x; c < nc; c += 256) {               // lanes own contours (a handful after postprocess_mask)
+    if (write && c == 0) continue;                               // written by the count pass
     const int start = roots[(size_t)img * cap + c];
     const int x0 = start % W, y0 = start / W;
     int *dst = nullptr;
     int room = 0;
-    if (write) {
-        const int o = offs[(size_t)img * (cap + 1) + c];
+    const bool store = write || c == 0;
+    if (store) {
+        const int o = write ? offs[(size_t)img * (cap + 1) + c] : 0;
         room = cap_points - o;
         dst = out_xy + ((size_t)img * cap_points + o) * 2;
     }
     int n = 0;
     auto emit = [&](int x, int y) {
-        if (write && n < room) { dst[2 * n] = x; dst[2 * n + 1] = y; }
+        if (store && n < room) { dst[2 * n] = x; dst[2 * n + 1] = y; }
         ++n;
     };
-    int dir = 4, first = -1;                                    // first neighbour: clockwise, starting after west
-    for (int k = 0; k < 8; ++k) {
-        dir = (dir + 7) & 7;
-        if (at(x0 + DX(dir), y0 + DY(dir))) { first = dir; break; }
+    // The walk is a chain of dependent steps; inside a step the eight neighbour probes are INDEPENDENT reads (issued together,
+    // one LDS latency), and the search order -- counter-clockwise from the arrival direction -- is a rotate + find-first-set
+    // on the resulting 8-bit mask instead of up to eight chained probes.
+    // three pixels (x-1, x, x+1) of row y as bits 0..2: the rows of the plane are packed back to back, so they are three
+    // CONSECUTIVE bits of one 64-bit window (two LDS words), whatever W is; columns outside the image are masked off
+    auto row3 = [&](int x, int y) -> unsigned {
+        if (y < 0 || y >= H) return 0u;
+        const int p = y * W + x;
+        const int q = p > 0 ? p - 1 : 0;                        // first bit of the window (p = 0 only at the image origin)
+        const unsigned lo = bits[q >> 5], hi = bits[(q >> 5) + 1];
+        unsigned v = (unsigned)((((unsigned long long)hi << 32) | lo) >> (q & 31));
+        if (p == 0) v <<= 1;
+        return v & (x > 0 ? 7u : 6u) & (x + 1 < W ? 7u : 3u);
+    };
+    auto nb8 = [&](int x, int y) -> unsigned {                  // bit d = neighbour in direction d is foreground
+        if constexpr (IN_LDS) {
+            const unsigned r0 = row3(x, y - 1), r1 = row3(x, y), r2 = row3(x, y + 1);
+            return ((r1 >> 2) & 1u) | (((r0 >> 2) & 1u) << 1) | (((r0 >> 1) & 1u) << 2) | ((r0 & 1u) << 3) | ((r1 & 1u) << 4) |
+                   ((r2 & 1u) << 5) | (((r2 >> 1) & 1u) << 6) | (((r2 >> 2) & 1u) << 7);
+        } else {
+            unsigned m = 0;
+#pragma unroll
+            for (int d = 0; d < 8; ++d) m |= (at(x + DX(d), y + DY(d)) ? 1u : 0u) << d;
+            return m;
+        }
+    };
+    int first = -1;                                             // first neighbour: clockwise, starting after west
+    {
+        const unsigned m = nb8(x0, y0);
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            const int d = (3 - k) & 7;                          // 3, 2, 1, 0, 7, 6, 5, 4
+            if (first < 0 && ((m >> d) & 1u)) first = d;
+        }
     }
     if (first < 0) {
         emit(x0, y0);                                           // isolated pixel
@@ -450,9 +486,12 @@ __global__ __launch_bounds__(256) void k_trace(const uint8_t *__restrict__ fg, c
         const int x1 = x0 + DX(first), y1 = y0 + DY(first);
         int cx = x0, cy = y0, came = first, last_step = first ^ 4;
         for (long long guard = 0; guard < 4LL * H * W + 16; ++guard) {      // a border has at most 4 visits per pixel
-            int s = came, nx, ny;
-            do { ++s; nx = cx + DX(s & 7); ny = cy + DY(s & 7); } while (!at(nx, ny));
-            const int step = s & 7;
+            const unsigned m = nb8(cx, cy);
+            if (m == 0) break;                                  // cannot happen on a border pixel; keeps the loop finite on bad input
+            const int base = (came + 1) & 7;                    // search came+1, came+2, ... (counter-clockwise)
+            const unsigned rot = ((m | (m << 8)) >> base) & 0xFFu;
+            const int step = (base + __builtin_ctz(rot)) & 7;
+            const int nx = cx + DX(step), ny = cy + DY(step);
             if (step != last_step) { emit(cx, cy); last_step = step; }
             const bool closing = (nx == x0 && ny == y0 && cx == x1 && cy == y1);
             cx = nx; cy = ny;
@@ -525,8 +564,8 @@ hipError_t launch_extract_contours(const uint8_t *masks, int B, int H, int W, in
     hipLaunchKernelGGL(ct::k_collect, g, b, 0, s, fparent, bparent, minx, miny, maxx, maxy, roots, counts, cap_contours, H, W, n);
     hipLaunchKernelGGL(ct::k_sort_roots, dim3((B + 63) / 64), dim3(64), 0, s, roots, counts, cap_contours, B);
     // one workgroup per image; the mask as an LDS bit plane when it fits
-    const size_t plane = (((size_t)H * W + 31) / 32) * 4;
-    const bool in_lds = plane <= 128 * 1024;
+    const size_t plane = (((size_t)H * W + 31) / 32) * 4 + 4;    // + one word of slack behind the plane (k_trace's windows)
+    const bool in_lds = plane <= 160 * 1024;                     // the whole LDS of a CU: 1024x1024 is 128 KB + 4
     const dim3 gt((unsigned)B), bt(256);
     for (int pass = 0; pass < 2; ++pass) {
         if (in_lds) {

@@ -36,6 +36,7 @@ namespace MedicalSeg {
 namespace {
 std::mutex g_state_mutex;          // guards the four below
 mi_unet_group_t *g_group = nullptr;
+mi_unet_group_t *g_lane2 = nullptr;  // a clone of g_group, created by the first directory-mode call with more than one chunk
 mi_unet_config g_cfg{};            // per-rank configuration of the group (tile size, topology, max_batch, algorithm)
 int g_thread_batch = 1;            // micro-batch capacity of a per-thread context
 unsigned long g_generation = 0;    // bumped by every (re)initialisation and cleanup: older thread contexts are stale
@@ -111,6 +112,7 @@ bool initialize_engine(const std::string &trt_cache_path, const std::string &log
             g_log_file << "Error: engine weight file not found - " << trt_cache_path << std::endl;
             return false;
         }
+        if (g_lane2) { mi_unet_group_destroy(g_lane2); g_lane2 = nullptr; }
         if (g_group) { mi_unet_group_destroy(g_group); g_group = nullptr; }
         ++g_generation;
         mi_unet_default_config(&g_cfg);            // 512x512x1, 3 classes (src/process.cpp:70, :162)
@@ -350,7 +352,7 @@ ChunkIn read_chunk(const std::vector<std::string> &paths, const std::vector<int>
     return in;
 }
 
-ChunkOut device_chunk(const ChunkIn &in, const std::vector<int> &widths, const std::vector<int> &heights)
+ChunkOut device_chunk(const ChunkIn &in, const std::vector<int> &widths, const std::vector<int> &heights, mi_unet_group_t *group)
 {
     ChunkOut out;
     std::vector<const uint16_t *> ptrs;
@@ -369,15 +371,11 @@ ChunkOut device_chunk(const ChunkIn &in, const std::vector<int> &widths, const s
     out.tiles.resize(hw * m); out.labels.resize(hw * m);
     out.xy.resize(m * kCapPoints * 2); out.start.resize(m * (kCapContours + 1)); out.cnt.resize(m);
     const auto t0 = std::chrono::high_resolution_clock::now();
-    mi_unet_group_t *group = get_engine_group();
     if (!group) throw std::runtime_error("Engine not initialized");
-    {
-        std::lock_guard<std::mutex> lk(g_batch_mutex);
-        if (mi_unet_group_segment_raw16(group, ptrs.data(), ws.data(), hs.data(), (int)m, C > 1 ? tiles_c.data() : out.tiles.data(),
-                                        out.labels.data(), out.xy.data(), kCapPoints, out.start.data(), kCapContours,
-                                        out.cnt.data()) != MI_UNET_OK)
-            throw std::runtime_error(std::string("Inference failed: ") + mi_unet_last_error());
-    }
+    if (mi_unet_group_segment_raw16(group, ptrs.data(), ws.data(), hs.data(), (int)m, C > 1 ? tiles_c.data() : out.tiles.data(),
+                                    out.labels.data(), out.xy.data(), kCapPoints, out.start.data(), kCapContours,
+                                    out.cnt.data()) != MI_UNET_OK)
+        throw std::runtime_error(std::string("Inference failed: ") + mi_unet_last_error());
     if (C > 1)                                 // the artefact is the grey tile: channel 0 of the replicated planes
         for (size_t p = 0; p < hw * m; ++p) out.tiles[p] = tiles_c[p * C];
     out.device_ms = std::chrono::duration_cast<std::chrono::milliseconds>(std::chrono::high_resolution_clock::now() - t0).count();
@@ -433,13 +431,34 @@ ChunkText artefact_chunk(const ChunkIn &in, const ChunkOut &out, const std::vect
     return tx;
 }
 
-// the all-device route of process_image_batch; returns the number of images that succeeded
+// the all-device route of process_image_batch; returns the number of images that succeeded.
+// Stages: read the files of chunk k+1 || device work of chunk k || PNG / JSON artefacts of chunk k-1.
+// MEDSEG_DEVICE_LANES=2 adds a second device lane (a clone of the engine group: shared weights, own buffers / streams /
+// worker threads) so that two chunks are on the device at once.  Measured on one MI355X it buys nothing -- 1.77 vs 1.78 ms
+// per image over 64 files: the network's workgroups take whole CUs (144 KB of LDS, 512 registers per lane), so the ~30 small
+// dependent kernels of the other chunk's labelling and contour stages each wait for a network kernel to drain instead of
+// running beside it -- hence one lane by default.
 int process_batch_pipelined(const std::vector<std::string> &paths, const std::vector<int> &widths, const std::vector<int> &heights,
                             const std::string &output_dir)
 {
     auto &log_file = get_log_file();
+    mi_unet_group_t *lanes[2] = { nullptr, nullptr };
+    int n_lanes = 1;
+    {
+        std::lock_guard<std::mutex> lk(g_state_mutex);
+        if (!g_group) throw std::runtime_error("Engine not initialized");
+        lanes[0] = g_group;
+        const size_t chunk = (size_t)std::max(1, g_cfg.max_batch) * (size_t)std::max(1, mi_unet_group_size(g_group));
+        if (paths.size() > chunk && env_int("MEDSEG_DEVICE_LANES", 1) >= 2) {
+            if (!g_lane2 && mi_unet_group_clone(g_group, &g_lane2) != MI_UNET_OK) {
+                if (log_file.is_open()) log_file << "Warning: second device lane unavailable (" << mi_unet_last_error() << ")" << std::endl;
+                g_lane2 = nullptr;
+            }
+            if (g_lane2) { lanes[1] = g_lane2; n_lanes = 2; }
+        }
+    }
     // a chunk = one micro-batch on every device of the group
-    const size_t n = paths.size(), step = (size_t)std::max(1, g_cfg.max_batch) * (size_t)std::max(1, mi_unet_group_size(get_engine_group()));
+    const size_t n = paths.size(), step = (size_t)std::max(1, g_cfg.max_batch) * (size_t)std::max(1, mi_unet_group_size(lanes[0]));
     int ok = 0;
     auto emit = [&](const ChunkIn &in, const ChunkOut &out, const ChunkText &tx) {
         for (size_t k = 0; k < tx.con.size(); ++k) {
@@ -452,40 +471,57 @@ int process_batch_pipelined(const std::vector<std::string> &paths, const std::ve
                      << " ms for " << out.idx.size() << " images; Batch artefact time: " << tx.art_ms << " ms" << std::endl;
         ok += tx.ok;
     };
-    struct Stage { ChunkIn in; ChunkOut out; };
+    struct Stage { ChunkIn in; ChunkOut out; std::string dev_err; };
+    struct InFlight { std::shared_ptr<Stage> st; std::future<void> done; };
+    std::vector<InFlight> dev_q;                       // device work in flight, oldest first, at most n_lanes entries
     std::future<ChunkIn> next_read = std::async(std::launch::async, read_chunk, std::cref(paths), std::cref(widths), std::cref(heights),
                                                 (size_t)0, std::min(step, n));
     std::future<ChunkText> pending_art;
     std::shared_ptr<Stage> art_stage;                  // keeps the chunk alive while its artefacts are being written
-    for (size_t first = 0; first < n; first += step) {
-        auto st = std::make_shared<Stage>();
-        st->in = next_read.get();
-        if (first + step < n)
-            next_read = std::async(std::launch::async, read_chunk, std::cref(paths), std::cref(widths), std::cref(heights),
-                                   first + step, std::min(step, n - first - step));
-        for (size_t k = 0; k < st->in.count; ++k)
-            if (!st->in.read_err[k].empty()) {
-                std::cerr << st->in.read_err[k] << std::endl;
-                if (log_file.is_open()) log_file << st->in.read_err[k] << std::endl;
-            }
-        try {
-            st->out = device_chunk(st->in, widths, heights);
-        } catch (const std::exception &e) {
+    auto retire_oldest = [&]() {                       // device work of the oldest chunk is over: hand it to the artefact stage
+        InFlight f = std::move(dev_q.front());
+        dev_q.erase(dev_q.begin());
+        f.done.get();
+        std::shared_ptr<Stage> st = f.st;
+        if (!st->dev_err.empty()) {
             // this chunk's images fail (message as process_single_image's); chunks already done keep their successes and
             // the chunks behind it still run
-            const std::string msg = std::string("Processing error: ") + e.what() + " (files " + std::to_string(first) + ".." +
-                                    std::to_string(first + st->in.count - 1) + " of the batch)";
+            const std::string msg = "Processing error: " + st->dev_err + " (files " + std::to_string(st->in.first) + ".." +
+                                    std::to_string(st->in.first + st->in.count - 1) + " of the batch)";
             std::cerr << msg << std::endl;
             if (log_file.is_open()) log_file << msg << std::endl;
-            continue;
+            return;
         }
-        for (auto &r : st->in.raws) std::vector<uint16_t>().swap(r);      // the RAW images are on the device's side now
         if (pending_art.valid()) emit(art_stage->in, art_stage->out, pending_art.get());
         art_stage = st;
         pending_art = std::async(std::launch::async, [st, &paths, &widths, &heights, &output_dir] {
             return artefact_chunk(st->in, st->out, paths, widths, heights, output_dir);
         });
+    };
+    size_t k = 0;
+    for (size_t first = 0; first < n; first += step, ++k) {
+        auto st = std::make_shared<Stage>();
+        st->in = next_read.get();
+        if (first + step < n)
+            next_read = std::async(std::launch::async, read_chunk, std::cref(paths), std::cref(widths), std::cref(heights),
+                                   first + step, std::min(step, n - first - step));
+        for (size_t q = 0; q < st->in.count; ++q)
+            if (!st->in.read_err[q].empty()) {
+                std::cerr << st->in.read_err[q] << std::endl;
+                if (log_file.is_open()) log_file << st->in.read_err[q] << std::endl;
+            }
+        if ((int)dev_q.size() == n_lanes) retire_oldest();          // frees the lane this chunk will use (FIFO: chunk k - n_lanes)
+        mi_unet_group_t *lane = lanes[k % n_lanes];
+        dev_q.push_back({ st, std::async(std::launch::async, [st, lane, &widths, &heights] {
+            try {
+                st->out = device_chunk(st->in, widths, heights, lane);
+                for (auto &r : st->in.raws) std::vector<uint16_t>().swap(r);      // the RAW images are on the device's side now
+            } catch (const std::exception &e) {
+                st->dev_err = e.what();
+            }
+        }) });
     }
+    while (!dev_q.empty()) retire_oldest();
     if (pending_art.valid()) emit(art_stage->in, art_stage->out, pending_art.get());
     return ok;
 }
@@ -506,8 +542,10 @@ int process_image_batch(const std::vector<std::string> &raw_paths, const std::ve
         if (!group) throw std::runtime_error("Engine not initialized");
         const size_t n = raw_paths.size();
         if (widths.size() != n || heights.size() != n) throw std::runtime_error("widths/heights do not match raw_paths");
-        if (n > 0 && device_postprocess_requested() && device_contours_requested())
+        if (n > 0 && device_postprocess_requested() && device_contours_requested()) {
+            std::lock_guard<std::mutex> lk(g_batch_mutex);     // one directory-mode call at a time: it owns both device lanes
             return process_batch_pipelined(raw_paths, widths, heights, output_dir);
+        }
         std::vector<std::vector<uint16_t>> raws(n);
         std::vector<const uint16_t *> ptrs;
         std::vector<int> ws, hs;
@@ -678,6 +716,7 @@ void cleanup_resources()
             if (log_file.is_open()) log_file << "Execution context destroyed" << std::endl;
         }
         ++g_generation;
+        if (g_lane2) { mi_unet_group_destroy(g_lane2); g_lane2 = nullptr; }
         if (g_group) {
             mi_unet_group_destroy(g_group);         // every device's buffers, streams, worker thread, weights
             g_group = nullptr;

@@ -18,7 +18,7 @@ EXPORTS = [
     "mi_unet_infer_u8", "mi_unet_infer_u8_device", "mi_unet_infer_raw16", "mi_unet_set_postprocess", "mi_unet_postprocess_masks", "mi_unet_extract_contours", "mi_unet_segment_raw16", "mi_unet_set_stream", "mi_unet_sync", "mi_unet_timer_begin",
     "mi_unet_timer_end", "mi_unet_set_profiling", "mi_unet_get_kernel_stats", "mi_unet_layer_debug", "mi_unet_destroy",
     "mi_unet_last_error", "mi_unet_device_count", "mi_unet_clone",
-    "mi_unet_group_create", "mi_unet_group_size", "mi_unet_group_handle", "mi_unet_group_load_weights",
+    "mi_unet_group_create", "mi_unet_group_clone", "mi_unet_group_size", "mi_unet_group_handle", "mi_unet_group_load_weights",
     "mi_unet_group_load_weights_from_memory", "mi_unet_group_set_gather", "mi_unet_group_set_postprocess",
     "mi_unet_group_weight_transport", "mi_unet_group_gather", "mi_unet_group_infer_u8", "mi_unet_group_infer_raw16",
     "mi_unet_group_segment_raw16", "mi_unet_group_destroy", "mi_unet_shard_range",
@@ -78,6 +78,7 @@ def lib():
         L.mi_unet_default_config.restype = None
         L.mi_unet_clone.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_void_p)]
         L.mi_unet_group_create.argtypes = [C.POINTER(Config), C.POINTER(C.c_int), C.c_int, C.POINTER(C.c_void_p)]
+        L.mi_unet_group_clone.argtypes = [C.c_void_p, C.POINTER(C.c_void_p)]
         L.mi_unet_group_size.argtypes = [C.c_void_p]
         L.mi_unet_group_handle.argtypes = [C.c_void_p, C.c_int]
         L.mi_unet_group_handle.restype = C.c_void_p
@@ -297,6 +298,13 @@ class Group:
             _check(lib().mi_unet_group_create(C.byref(self.cfg), arr, len(devices), C.byref(self._g)))
         else:
             _check(lib().mi_unet_group_create(C.byref(self.cfg), None, n_devices, C.byref(self._g)))
+
+    def clone(self) -> "Group":
+        other = object.__new__(Group)
+        other.cfg = self.cfg
+        other._g = C.c_void_p()
+        _check(lib().mi_unet_group_clone(self._g, C.byref(other._g)))
+        return other
 
     def close(self):
         if self._g:
