@@ -510,7 +510,9 @@ bool conv3x3_wino4_runs_staged(const ConvArgs &a)
     const int staged = w4s ? atoi(w4s) : 1;
     const int rem = a.Cout % 128;
     const long long wg1 = (long long)((a.W + 15) / 16) * ((a.H + 15) / 16) * a.B * ((a.Cout + 63) / 64);
-    const bool one_block = a.head_w != nullptr || !(a.Cout >= 128 && (rem == 0 || rem > 64));
+    // ... and wider layers whose K loop is at most four chunks (down1.c1, 64 -> 128: 0.521 -> 0.488 ms); with eight chunks and
+    // more the two-block kernel's shared forward transform wins (measured on every such layer: 7-20 % slower staged)
+    const bool one_block = a.head_w != nullptr || !(a.Cout >= 128 && (rem == 0 || rem > 64)) || a.Cin <= 64;
     // a.ksplit_ws == nullptr is the batch-invariant mode (MIUNET_SPLITK=0): there the choice must not depend on the batch
     return one_block && (staged == 2 || (staged == 1 && (wg1 >= 2 * persistent_cus() || a.ksplit_ws == nullptr)));
 }
