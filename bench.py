@@ -341,6 +341,8 @@ def main():
     ap.add_argument("--batch", type=int, default=16, help="images per GPU per step")
     ap.add_argument("--global-batch", type=int, default=0, help="strong scaling (BASELINE configs[3]: 512): this many images per "
                     "step over ALL ranks, contiguous shards of miunet.shard.shard_range; overrides --batch")
+    ap.add_argument("--micro-batch", type=int, default=16, help="engine max_batch: images per launch (a batch larger than this runs in "
+                    "micro-batches)")
     ap.add_argument("--size", type=int, default=512)
     ap.add_argument("--in-ch", type=int, default=1)
     ap.add_argument("--base", type=int, default=64)
@@ -398,7 +400,7 @@ def main():
     if use_dist:
         blob = shard.broadcast_blob(blob, spec.n_params() * 4 + 36, dev)
 
-    eng = binding.Engine(H, W, spec.in_ch, spec.base, spec.levels, spec.classes, max_batch=min(B, 16), device=local_rank,
+    eng = binding.Engine(H, W, spec.in_ch, spec.base, spec.levels, spec.classes, max_batch=min(B, args.micro_batch), device=local_rank,
                          conv_algo=args.conv_algo)
     eng.load_weights(blob)
 

@@ -4,11 +4,14 @@
 namespace miunet {
 
 // --------------------------------------------------------------------------------------------------------------------
-// First layer (K = 9*Cin with Cin <= 4: HBM-bound on its output, 1 GiB at batch 16).  A workgroup owns 64 consecutive
-// pixels of one image row; thread = (pixel slot, 4 output channels) and walks FOUR consecutive pixels, so the 3 x 6 input
-// bytes it needs are loaded and looked up once for all four (4.5 loads per pixel instead of 9) and there is no per-pixel
-// index arithmetic; the Cout/4 threads of a pixel write one contiguous NHWC row (256 bytes at Cout = 64).  u8 -> fp32
-// through the host-built 256-entry table so the input equals float(x)/255.0f bit for bit (src/process.cpp:36-39).
+// First layer (K = 9*Cin with Cin <= 4: HBM-bound on its output, 1 GiB at batch 16).  A workgroup owns PPB consecutive
+// pixels of one image row (64 at Cout = 64, 128 at Cout = 32); thread = (pixel slot, 4 output channels) and walks FOUR
+// consecutive pixels.  The three input rows of the workgroup -- (PPB + 2) x Cin bytes each -- are loaded ONCE, converted
+// u8 -> fp32 through the host-built 256-entry table (so the input equals float(x)/255.0f bit for bit, src/process.cpp:36-39)
+// and kept in LDS; every thread then reads its 3 x 6 x Cin floats from there with 16-byte reads.  (Round 1 had every thread
+// load and look up its own bytes: the Cout/4 threads of a pixel slot repeated the same 18 x Cin byte loads, which at
+// Cin = 3, Cout = 32 -- BASELINE config 5 -- made the layer 1.05 ms at 0.5 TB/s, the slowest kernel of that network.)
+// The Cout/4 threads of a pixel write one contiguous NHWC row (256 bytes at Cout = 64).
 // OT = float, or __bf16 / _Float16 for the 16-bit pipelines (the tensor is then rounded here, once, instead of by its consumer)
 template <int CIN, typename OT>
 __global__ __launch_bounds__(256) void conv3x3_first_kernel(const uint8_t *__restrict__ img, const float *__restrict__ lut,
@@ -17,48 +20,77 @@ __global__ __launch_bounds__(256) void conv3x3_first_kernel(const uint8_t *__res
                                                             int quads, int xblocks)
 {
     __shared__ float s_lut[256];
+    extern __shared__ __attribute__((aligned(16))) float s_in[];      // planar: [CIN][3 rows][rowlen], rowlen = ppb + 2 (+ pad)
     s_lut[threadIdx.x] = lut[threadIdx.x];
-    __syncthreads();
     const int q = threadIdx.x % quads;            // which 4 couts
     const int pl = threadIdx.x / quads;           // pixel slot in block
     const int ppb = 4 * (256 / quads);            // pixels per block (4 per slot)
     const int xb = blockIdx.x % xblocks;
     const int row = blockIdx.x / xblocks;         // b * H + y
     const int y = row % H;
-    const int x0 = xb * ppb + 4 * pl;
-    if (x0 >= W) return;
-    f32x4 wr[9 * CIN];
-#pragma unroll
-    for (int t = 0; t < 9 * CIN; ++t) wr[t] = *reinterpret_cast<const f32x4 *>(w + (size_t)t * Cout + 4 * q);
+    const int xb0 = xb * ppb;                     // first pixel of the block
+    const int rowlen = (ppb + 2 + 3) & ~3;        // floats per staged row, a 16-byte multiple
     const f32x4 sh = *reinterpret_cast<const f32x4 *>(shift + 4 * q);
-    const uint8_t *rowp = img + (size_t)row * W * CIN;
-    float v[3][6][CIN];                           // rows y-1..y+1, columns x0-1..x0+4
+    f32x4 w0[9];                                  // Cin = 1: the nine weight quads are issued here and land under the staging
+    if constexpr (CIN == 1) {
 #pragma unroll
-    for (int r = 0; r < 3; ++r) {
+        for (int t = 0; t < 9; ++t) w0[t] = *reinterpret_cast<const f32x4 *>(w + (size_t)t * Cout + 4 * q);
+    }
+    __syncthreads();                              // the table is complete
+    const uint8_t *rowp = img + (size_t)row * W * CIN;
+    const int rowbytes = (ppb + 2) * CIN;
+#pragma unroll
+    for (int r = 0; r < 3; ++r) {                 // no runtime divisions: CIN is a compile-time constant
         const int yy = y + r - 1;
         const bool yok = yy >= 0 && yy < H;
-#pragma unroll
-        for (int c6 = 0; c6 < 6; ++c6) {
-            const int xx = x0 + c6 - 1;
+        for (int k = threadIdx.x; k < rowbytes; k += 256) {
+            const int slot = k / CIN, c = k - slot * CIN, xx = xb0 - 1 + slot;
             const bool ok = yok && xx >= 0 && xx < W;
-#pragma unroll
-            for (int c = 0; c < CIN; ++c)
-                v[r][c6][c] = ok ? s_lut[rowp[((long long)(r - 1) * W + xx) * CIN + c]] : 0.f;
+            s_in[(c * 3 + r) * rowlen + slot] = ok ? s_lut[rowp[((long long)(r - 1) * W + xb0 - 1) * CIN + k]] : 0.f;
         }
+    }
+    __syncthreads();
+    const int x0 = xb0 + 4 * pl;
+    if (x0 >= W) return;
+    // One input channel at a time: its nine weight quads (36 registers) and its 3 x 6 pixel window; the four pixels'
+    // accumulators stay live across the channels.  (Holding all 9 x Cin weight quads at once -- 108 registers at Cin = 3 --
+    // left two waves per SIMD; this order leaves five.)  Sum order: channel-major, taps in raster order inside a channel.
+    f32x4 acc[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) acc[i] = f32x4{ 0.f, 0.f, 0.f, 0.f };
+    auto channel = [&](int c) {
+        f32x4 wc[9];
+#pragma unroll
+        for (int t = 0; t < 9; ++t) {
+            if constexpr (CIN == 1) wc[t] = w0[t];
+            else wc[t] = *reinterpret_cast<const f32x4 *>(w + (size_t)(t * CIN + c) * Cout + 4 * q);
+        }
+        float v[3][6];                            // rows y-1..y+1, columns x0-1..x0+4 of channel c
+#pragma unroll
+        for (int r = 0; r < 3; ++r) {
+            const float *src = s_in + (c * 3 + r) * rowlen + 4 * pl;      // 16-byte aligned
+#pragma unroll
+            for (int k = 0; k < 6; ++k) v[r][k] = src[k];
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int t = 0; t < 9; ++t) acc[i] += v[t / 3][i + t % 3] * wc[t];
+    };
+    if constexpr (CIN == 1) {
+        channel(0);
+    } else {
+#pragma unroll 1                                  // a real loop: unrolled, hipcc hoists all 9 x Cin weight loads again
+        for (int c = 0; c < CIN; ++c) channel(c);
     }
     OT *orow = out + ((size_t)row * W + x0) * ldo + 4 * q;
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
         if (x0 + i >= W) break;
-        f32x4 acc = { 0.f, 0.f, 0.f, 0.f };
-#pragma unroll
-        for (int t = 0; t < 9; ++t)               // same tap / channel order as before: bit-identical sums
-#pragma unroll
-            for (int c = 0; c < CIN; ++c) acc += v[t / 3][i + t % 3][c] * wr[t * CIN + c];
-        acc += sh;
+        const f32x4 a4 = acc[i] + sh;
         f32x4 r;
-        r.x = acc.x > 0.f ? acc.x : 0.f; r.y = acc.y > 0.f ? acc.y : 0.f;
-        r.z = acc.z > 0.f ? acc.z : 0.f; r.w = acc.w > 0.f ? acc.w : 0.f;
+        r.x = a4.x > 0.f ? a4.x : 0.f; r.y = a4.y > 0.f ? a4.y : 0.f;
+        r.z = a4.z > 0.f ? a4.z : 0.f; r.w = a4.w > 0.f ? a4.w : 0.f;
         if constexpr (sizeof(OT) == 4) {
             *reinterpret_cast<f32x4 *>(orow + (size_t)i * ldo) = r;
         } else {
@@ -80,9 +112,10 @@ static hipError_t launch_first_t(const uint8_t *img, const float *lut256, const 
     const int xblocks = (W + ppb - 1) / ppb;
     const long long blocks = (long long)B * H * xblocks;
     if (blocks <= 0 || blocks > 0x7FFFFFFFLL) return hipErrorInvalidValue;
+    const size_t lds = sizeof(float) * 3 * (size_t)Cin * (((size_t)ppb + 2 + 3) & ~(size_t)3);
     switch (Cin) {
-    case 1: hipLaunchKernelGGL((conv3x3_first_kernel<1, OT>), dim3((unsigned)blocks), dim3(256), 0, s, img, lut256, w, shift, out, H, W, Cout, ldo, quads, xblocks); break;
-    case 3: hipLaunchKernelGGL((conv3x3_first_kernel<3, OT>), dim3((unsigned)blocks), dim3(256), 0, s, img, lut256, w, shift, out, H, W, Cout, ldo, quads, xblocks); break;
+    case 1: hipLaunchKernelGGL((conv3x3_first_kernel<1, OT>), dim3((unsigned)blocks), dim3(256), lds, s, img, lut256, w, shift, out, H, W, Cout, ldo, quads, xblocks); break;
+    case 3: hipLaunchKernelGGL((conv3x3_first_kernel<3, OT>), dim3((unsigned)blocks), dim3(256), lds, s, img, lut256, w, shift, out, H, W, Cout, ldo, quads, xblocks); break;
     default: return hipErrorInvalidValue;
     }
     return hipGetLastError();
