@@ -38,14 +38,15 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_bf16(const ConvArgs a, const
                                                          const int m_tiles, const int nwg)
 {
     typedef typename LpVec<T>::x8 bf16x8;
+    static_assert(BN == 32 || BN % 64 == 0, "n-tile of 32 (narrow layers: base 32) or a multiple of 64 output channels");
     constexpr int ROW = KC_BF16 + 8;                     // bf16 elements per LDS row (80 bytes)
-    constexpr int HEAD_ROW = 64 + 4;                     // floats per pixel of the fused head's LDS tile
+    constexpr int HEAD_ROW = BN + 4;                     // floats per pixel of the fused head's LDS tile
     constexpr int HALO = (TAPS == 9) ? 1 : 0;
     constexpr int PW = 32 + 2 * HALO, PH = TH + 2 * HALO, NPIX = PW * PH;
     constexpr int NA8 = NPIX * (KC_BF16 / 8);            // 8-channel pieces of the A patch
     constexpr int A_ITERS = (NA8 + 255) / 256;
     constexpr int MT = TH / 4, NT = BN / 32;
-    constexpr int B_PARTS = BN / 64;                     // 64 rows x 64 bytes = 4 KB = 256 threads x 16 bytes
+    constexpr int B_PARTS = BN >= 64 ? BN / 64 : 1;      // 64 rows x 64 bytes = 4 KB = 256 threads x 16 bytes (BN = 32: half of them)
     constexpr int B_ITERS = TAPS * B_PARTS;
     extern __shared__ __attribute__((aligned(16))) float lds[];
     T *const As = reinterpret_cast<T *>(lds);
@@ -80,6 +81,7 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_bf16(const ConvArgs a, const
         a_loff[s] = live ? pix * ROW + 8 * q : -1;
     }
     const int bq = tid & 3, bn = tid >> 2;               // 16-byte piece (8 bf16) / cout row inside a 64-cout slab
+    const bool b_live = BN >= 64 || bn < BN;             // BN = 32: rows 32..63 of the slab belong to nobody
     const T *w_base = wpk + ((size_t)n0 + bn) * KC_BF16 + 8 * bq;
     const int b_loff = bn * ROW + 8 * bq;
 
@@ -99,7 +101,7 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_bf16(const ConvArgs a, const
 #pragma unroll
         for (int it = 0; it < B_ITERS; ++it) {
             const int tap = it / B_PARTS, part = it % B_PARTS;
-            b_reg[it] = *reinterpret_cast<const bf16x8 *>(w_base + (((size_t)chunk * TAPS + tap) * a.CoutPad + part * 64) * KC_BF16);
+            if (b_live) b_reg[it] = *reinterpret_cast<const bf16x8 *>(w_base + (((size_t)chunk * TAPS + tap) * a.CoutPad + part * 64) * KC_BF16);
         }
     };
     auto store_chunk = [&]() {
@@ -109,7 +111,7 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_bf16(const ConvArgs a, const
 #pragma unroll
         for (int it = 0; it < B_ITERS; ++it) {
             const int tap = it / B_PARTS, part = it % B_PARTS;
-            *reinterpret_cast<bf16x8 *>(Bs + (tap * BN + part * 64) * ROW + b_loff) = b_reg[it];
+            if (b_live) *reinterpret_cast<bf16x8 *>(Bs + (tap * BN + part * 64) * ROW + b_loff) = b_reg[it];
         }
     };
 
@@ -214,7 +216,7 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_bf16(const ConvArgs a, const
                 const int xr = (r & 3) + 8 * (r >> 2);
                 const float v = fmaxf(acc[i][j][r] + sh, relu_lo);
                 if constexpr (HEAD) {                     // pixel (wave*MT + i, xr + 4 lh) of the TH x 32 tile, channel n
-                    lds[((wave * MT + i) * 32 + xr + 4 * lh) * HEAD_ROW + n] = n_ok ? v : 0.f;
+                    lds[((wave * MT + i) * 32 + xr + 4 * lh) * HEAD_ROW + 32 * j + li] = n_ok ? v : 0.f;
                     continue;
                 }
                 const bool ok = interior || (yw + i < a.H && x0 + xr + 4 * lh < a.W);
@@ -224,20 +226,20 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_bf16(const ConvArgs a, const
         }
     }
     if constexpr (HEAD) {
-        static_assert(TAPS == 9 && TH * 32 == 256 && BN == 64 && !OUT_LP, "one pixel per thread, every channel in the workgroup");
-        float *const Wh = lds + 256 * HEAD_ROW;            // [classes][64]
-        if (tid < a.head_classes * 64) Wh[tid] = (tid & 63) < a.Cout ? a.head_w[(tid >> 6) * a.Cout + (tid & 63)] : 0.f;
+        static_assert(TAPS == 9 && TH * 32 == 256 && (BN == 64 || BN == 32) && !OUT_LP, "one pixel per thread, every channel in the workgroup");
+        float *const Wh = lds + 256 * HEAD_ROW;            // [classes][BN]
+        if (tid < a.head_classes * BN) Wh[tid] = (tid % BN) < a.Cout ? a.head_w[(tid / BN) * a.Cout + (tid % BN)] : 0.f;
         __syncthreads();
         f32x4 d4[4];
 #pragma unroll
         for (int k = 0; k < 4; ++k) d4[k] = f32x4{ 0.f, 0.f, 0.f, 0.f };
         const float *yrow = lds + tid * HEAD_ROW;
 #pragma unroll
-        for (int c4 = 0; c4 < 16; ++c4) {
+        for (int c4 = 0; c4 < BN / 4; ++c4) {
             const f32x4 yv = *reinterpret_cast<const f32x4 *>(yrow + 4 * c4);
 #pragma unroll
             for (int k = 0; k < 4; ++k)
-                if (k < a.head_classes) d4[k] += yv * *reinterpret_cast<const f32x4 *>(Wh + 64 * k + 4 * c4);
+                if (k < a.head_classes) d4[k] += yv * *reinterpret_cast<const f32x4 *>(Wh + BN * k + 4 * c4);
         }
         const int py = y0 + (tid >> 5), px = x0 + (tid & 31);
         if (py < a.H && px < a.W) {
@@ -266,23 +268,32 @@ static hipError_t launch_bf16_cfg(const ConvArgs &a, hipStream_t s)
     const int n_tiles = (n_total + BN - 1) / BN;
     const int nwg = m_tiles * n_tiles;
     constexpr int HALO = (TAPS == 9) ? 1 : 0;
-    constexpr size_t lds = 2 * (size_t)(KC_BF16 + 8) * ((32 + 2 * HALO) * (TH + 2 * HALO) + TAPS * BN);
+    constexpr size_t lds_stage = 2 * (size_t)(KC_BF16 + 8) * ((32 + 2 * HALO) * (TH + 2 * HALO) + TAPS * BN);
+    constexpr size_t lds_head = HEAD ? sizeof(float) * (256 * (size_t)(BN + 4) + 4 * BN) : 0;     // [256 px][BN + 4] + [4 classes][BN]
+    constexpr size_t lds = lds_stage > lds_head ? lds_stage : lds_head;
     auto kern = conv_mfma_bf16<T, TAPS, TH, BN, NFAST, OUT_LP, HEAD>;
     if (hipError_t e = ensure_dynamic_lds(kern, lds); e != hipSuccess) return e;
     hipLaunchKernelGGL(kern, dim3(nwg), dim3(256), lds, s, a, tiles_x, tiles_y, m_tiles, nwg);
     return hipGetLastError();
 }
 
-hipError_t launch_conv3x3_bf16(const ConvArgs &a, hipStream_t s)
+// Cout <= 32 (the top level of a base-32 network, BASELINE config 5) takes a 32-wide n-tile: the 64-wide one would stage,
+// read and multiply a half-empty weight slab.
+template <typename T>
+static hipError_t launch_conv3x3_lp(const ConvArgs &a, hipStream_t s)
 {
     if (a.Cin % 8 || a.ldc % 8 || a.CoutPad % NPAD) return hipErrorInvalidValue;
+    const bool narrow = a.Cout <= 32;
     if (a.head_w != nullptr) {
         if (a.out_lp || a.Cout > 64 || a.head_classes < 1 || a.head_classes > 4 || a.pool_out != nullptr || a.head_labels == nullptr)
             return hipErrorInvalidValue;
-        return launch_bf16_cfg<__bf16, 9, 8, 64, false, false, true>(a, s);
+        return narrow ? launch_bf16_cfg<T, 9, 8, 32, false, false, true>(a, s) : launch_bf16_cfg<T, 9, 8, 64, false, false, true>(a, s);
     }
-    return a.out_lp ? launch_bf16_cfg<__bf16, 9, 8, 64, false, true>(a, s) : launch_bf16_cfg<__bf16, 9, 8, 64, false, false>(a, s);
+    if (narrow) return a.out_lp ? launch_bf16_cfg<T, 9, 8, 32, false, true>(a, s) : launch_bf16_cfg<T, 9, 8, 32, false, false>(a, s);
+    return a.out_lp ? launch_bf16_cfg<T, 9, 8, 64, false, true>(a, s) : launch_bf16_cfg<T, 9, 8, 64, false, false>(a, s);
 }
+
+hipError_t launch_conv3x3_bf16(const ConvArgs &a, hipStream_t s) { return launch_conv3x3_lp<__bf16>(a, s); }
 
 hipError_t launch_convT2x2_bf16(const ConvArgs &a, hipStream_t s)
 {
@@ -290,16 +301,7 @@ hipError_t launch_convT2x2_bf16(const ConvArgs &a, hipStream_t s)
     return a.out_lp ? launch_bf16_cfg<__bf16, 1, 8, 64, true, true>(a, s) : launch_bf16_cfg<__bf16, 1, 8, 64, true, false>(a, s);
 }
 
-hipError_t launch_conv3x3_fp16(const ConvArgs &a, hipStream_t s)
-{
-    if (a.Cin % 8 || a.ldc % 8 || a.CoutPad % NPAD) return hipErrorInvalidValue;
-    if (a.head_w != nullptr) {
-        if (a.out_lp || a.Cout > 64 || a.head_classes < 1 || a.head_classes > 4 || a.pool_out != nullptr || a.head_labels == nullptr)
-            return hipErrorInvalidValue;
-        return launch_bf16_cfg<_Float16, 9, 8, 64, false, false, true>(a, s);
-    }
-    return a.out_lp ? launch_bf16_cfg<_Float16, 9, 8, 64, false, true>(a, s) : launch_bf16_cfg<_Float16, 9, 8, 64, false, false>(a, s);
-}
+hipError_t launch_conv3x3_fp16(const ConvArgs &a, hipStream_t s) { return launch_conv3x3_lp<_Float16>(a, s); }
 
 hipError_t launch_convT2x2_fp16(const ConvArgs &a, hipStream_t s)
 {

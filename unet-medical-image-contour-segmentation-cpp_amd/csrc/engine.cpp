@@ -507,8 +507,7 @@ int build_plan(mi_unet *h, const HostWeights &hw)
         Step &lc = h->plan[last - 1];
         if (lc.kind == Step::CONV) lc.feeds_head = true;
         const bool lp_algo = h->algo == MI_UNET_CONV_BF16 || h->algo == MI_UNET_CONV_FP16;
-        if (!(fh && fh[0] == '0') && lc.kind == Step::CONV && (lc.a.wpk4 != nullptr || (lp_algo && lc.a.Cout > 32)) && lc.a.Cout <= 64 && c.classes <= 4 &&   // (narrower layers: the
-            // fused head would read a half-empty 64-channel tile; measured slower than the stand-alone kernel at base 32)
+        if (!(fh && fh[0] == '0') && lc.kind == Step::CONV && (lc.a.wpk4 != nullptr || lp_algo) && lc.a.Cout <= 64 && c.classes <= 4 &&
             lc.a.pool_out == nullptr)
             lc.head_step = last;
     }
