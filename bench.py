@@ -44,13 +44,16 @@ HBM_PEAK_GBS = 8000.0
 
 # multiplies the MFMA pipe executes per algorithmic (direct-convolution) multiply, by kernel family
 WINOGRAD_REDUCTION = {"conv3x3_wino4": 4.0, "conv3x3_wino4s": 4.0, "conv3x3_wino": 2.25, "conv3x3_wino16": 2.25}
-CONV_FAMILIES = ("conv3x3_mfma", "conv3x3_wino", "conv3x3_wino16", "conv3x3_wino4", "conv3x3_wino4s", "conv3x3_bf16", "conv3x3_fp16")
+CONV_FAMILIES = ("conv3x3_mfma", "conv3x3_wino", "conv3x3_wino16", "conv3x3_wino4", "conv3x3_wino4s", "conv3x3_bf16", "conv3x3_fp16",
+                 "conv3x3_bf16w", "conv3x3_fp16w")
+LP_FAMILIES = ("conv3x3_bf16", "conv3x3_fp16", "conv3x3_bf16w", "conv3x3_fp16w", "convT2x2_bf16", "convT2x2_fp16")
 ROCPROF_NAME = {"conv3x3_wino": "miunet::conv3x3_wino_f32<*>", "conv3x3_wino16": "miunet::conv3x3_wino16_f32",
                 "conv3x3_wino4": "miunet::conv3x3_wino4_f32<*>", "conv3x3_wino4s": "miunet::conv3x3_wino4s_f32<*>",
                 "conv3x3_mfma": "miunet::conv_mfma_f32<*>", "convT2x2_taps": "miunet::convT2x2_taps_f32<*>",
                 "convT2x2_mfma": "miunet::conv_mfma_f32<*>", "conv3x3_first": "miunet::conv3x3_first_kernel<*>",
                 "conv3x3_bf16": "miunet::conv_mfma_bf16<*>", "conv3x3_fp16": "miunet::conv_mfma_bf16<*>",
-                "convT2x2_bf16": "miunet::conv_mfma_bf16<*>", "convT2x2_fp16": "miunet::conv_mfma_bf16<*>"}
+                "convT2x2_bf16": "miunet::conv_mfma_bf16<*>", "convT2x2_fp16": "miunet::conv_mfma_bf16<*>",
+                "conv3x3_bf16w": "miunet::conv3x3_lp2<*>", "conv3x3_fp16w": "miunet::conv3x3_lp2<*>"}
 
 
 def family(kernel):
@@ -158,12 +161,12 @@ def roofline_from_stats(stats, spec_macs, ips_per_gpu, tag):
     dom_flops = sum(s["flops"] for s in dom)
     dom_ms = sum(s["ms"] for s in dom)
     all_ms = sum(s["ms"] for s in stats)
-    lp = dom_kernel in ("conv3x3_bf16", "conv3x3_fp16")
+    lp = dom_kernel in LP_FAMILIES
     peak = LP_PEAK_TFLOPS if lp else FP32_PEAK_TFLOPS
     red = WINOGRAD_REDUCTION.get(dom_kernel, 1.0)
     algorithmic = dom_flops / (dom_ms * 1e-3) / 1e12 if dom_ms else 0.0
     executed = algorithmic / red
-    insn = ("v_mfma_f32_32x32x16_f16" if dom_kernel == "conv3x3_fp16" else "v_mfma_f32_32x32x16_bf16" if lp
+    insn = ("v_mfma_f32_32x32x16_f16" if "fp16" in dom_kernel else "v_mfma_f32_32x32x16_bf16" if lp
             else "v_mfma_f32_16x16x4_f32" if dom_kernel == "conv3x3_wino4" else "v_mfma_f32_32x32x2_f32")
     pmc, pmc_src = pmc_summary(tag)
     rk = (pmc or {}).get("kernels", {}).get(ROCPROF_NAME.get(dom_kernel, ""), {})
@@ -175,7 +178,7 @@ def roofline_from_stats(stats, spec_macs, ips_per_gpu, tag):
     families = []
     for name, (n, ms, fl, by) in sorted(fam.items(), key=lambda kv: -kv[1][1]):
         r = WINOGRAD_REDUCTION.get(name, 1.0)
-        pk = LP_PEAK_TFLOPS if (name.endswith("bf16") or name.endswith("fp16")) else FP32_PEAK_TFLOPS
+        pk = LP_PEAK_TFLOPS if name in LP_FAMILIES else FP32_PEAK_TFLOPS
         c = (pmc or {}).get("kernels", {}).get(ROCPROF_NAME.get(name, ""), {})
         families.append({"kernel": name, "launches": n, "share_of_device_time": ms / all_ms if all_ms else None,
                          "avg_launch_ms": ms / n, "algorithmic_tflops": fl / ms / 1e9, "executed_tflops": fl / ms / 1e9 / r,

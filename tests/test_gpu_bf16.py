@@ -138,3 +138,47 @@ def test_config5_fp16_1024_three_channels_five_levels():
     srt = np.sort(ref32, axis=1)
     safe = (srt[:, -1] - srt[:, -2]) > 2e-2
     assert np.array_equal(labels[safe], lab32[safe])
+
+
+# ---------------------------------------------------------------- the wide-layer kernel (conv_lp2.hip: 4 x 4 register tile per wave)
+@pytest.mark.parametrize("op,B,H,W,Cin,Cout", [
+    ("conv3x3_bf16", 2, 16, 32, 64, 128),       # exactly one tile per image, two chunks
+    ("conv3x3_bf16", 1, 21, 45, 40, 128),       # ragged in x and y, Cin % 32 != 0 (masked last chunk)
+    ("conv3x3_bf16", 1, 8, 8, 256, 256),        # a deep-layer shape: two n-tiles, eight chunks, a tile mostly past the image
+    ("conv3x3_fp16", 1, 32, 64, 32, 128),       # several tiles, a single chunk
+    ("conv3x3_fp16", 1, 5, 7, 96, 384),         # three n-tiles
+])
+def test_conv3x3_wide_kernel(op, B, H, W, Cin, Cout):
+    """Same products, same fp32 accumulation order (taps in raster order, 16 channels per MFMA, chunks in order) as the 2 x 2
+    kernel: pinned to the rounded-operand oracle at 1e-4 AND bit-identical to that kernel, 16-bit outputs included."""
+    r = np.random.default_rng(B + 3 * H + 5 * W + Cin + Cout)
+    x = r.standard_normal((B, H, W, Cin), dtype=np.float32)
+    w = (r.standard_normal((Cout, Cin, 3, 3), dtype=np.float32) * np.sqrt(2.0 / (9 * Cin))).astype(np.float32)
+    scale = (1.0 + 0.1 * r.standard_normal(Cout)).astype(np.float32)
+    shift = (0.1 * r.standard_normal(Cout)).astype(np.float32)
+    rnd = orc.bf16_round if op.endswith("bf16") else orc.fp16_round
+    got = binding.layer_debug(op + "w", x, w, scale, shift, relu=True)
+    wf = (w.astype(np.float64) * scale.astype(np.float64)[:, None, None, None]).astype(np.float32)
+    ref = np.maximum(orc.conv3x3(rnd(x), rnd(wf)) + shift, 0.0)
+    assert not np.isnan(got).any(), "unwritten (NaN-poisoned) outputs"
+    assert np.max(np.abs(got - ref)) < 1e-4 * max(1.0, float(np.abs(ref).max()))
+    assert np.array_equal(got, binding.layer_debug(op, x, w, scale, shift, relu=True))
+    got16 = binding.layer_debug(op + "w_lpout", x, w, scale, shift, relu=True)
+    assert np.array_equal(got16, binding.layer_debug(op + "_lpout", x, w, scale, shift, relu=True))
+    assert np.array_equal(got16, rnd(got))                    # the stored 16-bit tensor = one rounding of the fp32 result
+
+
+@pytest.mark.parametrize("algo", ["bf16", "fp16"])
+def test_wide_kernel_in_the_whole_network(algo, monkeypatch):
+    """MIUNET_LP2=2 sends every Cout % 128 == 0 layer (fused pooling included) to the wide kernel whatever its grid, =0 none:
+    identical arithmetic, so logits and label maps must agree bit for bit."""
+    spec = UNetSpec(1, 64, 3, 3)
+    blob = pack_weights(spec, synth.make_weights(spec, 31))
+    imgs = synth.make_images(3, 88, 72, 1, 0x99, "blobs")
+    out = {}
+    for mode in ("0", "2"):
+        monkeypatch.setenv("MIUNET_LP2", mode)
+        with binding.Engine(88, 72, 1, 64, 3, 3, max_batch=2, conv_algo=algo) as eng:
+            eng.load_weights(blob)
+            out[mode] = eng.infer(imgs, want_logits=True)
+    assert np.array_equal(out["0"][1], out["2"][1]) and np.array_equal(out["0"][0], out["2"][0])

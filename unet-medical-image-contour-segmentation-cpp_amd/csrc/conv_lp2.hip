@@ -1,0 +1,258 @@
+// conv_lp2.hip -- the 16-bit-operand conv3x3 for the WIDE layers (Cout a multiple of 128): a 4 x 4 register tile per wave.
+// bf16 or fp16 operands, fp32 accumulation on v_mfma_f32_32x32x16_{bf16,f16}; gfx950 only.
+//
+// Why a second kernel.  conv_mfma_bf16 (conv_lp.hip) gives a wave 2 x 2 blocks of 32 x 32: every MFMA needs one fresh 1 KB
+// fragment from LDS (2 A + 2 B reads per 4 MFMAs).  At 32 cycles per MFMA and four SIMDs that is 256 B/clk per CU against the
+// LDS's 128 B/clk: the matrix pipe cannot be more than 50 % busy, and the counters say exactly that on the deep layers
+// (SQ_VALU_MFMA_BUSY_CYCLES: 0.44 of the cycles at 2.4 GHz = about half of the cycles at the clock this instruction stream
+// actually holds; a register-only loop of the same MFMA sustains 1.89 PFLOP/s at 1.80 GHz on this card,
+// tools/dev/mfma_clock_probe.hip).  Here a wave owns 4 image rows x 128 output channels = 4 x 4 blocks: 4 A + 4 B reads per
+// 16 MFMAs = 0.5 KB per MFMA = the LDS rate exactly, 256 accumulator registers, one wave per SIMD.
+//
+// Even that is the LDS rate EXACTLY, so the weights do not go through LDS at all: all four waves of a workgroup need the same
+// weight fragments, but they are small and hot (one kernel's worth per 32 input channels: 72 KB), so every lane loads its
+// 16-byte fragment straight from L1/L2 with a buffer load whose (chunk, tap, half) displacement is a scalar offset -- the U
+// ring of the fp32 Winograd kernels -- three groups (48 MFMAs) ahead.  LDS then carries only the input patch: 4 reads per 16
+// MFMAs = 0.25 KB per MFMA, half its rate; the weight loads take the other half of the operand traffic on the vector-memory
+// path (4 KB per 16 MFMAs and wave = 32 B/clk per CU of the L1's 64).
+//
+// Workgroup = 4 waves = 16 rows x 32 columns of pixels x 128 output channels.  K is walked in chunks of 32 input channels:
+//   LDS: the 18 x 34 input patch of the chunk [pixel][32 + 8 pad], double-buffered (2 x 48,960 B); the next chunk's patch
+//        travels global -> registers at the start of a chunk and registers -> the other buffer at its end: ONE barrier per chunk
+//        = per 288 MFMAs of a wave;
+//   per chunk and wave: 18 groups (9 taps x 2 halves) of 4 ds_read_b128 + 4 buffer_load_b128 + 16 MFMAs; the patch fragments
+//        are read one group ahead, the weight fragments three.
+// Same arithmetic as conv_mfma_bf16 (same products, fp32 accumulation in k order inside a tap, taps in raster order, chunks in
+// order), same epilogue semantics: + folded-BN shift, ReLU, one round-to-nearest-even to the 16-bit output, optional fused 2x2
+// max pooling (each wave holds rows 4w .. 4w+3: both row pairs in-lane).
+#include <type_traits>
+
+#include "kernel_common.h"
+
+namespace miunet {
+
+template <typename T> struct Lp2Vec { typedef T x8 __attribute__((ext_vector_type(8))); };
+
+__device__ __forceinline__ f32x16 mfma_lp2(Lp2Vec<__bf16>::x8 a, Lp2Vec<__bf16>::x8 b, f32x16 c)
+{
+    return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
+}
+__device__ __forceinline__ f32x16 mfma_lp2(Lp2Vec<_Float16>::x8 a, Lp2Vec<_Float16>::x8 b, f32x16 c)
+{
+    return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0);
+}
+
+struct LP2 {
+    static constexpr int TH = 16, BN = 128, MT = 4, NT = 4;
+    static constexpr int ROW = KC_BF16 + 8;                  // 16-bit elements per LDS row (80 bytes: conflict-free b128 reads)
+    static constexpr int PW = 34, PH = TH + 2, NPIX = PW * PH;
+    static constexpr int A_ELEMS = NPIX * ROW;               // per patch buffer
+    static constexpr int NA8 = NPIX * 4;                     // 16-byte pieces of a patch
+    static constexpr int A_ITERS = (NA8 + 255) / 256;        // 10
+    static constexpr size_t LDS_BYTES = 2 * (size_t)(2 * A_ELEMS);
+};
+
+template <typename T, bool OUT_LP, int WD>
+__global__ __launch_bounds__(256, 1) void conv3x3_lp2(const ConvArgs a, const int tiles_x, const int tiles_y, const int m_tiles,
+                                                      const int nwg)
+{
+    typedef typename Lp2Vec<T>::x8 x8;
+    constexpr int ROW = LP2::ROW, PW = LP2::PW, MT = LP2::MT, NT = LP2::NT, BN = LP2::BN, TH = LP2::TH;
+    constexpr int A_ITERS = LP2::A_ITERS;
+    static_assert(18 % WD == 0, "ring depth must divide the group count");
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    T *const As = reinterpret_cast<T *>(lds);                // [2][NPIX][ROW]
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int li = lane & 31, lh = lane >> 5;
+
+    const int L = xcd_remap(blockIdx.x, nwg);
+    const int n_tile = L / m_tiles;
+    int m = L - n_tile * m_tiles;
+    const int tx = m % tiles_x; m /= tiles_x;
+    const int ty = m % tiles_y;
+    const int b = m / tiles_y;
+    const int x0 = tx * 32, y0 = ty * TH, n0 = n_tile * BN;
+    const T *in_img = reinterpret_cast<const T *>(a.in) + (size_t)b * a.H * a.W * a.ldc;
+
+    // ---- patch staging map: 4 pieces of 8 channels per pixel
+    int a_goff[A_ITERS], a_loff[A_ITERS];
+#pragma unroll
+    for (int s = 0; s < A_ITERS; ++s) {
+        const int e = tid + 256 * s;
+        const int pix = e >> 2, q = e & 3;
+        const int py = pix / PW, px = pix - py * PW;
+        const int gy = y0 - 1 + py, gx = x0 - 1 + px;
+        const bool live = e < LP2::NA8;
+        const bool inb = live && gy >= 0 && gy < a.H && gx >= 0 && gx < a.W;
+        a_goff[s] = inb ? (gy * a.W + gx) * a.ldc + 8 * q : -1;
+        a_loff[s] = live ? pix * ROW + 8 * q : -1;
+    }
+    x8 a_reg[A_ITERS];
+    auto load_a = [&](int chunk) {
+        const int c0 = chunk * KC_BF16;
+#pragma unroll
+        for (int s = 0; s < A_ITERS; ++s) {
+            const int q8 = 8 * ((tid + 256 * s) & 3);
+            x8 v;
+#pragma unroll
+            for (int k = 0; k < 8; ++k) v[k] = (T)0.f;
+            if (a_goff[s] >= 0 && c0 + q8 < a.Cin) v = *reinterpret_cast<const x8 *>(in_img + a_goff[s] + c0);
+            a_reg[s] = v;
+        }
+    };
+    auto store_a = [&](int buf) {
+#pragma unroll
+        for (int s = 0; s < A_ITERS; ++s)
+            if (a_loff[s] >= 0) *reinterpret_cast<x8 *>(As + buf * LP2::A_ELEMS + a_loff[s]) = a_reg[s];
+    };
+
+    // ---- weight fragments straight from global memory: packed [chunk][tap][CoutPad][32]; lane (li, lh) of block j wants the
+    // 8 channels 16 g + 8 lh .. of output channel n0 + 32 j + li; the (chunk, tap, g) displacement is a scalar offset
+    const int nchunks = (a.Cin + KC_BF16 - 1) / KC_BF16;
+    const unsigned tap_bytes = (unsigned)a.CoutPad * KC_BF16 * 2;
+    const __amdgpu_buffer_rsrc_t w_rsrc =
+        __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(a.wpk), 0, (int)((size_t)nchunks * 9 * tap_bytes), 0x00020000);
+    const unsigned w_voff = (unsigned)(((n0 + li) * KC_BF16 + 8 * lh) * 2);
+    auto w_load = [&](int chunk, int grp, int j) {           // grp = 2 tap + g
+        return __builtin_bit_cast(x8, __builtin_amdgcn_raw_buffer_load_b128(w_rsrc, w_voff + (unsigned)(32 * j * KC_BF16 * 2),
+                                                                             (unsigned)(chunk * 9 + (grp >> 1)) * tap_bytes + (grp & 1) * 32, 0));
+    };
+
+    f32x16 acc[MT][NT];
+#pragma unroll
+    for (int i = 0; i < MT; ++i)
+#pragma unroll
+        for (int j = 0; j < NT; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    const T *a_frag = As + ((wave * MT) * PW + li) * ROW + 8 * lh;          // + abuf*A_ELEMS + ((i + dy)*PW + dx)*ROW + 16 g
+    load_a(0);
+    x8 wf[WD][NT];
+#pragma unroll
+    for (int k = 0; k < WD; ++k)
+#pragma unroll
+        for (int j = 0; j < NT; ++j) wf[k][j] = w_load(0, k, j);
+    store_a(0);
+    __syncthreads();
+    for (int chunk = 0; chunk < nchunks; ++chunk) {
+        const int abuf = chunk & 1;
+        const bool more = chunk + 1 < nchunks;
+        const int nxt = more ? chunk + 1 : chunk;                          // the last chunk prefetches itself: straight-line code
+        if (more) load_a(chunk + 1);              // global -> registers; they land during this chunk's 288 MFMAs
+        const T *af0 = a_frag + abuf * LP2::A_ELEMS;
+        auto read_a = [&](int grp, x8 *af) {      // patch fragments of group grp = 2 tap + g
+            const int tap = grp >> 1, g = grp & 1, dy = tap / 3, dx = tap - 3 * dy;
+#pragma unroll
+            for (int i = 0; i < MT; ++i) af[i] = *reinterpret_cast<const x8 *>(af0 + ((i + dy) * PW + dx) * ROW + 16 * g);
+        };
+        x8 af[2][MT];
+        read_a(0, af[0]);
+#pragma unroll
+        for (int k = 0; k < 18; ++k) {
+            if (k + 1 < 18) read_a(k + 1, af[(k + 1) & 1]);               // one group ahead (LDS latency)
+            __builtin_amdgcn_sched_barrier(0);    // ... issued here, not sunk next to their use
+#pragma unroll
+            for (int i = 0; i < MT; ++i)
+#pragma unroll
+                for (int j = 0; j < NT; ++j) acc[i][j] = mfma_lp2(af[k & 1][i], wf[k % WD][j], acc[i][j]);
+            const int kn = k + WD;                // refill the ring slot three groups ahead (into the next chunk at the end)
+#pragma unroll
+            for (int j = 0; j < NT; ++j) wf[k % WD][j] = w_load(kn < 18 ? chunk : nxt, kn % 18, j);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        if (more) store_a(abuf ^ 1);              // the other buffer: its last readers passed the previous barrier
+        __syncthreads();
+    }
+
+    // ---- epilogue: + shift, ReLU, (16-bit rounding), buffer stores.  Lane = channel li of block j, register r = pixel
+    // column (r & 3) + 8 (r >> 2) + 4 lh of image row y0 + 4 wave + i.
+    typedef typename std::conditional<OUT_LP, T, float>::type OutT;
+    constexpr unsigned ES = sizeof(OutT);
+    const __amdgpu_buffer_rsrc_t out_rsrc = __builtin_amdgcn_make_buffer_rsrc(
+        reinterpret_cast<OutT *>(a.out) + (size_t)b * a.H * a.W * a.ldo, 0, (int)((size_t)a.H * a.W * a.ldo * ES), 0x00020000);
+    const bool do_pool = a.pool_out != nullptr;
+    const int Hp = a.H >> 1, Wp = a.W >> 1;
+    const __amdgpu_buffer_rsrc_t pool_rsrc = __builtin_amdgcn_make_buffer_rsrc(
+        do_pool ? reinterpret_cast<OutT *>(a.pool_out) + (size_t)b * Hp * Wp * a.pool_ld : reinterpret_cast<OutT *>(a.out), 0,
+        do_pool ? (int)((size_t)Hp * Wp * a.pool_ld * ES) : 0, 0x00020000);
+    const unsigned pix_bytes = (unsigned)a.ldo * ES, ppix_bytes = (unsigned)a.pool_ld * ES;
+    const float relu_lo = a.relu ? 0.f : -3.402823466e+38f;
+    const int yw = y0 + wave * MT;
+    auto store_out = [&](const __amdgpu_buffer_rsrc_t &rs, float v, unsigned voff, unsigned soff) {
+        if constexpr (OUT_LP) {
+            const T t = (T)v;                     // round-to-nearest-even, once, by the producer
+            __builtin_amdgcn_raw_buffer_store_b16(__builtin_bit_cast(unsigned short, t), rs, voff, soff, 0);
+        } else {
+            __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), rs, voff, soff, 0);
+        }
+    };
+    const bool interior = x0 + 32 <= a.W && y0 + TH <= a.H;
+#pragma unroll
+    for (int j = 0; j < NT; ++j) {
+        const int co = n0 + 32 * j + li;
+        const bool n_ok = co < a.Cout;
+        const float sh = n_ok ? a.bias[co] : 0.f;
+        const unsigned vbase = n_ok ? (unsigned)(((yw * a.W + x0 + 4 * lh) * a.ldo + a.co_off + co) * ES) : 0xFFFFFFFFu;
+        if (do_pool) {
+            const unsigned pbase = n_ok ? (unsigned)((((yw >> 1) * Wp + ((x0 + 4 * lh) >> 1)) * a.pool_ld + co) * ES) : 0xFFFFFFFFu;
+#pragma unroll
+            for (int ip = 0; ip < MT / 2; ++ip)
+#pragma unroll
+                for (int r = 0; r < 16; r += 2) {
+                    const int xr = (r & 3) + 8 * (r >> 2);
+                    const float mx = fmaxf(fmaxf(fmaxf(acc[2 * ip][j][r], acc[2 * ip][j][r + 1]), fmaxf(acc[2 * ip + 1][j][r], acc[2 * ip + 1][j][r + 1])) + sh, relu_lo);
+                    const bool ok = interior || (yw + 2 * ip + 1 < a.H && x0 + xr + 4 * lh + 1 < a.W);
+                    store_out(pool_rsrc, mx, ok ? pbase : 0xFFFFFFFFu, (unsigned)(ip * Wp + (xr >> 1)) * ppix_bytes);
+                }
+        }
+#pragma unroll
+        for (int i = 0; i < MT; ++i) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int xr = (r & 3) + 8 * (r >> 2);
+                const float v = fmaxf(acc[i][j][r] + sh, relu_lo);
+                const bool ok = interior || (yw + i < a.H && x0 + xr + 4 * lh < a.W);
+                store_out(out_rsrc, v, ok ? vbase : 0xFFFFFFFFu, (unsigned)(i * a.W + xr) * pix_bytes);
+            }
+        }
+    }
+}
+
+template <typename T, bool OUT_LP>
+static hipError_t launch_lp2_cfg(const ConvArgs &a, hipStream_t s)
+{
+    const int tiles_x = (a.W + 31) / 32, tiles_y = (a.H + LP2::TH - 1) / LP2::TH;
+    const int m_tiles = tiles_x * tiles_y * a.B;
+    const int n_tiles = (a.Cout + LP2::BN - 1) / LP2::BN;
+    const int nwg = m_tiles * n_tiles;
+    // ring depth 3: a ring of 6 groups measured the same within 1 % and spills a register
+    auto kern = conv3x3_lp2<T, OUT_LP, 3>;
+    if (hipError_t e = ensure_dynamic_lds(kern, LP2::LDS_BYTES); e != hipSuccess) return e;
+    hipLaunchKernelGGL(kern, dim3(nwg), dim3(256), LP2::LDS_BYTES, s, a, tiles_x, tiles_y, m_tiles, nwg);
+    return hipGetLastError();
+}
+
+// the wide-layer kernel takes a layer when its 16 x 32-pixel x 128-channel grid gives every CU a workgroup
+bool conv3x3_lp2_takes(const ConvArgs &a)
+{
+    const char *e = getenv("MIUNET_LP2");
+    if (e && e[0] == '0') return false;
+    if (a.head_w != nullptr || a.Cout % 128 != 0 || a.Cin % 8 || a.CoutPad % NPAD) return false;
+    if (e && e[0] == '2') return true;                                   // parity tests: every eligible layer, whatever its size
+    // measured per layer at batch 16 (r02): faster than the 2 x 2 kernel from Cin = 256 up (down4.c2 0.280 -> 0.226 ms, up1.c1
+    // 0.552 -> 0.459), level with it at Cin = 128, slower below (fewer chunks to amortise its 256-store epilogue)
+    const long long nwg = (long long)((a.W + 31) / 32) * ((a.H + LP2::TH - 1) / LP2::TH) * a.B * (a.Cout / 128);
+    return a.Cin >= 256 && nwg >= 192;
+}
+
+hipError_t launch_conv3x3_lp2(const ConvArgs &a, bool fp16, hipStream_t s)
+{
+    if (fp16) return a.out_lp ? launch_lp2_cfg<_Float16, true>(a, s) : launch_lp2_cfg<_Float16, false>(a, s);
+    return a.out_lp ? launch_lp2_cfg<__bf16, true>(a, s) : launch_lp2_cfg<__bf16, false>(a, s);
+}
+
+}  // namespace miunet

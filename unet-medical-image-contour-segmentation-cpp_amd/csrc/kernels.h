@@ -84,6 +84,10 @@ hipError_t launch_convT2x2_bf16(const ConvArgs &a, hipStream_t s);
 // the same kernels on v_mfma_f32_32x32x16_f16 (BASELINE config 5's arithmetic); a.wpk holds IEEE half weights, same packing
 hipError_t launch_conv3x3_fp16(const ConvArgs &a, hipStream_t s);
 hipError_t launch_convT2x2_fp16(const ConvArgs &a, hipStream_t s);
+// The wide layers (Cout % 128 == 0) of the same pipelines on a 4 x 4 register tile per wave (conv_lp2.hip): half the LDS bytes
+// per MFMA.  Same packing (a.wpk), same arithmetic; conv3x3_lp2_takes says whether the layer's grid fills the chip.
+bool conv3x3_lp2_takes(const ConvArgs &a);
+hipError_t launch_conv3x3_lp2(const ConvArgs &a, bool fp16, hipStream_t s);
 
 // First layer: u8 image -> (LUT /255) -> conv3x3 (Cin = 1..4) + shift + ReLU.  w is [9][Cin][Cout] (BN scale folded).
 // out_kind: 0 = fp32 output, 1 = bf16, 2 = fp16 (the 16-bit pipelines keep every activation tensor 16-bit in HBM)
