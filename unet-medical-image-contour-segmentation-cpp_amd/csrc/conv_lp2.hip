@@ -25,6 +25,7 @@
 // Same arithmetic as conv_mfma_bf16 (same products, fp32 accumulation in k order inside a tap, taps in raster order, chunks in
 // order), same epilogue semantics: + folded-BN shift, ReLU, one round-to-nearest-even to the 16-bit output, optional fused 2x2
 // max pooling (each wave holds rows 4w .. 4w+3: both row pairs in-lane).
+#include <cstdlib>
 #include <type_traits>
 
 #include "kernel_common.h"
@@ -43,21 +44,25 @@ __device__ __forceinline__ f32x16 mfma_lp2(Lp2Vec<_Float16>::x8 a, Lp2Vec<_Float
 }
 
 struct LP2 {
-    static constexpr int TH = 16, BN = 128, MT = 4, NT = 4;
+    static constexpr int TH = 16, MT = 4;
     static constexpr int ROW = KC_BF16 + 8;                  // 16-bit elements per LDS row (80 bytes: conflict-free b128 reads)
     static constexpr int PW = 34, PH = TH + 2, NPIX = PW * PH;
     static constexpr int A_ELEMS = NPIX * ROW;               // per patch buffer
     static constexpr int NA8 = NPIX * 4;                     // 16-byte pieces of a patch
     static constexpr int A_ITERS = (NA8 + 255) / 256;        // 10
-    static constexpr size_t LDS_BYTES = 2 * (size_t)(2 * A_ELEMS);
+    static constexpr size_t lds_bytes(bool dbuf) { return 2 * (size_t)A_ELEMS * (dbuf ? 2 : 1); }
 };
 
-template <typename T, bool OUT_LP, int WD>
-__global__ __launch_bounds__(256, 1) void conv3x3_lp2(const ConvArgs a, const int tiles_x, const int tiles_y, const int m_tiles,
-                                                      const int nwg)
+// (A 4 x 2 variant -- 64 output channels, 128 accumulator registers, two workgroups per CU with one patch buffer each -- was
+// measured on the layers this kernel does not take: within 3 % of the 2 x 2 kernel either way, so it does not exist.)
+template <typename T, bool OUT_LP, int WD, int NT>
+__global__ __launch_bounds__(256, 1) void conv3x3_lp2(const ConvArgs a, const int tiles_x, const int tiles_y,
+                                                                    const int m_tiles, const int nwg)
 {
     typedef typename Lp2Vec<T>::x8 x8;
-    constexpr int ROW = LP2::ROW, PW = LP2::PW, MT = LP2::MT, NT = LP2::NT, BN = LP2::BN, TH = LP2::TH;
+    constexpr int ROW = LP2::ROW, PW = LP2::PW, MT = LP2::MT, BN = 32 * NT, TH = LP2::TH;
+    static_assert(NT == 4, "4 x 4 blocks of 32 x 32 per wave");
+    constexpr bool DBUF = true;
     constexpr int A_ITERS = LP2::A_ITERS;
     static_assert(18 % WD == 0, "ring depth must divide the group count");
     extern __shared__ __attribute__((aligned(16))) float lds[];
@@ -78,18 +83,18 @@ __global__ __launch_bounds__(256, 1) void conv3x3_lp2(const ConvArgs a, const in
     const T *in_img = reinterpret_cast<const T *>(a.in) + (size_t)b * a.H * a.W * a.ldc;
 
     // ---- patch staging map: 4 pieces of 8 channels per pixel
-    int a_goff[A_ITERS], a_loff[A_ITERS];
+    // (the LDS offset of piece s is linear in s -- pixel (tid >> 2) + 64 s -- so only the global offsets take registers)
+    int a_goff[A_ITERS];
 #pragma unroll
     for (int s = 0; s < A_ITERS; ++s) {
         const int e = tid + 256 * s;
         const int pix = e >> 2, q = e & 3;
         const int py = pix / PW, px = pix - py * PW;
         const int gy = y0 - 1 + py, gx = x0 - 1 + px;
-        const bool live = e < LP2::NA8;
-        const bool inb = live && gy >= 0 && gy < a.H && gx >= 0 && gx < a.W;
+        const bool inb = e < LP2::NA8 && gy >= 0 && gy < a.H && gx >= 0 && gx < a.W;
         a_goff[s] = inb ? (gy * a.W + gx) * a.ldc + 8 * q : -1;
-        a_loff[s] = live ? pix * ROW + 8 * q : -1;
     }
+    const int a_loff0 = (tid >> 2) * ROW + 8 * (tid & 3);
     x8 a_reg[A_ITERS];
     auto load_a = [&](int chunk) {
         const int c0 = chunk * KC_BF16;
@@ -106,7 +111,7 @@ __global__ __launch_bounds__(256, 1) void conv3x3_lp2(const ConvArgs a, const in
     auto store_a = [&](int buf) {
 #pragma unroll
         for (int s = 0; s < A_ITERS; ++s)
-            if (a_loff[s] >= 0) *reinterpret_cast<x8 *>(As + buf * LP2::A_ELEMS + a_loff[s]) = a_reg[s];
+            if (tid + 256 * s < LP2::NA8) *reinterpret_cast<x8 *>(As + buf * LP2::A_ELEMS + a_loff0 + 64 * s * ROW) = a_reg[s];
     };
 
     // ---- weight fragments straight from global memory: packed [chunk][tap][CoutPad][32]; lane (li, lh) of block j wants the
@@ -139,7 +144,7 @@ __global__ __launch_bounds__(256, 1) void conv3x3_lp2(const ConvArgs a, const in
     store_a(0);
     __syncthreads();
     for (int chunk = 0; chunk < nchunks; ++chunk) {
-        const int abuf = chunk & 1;
+        const int abuf = DBUF ? (chunk & 1) : 0;
         const bool more = chunk + 1 < nchunks;
         const int nxt = more ? chunk + 1 : chunk;                          // the last chunk prefetches itself: straight-line code
         if (more) load_a(chunk + 1);              // global -> registers; they land during this chunk's 288 MFMAs
@@ -164,8 +169,14 @@ __global__ __launch_bounds__(256, 1) void conv3x3_lp2(const ConvArgs a, const in
             for (int j = 0; j < NT; ++j) wf[k % WD][j] = w_load(kn < 18 ? chunk : nxt, kn % 18, j);
             __builtin_amdgcn_sched_barrier(0);
         }
-        if (more) store_a(abuf ^ 1);              // the other buffer: its last readers passed the previous barrier
-        __syncthreads();
+        if constexpr (DBUF) {
+            if (more) store_a(abuf ^ 1);          // the other buffer: its last readers passed the previous barrier
+            __syncthreads();
+        } else {
+            __syncthreads();                      // every wave is done reading the one buffer
+            if (more) store_a(0);
+            __syncthreads();
+        }
     }
 
     // ---- epilogue: + shift, ReLU, (16-bit rounding), buffer stores.  Lane = channel li of block j, register r = pixel
@@ -222,37 +233,40 @@ __global__ __launch_bounds__(256, 1) void conv3x3_lp2(const ConvArgs a, const in
     }
 }
 
-template <typename T, bool OUT_LP>
+template <typename T, bool OUT_LP, int NT>
 static hipError_t launch_lp2_cfg(const ConvArgs &a, hipStream_t s)
 {
+    constexpr int BN = 32 * NT;
+    constexpr size_t lds_bytes = LP2::lds_bytes(NT == 4);
     const int tiles_x = (a.W + 31) / 32, tiles_y = (a.H + LP2::TH - 1) / LP2::TH;
     const int m_tiles = tiles_x * tiles_y * a.B;
-    const int n_tiles = (a.Cout + LP2::BN - 1) / LP2::BN;
+    const int n_tiles = (a.Cout + BN - 1) / BN;
     const int nwg = m_tiles * n_tiles;
     // ring depth 3: a ring of 6 groups measured the same within 1 % and spills a register
-    auto kern = conv3x3_lp2<T, OUT_LP, 3>;
-    if (hipError_t e = ensure_dynamic_lds(kern, LP2::LDS_BYTES); e != hipSuccess) return e;
-    hipLaunchKernelGGL(kern, dim3(nwg), dim3(256), LP2::LDS_BYTES, s, a, tiles_x, tiles_y, m_tiles, nwg);
+    auto kern = conv3x3_lp2<T, OUT_LP, 3, NT>;
+    if (hipError_t e = ensure_dynamic_lds(kern, lds_bytes); e != hipSuccess) return e;
+    hipLaunchKernelGGL(kern, dim3(nwg), dim3(256), lds_bytes, s, a, tiles_x, tiles_y, m_tiles, nwg);
     return hipGetLastError();
 }
 
-// the wide-layer kernel takes a layer when its 16 x 32-pixel x 128-channel grid gives every CU a workgroup
+// Which layers it takes (measured per layer at batch 16, r02): faster than the 2 x 2 kernel of conv_lp.hip from Cin = 256 up
+// (down4.c2 0.280 -> 0.226 ms, up1.c1 0.552 -> 0.459), level with it at Cin = 128, slower below (fewer chunks to amortise its
+// 256-store epilogue).  MIUNET_LP2: 0 = never; 2 = every Cout % 128 == 0 layer whatever its size (parity tests).
 bool conv3x3_lp2_takes(const ConvArgs &a)
 {
     const char *e = getenv("MIUNET_LP2");
     if (e && e[0] == '0') return false;
     if (a.head_w != nullptr || a.Cout % 128 != 0 || a.Cin % 8 || a.CoutPad % NPAD) return false;
-    if (e && e[0] == '2') return true;                                   // parity tests: every eligible layer, whatever its size
-    // measured per layer at batch 16 (r02): faster than the 2 x 2 kernel from Cin = 256 up (down4.c2 0.280 -> 0.226 ms, up1.c1
-    // 0.552 -> 0.459), level with it at Cin = 128, slower below (fewer chunks to amortise its 256-store epilogue)
+    if (e && e[0] == '2') return true;
     const long long nwg = (long long)((a.W + 31) / 32) * ((a.H + LP2::TH - 1) / LP2::TH) * a.B * (a.Cout / 128);
     return a.Cin >= 256 && nwg >= 192;
 }
 
 hipError_t launch_conv3x3_lp2(const ConvArgs &a, bool fp16, hipStream_t s)
 {
-    if (fp16) return a.out_lp ? launch_lp2_cfg<_Float16, true>(a, s) : launch_lp2_cfg<_Float16, false>(a, s);
-    return a.out_lp ? launch_lp2_cfg<__bf16, true>(a, s) : launch_lp2_cfg<__bf16, false>(a, s);
+    if (a.Cout % 128 != 0 || a.head_w != nullptr) return hipErrorInvalidValue;
+    if (fp16) return a.out_lp ? launch_lp2_cfg<_Float16, true, 4>(a, s) : launch_lp2_cfg<_Float16, false, 4>(a, s);
+    return a.out_lp ? launch_lp2_cfg<__bf16, true, 4>(a, s) : launch_lp2_cfg<__bf16, false, 4>(a, s);
 }
 
 }  // namespace miunet
