@@ -169,9 +169,16 @@ def test_conv3x3_wino4_tap_orientation_exact():
     (2, 9, 70, 40, 128),       # ragged rows and columns, Cin % 32 != 0, the 4x4 configuration
     (1, 6, 32, 96, 256),       # the 2x8 configuration
     (1, 2, 33, 64, 576),       # the 1x16 configuration, two n-tiles, masked channels
+    (1, 32, 32, 1024, 512),    # up1.t of a single image: 1 x 2 blocks, 256 workgroups
+    (1, 64, 64, 512, 256),     # up2.t of a single image: 1 x 4 blocks, 256 workgroups
 ])
-@pytest.mark.parametrize("op", ["convT2x2", "convT2x2_taps"])
-def test_convT2x2_mfma(B, H, W, Cin, Cout, op):
+@pytest.mark.parametrize("op", ["convT2x2", "convT2x2_taps", "convT2x2_taps:large"])
+def test_convT2x2_mfma(B, H, W, Cin, Cout, op, monkeypatch):
+    # these inputs are far below one workgroup per CU, where the per-tap launcher shrinks its tiles to one row x 64 or 128
+    # channels at four workgroups per CU; ":large" pins the whole-batch shapes (MB x NBK = 1x8, 2x4, 4x2) on the same inputs
+    if op.endswith(":large"):
+        monkeypatch.setenv("MIUNET_CONVT_SMALL", "0")
+        op = op.split(":")[0]
     r = _rng(H * 7 + W + Cin)
     x = r.standard_normal((B, H, W, Cin), dtype=np.float32)
     w = (r.standard_normal((Cin, Cout, 2, 2), dtype=np.float32) / np.sqrt(Cin)).astype(np.float32)

@@ -169,7 +169,8 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wino4s_f32(const ConvArgs a, c
         for (int r = 0; r < 4; ++r) acc[p][r] = init;
     }
 
-    for (int chunk = 0; chunk < nchunks; ++chunk) {
+    int chunk = 0;                            // at least one chunk: a do-while has no zero-trip path to merge accumulators with
+    do {
         // the patch DMA of this chunk is older than the UD youngest loads (the U ring): wait for everything but those
         __builtin_amdgcn_s_waitcnt(0x0F70 | (UD & 15) | ((UD >> 4) << 14));
         __syncthreads();                      // every wave's part of the patch has landed; nobody reads V any more
@@ -193,7 +194,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wino4s_f32(const ConvArgs a, c
             av = avn;
             __builtin_amdgcn_sched_barrier(0);
         }
-    }
+    } while (++chunk < nchunks);
 
     // ---- epilogue: Y = A^T M A in-lane on all four tiles of a lane at once (the accumulator's four registers = tile
     // columns r = 0..3 of tile row kq, lane = channel), ReLU, 4x4 stores (+ the 2x2 pooled maxima).  Stores are buffer

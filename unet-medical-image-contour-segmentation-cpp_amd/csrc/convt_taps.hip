@@ -39,7 +39,7 @@ template <int MB, int NBK, int WPS>
 __global__ __launch_bounds__(256, WPS) void convT2x2_taps_f32(const ConvArgs a, const int tiles_x, const int tiles_y,
                                                               const int m_tiles, const int nwg, const int cpad)
 {
-    static_assert(MB * NBK * WPS == 16, "sixteen (WPS = 1) or eight (WPS = 2) 32x32 accumulators per wave");
+    static_assert(MB * NBK * WPS <= 16, "sixteen (WPS = 1), eight (2) or at most four (4) 32x32 accumulators per wave");
     using G = CTGeom<MB>;
     constexpr int A_P = G::A_P;
     constexpr int CPS = CT_SC / CT_KC;
@@ -114,7 +114,7 @@ __global__ __launch_bounds__(256, WPS) void convT2x2_taps_f32(const ConvArgs a, 
     f32x4 av[MB];
 #pragma unroll
     for (int mb = 0; mb < MB; ++mb) av[mb] = *reinterpret_cast<const f32x4 *>(a_rd + mb * 32 * A_P);
-    for (int S = 0; S < nsuper; ++S) {
+    auto super_chunk = [&](const int S) {
         const int buf = S & 1;
         if (S + 1 < nsuper) raw_load(S + 1);              // registers; they land during this super-chunk's 256 MFMAs
 #pragma unroll
@@ -150,6 +150,14 @@ __global__ __launch_bounds__(256, WPS) void convT2x2_taps_f32(const ConvArgs a, 
 #pragma unroll
             for (int mb = 0; mb < MB; ++mb) av[mb] = *reinterpret_cast<const f32x4 *>(a_rd + (buf ^ 1) * G::A_FLOATS + mb * 32 * A_P);
         }
+    };
+    // at least one super-chunk: as a do-while there is no zero-trip path whose accumulators hipcc merges with the loop's
+    // (150 register moves per tile); the 256-accumulator shapes spill in that form and keep the plain loop
+    if constexpr (WPS == 1) {
+        for (int S = 0; S < nsuper; ++S) super_chunk(S);
+    } else {
+        int S = 0;
+        do super_chunk(S); while (++S < nsuper);
     }
 
     // ---- epilogue: + bias, pixel-shuffle store.  Lane = channel (li) of block nb, register r = pixel column
@@ -200,26 +208,54 @@ static hipError_t launch_taps_cfg(const ConvArgs &a, int cpad, hipStream_t s)
     return hipGetLastError();
 }
 
+// The shape the launcher gives a layer: {MB image rows, NBK 32-channel blocks, waves per SIMD}.  Whole batches get the
+// measured-best shapes of DESIGN.md 4.4; when those leave the chip short of ~one workgroup per CU (single images, the deep
+// levels: 32 x 32 pixels x 512 channels is 64 of the large tiles) the tile shrinks to one row x 128 or 64 channels with
+// four workgroups per CU, which is latency cover for a K loop of 1024 channels rather than operand reuse.
+struct TapsShape { int mb, nbk, wps; };
+static long long taps_grid(const ConvArgs &a, const TapsShape &t)
+{
+    return (long long)((a.W + 31) / 32) * ((a.H + t.mb - 1) / t.mb) * a.B * ((a.Cout + 32 * t.nbk - 1) / (32 * t.nbk));
+}
+static TapsShape taps_shape(const ConvArgs &a)
+{
+    static const int mode = [] { const char *e = getenv("MIUNET_CONVT_WPS"); return e ? atoi(e) : 2; }();
+    if (mode != 2) {
+        if (a.Cout > 256) return { 1, 16, 1 };
+        if (a.Cout > 128) return { 2, 8, 1 };
+        if (a.Cout > 64) return { 4, 4, 1 };
+        return { 8, 2, 1 };
+    }
+    const TapsShape big = a.Cout > 256 ? TapsShape{ 1, 8, 2 } : a.Cout > 64 ? TapsShape{ 2, 4, 2 } : TapsShape{ 4, 2, 2 };
+    const char *small = getenv("MIUNET_CONVT_SMALL");        // 0: never shrink (parity tests of the large shapes on small inputs)
+    if (taps_grid(a, big) >= 192 || (small && small[0] == '0')) return big;
+    if (a.Cout > 64 && taps_grid(a, { 1, 4, 4 }) >= 192) return { 1, 4, 4 };
+    return { 1, 2, 4 };
+}
+long long convT_taps_grid(const ConvArgs &a) { return taps_grid(a, taps_shape(a)); }
+
 // a.wpk4 = the per-tap packing [Cin^32 / 8][4 taps][convT_taps_cpad(Cout)][8]; everything else as launch_convT2x2_mfma
 hipError_t launch_convT2x2_taps(const ConvArgs &a, hipStream_t s)
 {
     if (a.wpk4 == nullptr || a.Cin % 4 || a.ldc % 4) return hipErrorInvalidValue;
     const int cpad = convT_taps_cpad(a.Cout);
-    // default: half-size tiles, eight accumulators per wave, TWO workgroups per CU (measured 3-10 % faster than the
+    // whole batches: half-size tiles, eight accumulators per wave, TWO workgroups per CU (measured 3-10 % faster than the
     // sixteen-accumulator tiles on all four layers at batch 16: up1.t 0.501 -> 0.488 ms, up2.t 0.511 -> 0.499, up3.t 0.576 ->
     // 0.529, up4.t 0.706 -> 0.630; the other eight-accumulator shapes -- <1,8> at Cout 256, <4,2> at 128, and four workgroups
     // per CU with <2,2> at 64 -- were each within 2 % or slower); MIUNET_CONVT_WPS=1 keeps the large tiles
-    const char *wps = getenv("MIUNET_CONVT_WPS");
-    const int mode = wps ? atoi(wps) : 2;
-    if (mode == 2) {
-        if (a.Cout > 256) return launch_taps_cfg<1, 8, 2>(a, cpad, s);
-        if (a.Cout > 64) return launch_taps_cfg<2, 4, 2>(a, cpad, s);
-        return launch_taps_cfg<4, 2, 2>(a, cpad, s);
+    const TapsShape t = taps_shape(a);
+    const int key = t.mb * 100 + t.nbk * 10 + t.wps;
+    switch (key) {
+    case 182: return launch_taps_cfg<1, 8, 2>(a, cpad, s);
+    case 242: return launch_taps_cfg<2, 4, 2>(a, cpad, s);
+    case 422: return launch_taps_cfg<4, 2, 2>(a, cpad, s);
+    case 144: return launch_taps_cfg<1, 4, 4>(a, cpad, s);
+    case 124: return launch_taps_cfg<1, 2, 4>(a, cpad, s);
+    case 281: return launch_taps_cfg<2, 8>(a, cpad, s);
+    case 441: return launch_taps_cfg<4, 4>(a, cpad, s);
+    case 821: return launch_taps_cfg<8, 2>(a, cpad, s);
+    default: return launch_taps_cfg<1, 16>(a, cpad, s);
     }
-    if (a.Cout > 256) return launch_taps_cfg<1, 16>(a, cpad, s);
-    if (a.Cout > 128) return launch_taps_cfg<2, 8>(a, cpad, s);
-    if (a.Cout > 64) return launch_taps_cfg<4, 4>(a, cpad, s);
-    return launch_taps_cfg<8, 2>(a, cpad, s);
 }
 
 }  // namespace miunet

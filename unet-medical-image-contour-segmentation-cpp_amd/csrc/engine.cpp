@@ -267,15 +267,6 @@ void pack_convT_bf16(const float *w, int cin, int cout, uint16_t *dst, size_t np
                     cvt(w[((size_t)ci * cout + co) * 4 + k]);
 }
 
-// workgroups the per-tap kernel would launch (its tiles are large: MB rows x 32 pixels x up to 512 channels); single images
-// leave the deep levels with a few dozen of them, and the direct kernel's 64-wide column tiles fill the chip better there
-long long convT_taps_grid(const ConvArgs &a)
-{
-    const int mb = a.Cout > 256 ? 1 : a.Cout > 128 ? 2 : a.Cout > 64 ? 4 : 8;
-    const int nbk = 16 / mb;
-    return (long long)((a.W + 31) / 32) * ((a.H + mb - 1) / mb) * a.B * ((a.Cout + 32 * nbk - 1) / (32 * nbk));
-}
-
 bool convT_taps_enabled()
 {
     const char *e = std::getenv("MIUNET_CONVT_TAPS");
@@ -622,7 +613,7 @@ int launch_plan(mi_unet *h, const uint8_t *d_imgs, int B, uint8_t *d_labels, flo
             a.out_lp = lp_kind != 0 ? 1 : 0;
             if (h->algo == MI_UNET_CONV_BF16) { kname = "convT2x2_bf16"; e = launch_convT2x2_bf16(a, s); }
             else if (h->algo == MI_UNET_CONV_FP16) { kname = "convT2x2_fp16"; e = launch_convT2x2_fp16(a, s); }
-            else if (a.wpk4 != nullptr && convT_taps_grid(a) >= 192) { kname = "convT2x2_taps"; e = launch_convT2x2_taps(a, s); }
+            else if (a.wpk4 != nullptr && convT_taps_grid(a) >= 128) { kname = "convT2x2_taps"; e = launch_convT2x2_taps(a, s); }
             else { kname = "convT2x2_mfma"; e = launch_convT2x2_mfma(a, s); }
             break;
         }

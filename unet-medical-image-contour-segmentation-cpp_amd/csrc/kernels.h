@@ -74,6 +74,9 @@ hipError_t launch_convT2x2_mfma(const ConvArgs &a, hipStream_t s);
 // The transposed conv as four per-tap GEMMs sharing one A operand (convt_taps.hip): a.wpk4 holds the weights packed
 // [ceil(Cin/32)*4 chunks of 8][4 taps (dy*2+dx)][convT_taps_cpad(Cout)][8], zero-padded; other fields as above.
 inline int convT_taps_cpad(int cout) { return (cout + NPAD - 1) / NPAD * NPAD; }
+// workgroups launch_convT2x2_taps would start with the tile shape it picks for this layer (the engine keeps the direct
+// kernel below half a workgroup per CU)
+long long convT_taps_grid(const ConvArgs &a);
 hipError_t launch_convT2x2_taps(const ConvArgs &a, hipStream_t s);
 
 // BASELINE config 3: bf16 operands, fp32 accumulate on v_mfma_f32_32x32x16_bf16.  Activations are bf16 in HBM too (rounded

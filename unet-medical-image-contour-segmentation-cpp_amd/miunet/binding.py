@@ -11,7 +11,8 @@ import os
 import numpy as np
 
 PKG_DIR = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-LIB_PATH = os.path.join(PKG_DIR, "libmiunet.so")
+# MIUNET_LIB: another build of the same library (same-card A/B measurements of a kernel change, tools/dev/)
+LIB_PATH = os.environ.get("MIUNET_LIB") or os.path.join(PKG_DIR, "libmiunet.so")
 
 EXPORTS = [
     "mi_unet_default_config", "mi_unet_create", "mi_unet_load_weights", "mi_unet_load_weights_from_memory",
