@@ -182,3 +182,63 @@ def test_wide_kernel_in_the_whole_network(algo, monkeypatch):
             eng.load_weights(blob)
             out[mode] = eng.infer(imgs, want_logits=True)
     assert np.array_equal(out["0"][1], out["2"][1]) and np.array_equal(out["0"][0], out["2"][0])
+
+
+# ---------------------------------------------------------------- the narrow-layer kernel (conv_lpr.hip: weights in registers, persistent)
+@pytest.mark.parametrize("op,B,H,W,Cin,Cout", [
+    ("conv3x3_bf16", 2, 16, 64, 64, 64),        # 64 -> 64: one 32-channel block per wave, both column halves; border tiles only
+    ("conv3x3_bf16", 1, 40, 96, 64, 64),        # ... with interior tiles (offsets through the scalar offset)
+    ("conv3x3_fp16", 1, 24, 100, 32, 32),       # 32 -> 32, ragged in x (a 4-pixel tile column)
+    ("conv3x3_fp16", 1, 21, 45, 64, 32),        # 64 -> 32, ragged in x and y, odd height
+    ("conv3x3_bf16", 3, 8, 32, 32, 64),         # 32 -> 64, one tile per image
+    ("conv3x3_fp16", 1, 72, 160, 32, 64),       # 32 -> 64 with interior tiles
+])
+def test_conv3x3_resident_weights(op, B, H, W, Cin, Cout):
+    """Same products and fp32 accumulation order as the 2 x 2 kernel: its stored 16-bit tensor bit for bit, and within one
+    16-bit rounding of the rounded-operand oracle."""
+    r = np.random.default_rng(7 * B + 3 * H + 5 * W + Cin + Cout)
+    x = r.standard_normal((B, H, W, Cin), dtype=np.float32)
+    w = (r.standard_normal((Cout, Cin, 3, 3), dtype=np.float32) * np.sqrt(2.0 / (9 * Cin))).astype(np.float32)
+    scale = (1.0 + 0.1 * r.standard_normal(Cout)).astype(np.float32)
+    shift = (0.1 * r.standard_normal(Cout)).astype(np.float32)
+    rnd = orc.bf16_round if op.endswith("bf16") else orc.fp16_round
+    got16 = binding.layer_debug(op + "r_lpout", x, w, scale, shift, relu=True)
+    assert not np.isnan(got16).any(), "unwritten (NaN-poisoned) outputs"
+    assert np.array_equal(got16, binding.layer_debug(op + "_lpout", x, w, scale, shift, relu=True))
+    wf = (w.astype(np.float64) * scale.astype(np.float64)[:, None, None, None]).astype(np.float32)
+    ref = np.maximum(orc.conv3x3(rnd(x), rnd(wf)) + shift, 0.0)
+    ulp = 2.0 ** -7 if op.endswith("bf16") else 2.0 ** -10
+    assert np.max(np.abs(got16 - ref) / np.maximum(1.0, np.abs(ref))) < ulp
+
+
+@pytest.mark.parametrize("op,Cin,Cout", [("conv3x3_fp16", 32, 32), ("conv3x3_bf16", 64, 64)])
+def test_conv3x3_resident_weights_many_tiles_per_workgroup(op, Cin, Cout):
+    """2 048 tiles on 256 persistent workgroups: eight tiles each, so the patch ring wraps (twice at depth 4) and every
+    wait / barrier of the steady state runs; compared with the one-tile-per-workgroup kernel bit for bit."""
+    r = np.random.default_rng(Cin + Cout)
+    x = r.standard_normal((2, 256, 1024, Cin), dtype=np.float32)
+    w = (r.standard_normal((Cout, Cin, 3, 3), dtype=np.float32) * np.sqrt(2.0 / (9 * Cin))).astype(np.float32)
+    shift = (0.1 * r.standard_normal(Cout)).astype(np.float32)
+    got16 = binding.layer_debug(op + "r_lpout", x, w, None, shift, relu=True)
+    assert not np.isnan(got16).any()
+    assert np.array_equal(got16, binding.layer_debug(op + "_lpout", x, w, None, shift, relu=True))
+
+
+@pytest.mark.parametrize("algo,in_ch,levels", [("fp16", 3, 3), ("bf16", 1, 2)])
+def test_resident_weight_kernel_in_the_whole_network(algo, in_ch, levels, monkeypatch):
+    """base 32: inc.c2 (32 -> 32, pooled), down1.c1 (32 -> 64), down1.c2 (64 -> 64, pooled), the second-level up.c2 (64 -> 64)
+    and the top up.c1 (64 -> 32) all fit the resident-weight kernel -- every shape, the fused pooling, concat-buffer strides.
+    MIUNET_LPR=2 sends them there whatever the grid, =0 nowhere: identical arithmetic, identical logits and labels."""
+    spec = UNetSpec(in_ch, 32, levels, 3)
+    blob = pack_weights(spec, synth.make_weights(spec, 77))
+    imgs = synth.make_images(3, 96, 80, in_ch, 0x51, "blobs")
+    out, used = {}, {}
+    for mode in ("0", "2"):
+        monkeypatch.setenv("MIUNET_LPR", mode)
+        with binding.Engine(96, 80, in_ch, 32, levels, 3, max_batch=3, conv_algo=algo) as eng:
+            eng.load_weights(blob)
+            eng.set_profiling(True)
+            out[mode] = eng.infer(imgs, want_logits=True)
+            used[mode] = sum(s["kernel"].endswith("16r") for s in eng.kernel_stats())
+    assert used["0"] == 0 and used["2"] == 5      # inc.c2, down1.c1, down1.c2, the second-level up.c2, the top up.c1
+    assert np.array_equal(out["0"][1], out["2"][1]) and np.array_equal(out["0"][0], out["2"][0])

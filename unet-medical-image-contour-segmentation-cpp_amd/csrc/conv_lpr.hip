@@ -1,0 +1,360 @@
+// conv_lpr.hip -- the narrow 16-bit 3x3 layers (Cin, Cout <= 64) with the weights resident in registers, gfx950 only.
+#include <cstdlib>
+#include <type_traits>
+
+#include "kernel_common.h"
+
+namespace miunet {
+
+// --------------------------------------------------------------------------------------------------------------------
+// The top levels of the 16-bit pipelines (512 x 512 x 64 in BASELINE config 3, 1024 x 1024 x 32 and 512 x 512 x 64 in
+// config 5) sit at the ridge of the roofline: 64 -> 64 channels is 288 FLOP per byte moved, 32 -> 32 half of that, against
+// 1.89 PFLOP/s / 6.3 TB/s = 300.  conv_mfma_bf16 (conv_lp.hip) runs them at 40-48 % of either roof: one tile per workgroup,
+// and every tile stages the layer's WHOLE weight set into LDS again (73 KB for 64 -> 64: more bytes than its input patch),
+// waits for its patch with nothing else to do, and reads one LDS fragment per MFMA.  Here:
+//   * one PERSISTENT workgroup of eight waves per CU walks its XCD's share of the 8 x 32-pixel tiles;
+//   * the weights never touch LDS: a layer's 9 x Cin x Cout 16-bit weights are 9 x Cin/16 MFMA B-fragments of four
+//     registers per 32 output channels -- 72 registers for 32 -> 32, 144 for 64 -> 32, 32 -> 64, and for 64 -> 64 when a wave
+//     keeps one 32-channel block (its partner wave the other).  Loaded once per workgroup, they stay for every tile;
+//   * LDS holds only input patches: a ring of NBUF (8+2) x (32+2)-pixel patches, 64 bytes per pixel and 32-channel plane,
+//     filled by LDS-DMA loads (buffer_load ... lds, 16 bytes per lane, no staging registers) LEAD = NBUF - 1 tiles ahead of
+//     the MFMAs -- one to two patches (22-87 KB) in flight per CU at any time, which is what 1/256 of the HBM bandwidth
+//     needs at its latency.  An LDS-DMA load places lane l's 16 bytes at base + 16 l, so rows cannot be padded; instead
+//     the four 16-byte pieces of pixel p sit in slots piece ^ ((p >> 1) & 3): eight consecutive pixels then cover all eight
+//     16-byte bank groups whatever piece they read (conflict-free ds_read_b128), and the permutation costs nothing -- it is
+//     the per-lane global offset of the load;
+//   * an MFMA row block is 2 image rows x 16 columns (not 1 x 32): the 32x32 accumulator then holds every 2 x 2 output
+//     block in ONE lane (registers r, r+1, r+8, r+9), so the fused max pooling stays in-lane;
+//   * one barrier per tile.  A wave waits for ITS loads of tile n+1 after the MFMAs of tile n and before its stores
+//     (vmcnt <= the loads it issued for the tiles after n+1: loads return in order, so that bound holds whatever the
+//     stores of tile n-1 do), the barrier at the head of the next tile publishes them;
+//   * outputs leave through a wave-private LDS tile as 16-byte stores (the conv_lp.hip epilogue, without its barrier).
+// Same products and the same fp32 accumulation order as conv_mfma_bf16 (chunks of 32 channels, taps in raster order, 16
+// channels per MFMA): bit-identical results (tests/test_gpu_bf16.py::test_conv3x3_resident_weights).
+template <typename T> struct LprVec { typedef T x8 __attribute__((ext_vector_type(8))); };
+
+__device__ __forceinline__ f32x16 mfma_lpr(LprVec<__bf16>::x8 a, LprVec<__bf16>::x8 b, f32x16 c)
+{
+    return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
+}
+__device__ __forceinline__ f32x16 mfma_lpr(LprVec<_Float16>::x8 a, LprVec<_Float16>::x8 b, f32x16 c)
+{
+    return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0);
+}
+
+struct LPR {
+    static constexpr int TH = 8, PW = 34, NPIX = 340;            // (8 + 2) x (32 + 2) pixels per patch
+    static constexpr int PLANE_LOADS = 22;                        // wave-wide LDS-DMA loads per 32-channel plane: 16 pixels each
+    static constexpr int PLANE_BYTES = PLANE_LOADS * 1024;
+    static constexpr int TROW = 40;                               // 16-bit elements per pixel of the output tile (32 + 8 pad)
+    static constexpr int SCR_BYTES = (32 + 8) * TROW * 2;         // per wave: [32 pixels][TROW] + pooled [8][TROW]
+    static constexpr size_t lds_bytes(int cin, int nbuf) { return (size_t)nbuf * (cin / 32) * PLANE_BYTES + 8 * SCR_BYTES; }
+};
+
+template <int N> __device__ __forceinline__ void lpr_wait_vm()
+{
+    __builtin_amdgcn_s_waitcnt(0x0F70 | (N & 15) | ((N >> 4) << 14));      // vmcnt(N); expcnt / lgkmcnt untouched
+}
+__device__ __forceinline__ void lpr_wait_vm_n(int n)      // uniform n
+{
+    switch (n) {
+    case 0: lpr_wait_vm<0>(); break;
+    case 2: lpr_wait_vm<2>(); break;
+    case 3: lpr_wait_vm<3>(); break;
+    case 4: lpr_wait_vm<4>(); break;
+    case 5: lpr_wait_vm<5>(); break;
+    case 6: lpr_wait_vm<6>(); break;
+    case 10: lpr_wait_vm<10>(); break;
+    case 12: lpr_wait_vm<12>(); break;
+    default: lpr_wait_vm<0>(); break;
+    }
+}
+
+// CIN = 32 or 64 input channels (exactly), NBT = 1 or 2 blocks of 32 output channels (Cout = 32 NBT exactly), NBUF = patch ring
+template <typename T, int CIN, int NBT, int NBUF>
+__global__ __launch_bounds__(512, 1) void conv3x3_lpr(const ConvArgs a, const int tiles_x, const int tiles_y, const int ntiles)
+{
+    typedef typename LprVec<T>::x8 x8;
+    typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+    typedef __attribute__((address_space(3))) void *lds_ptr;
+    static_assert((CIN == 32 || CIN == 64) && (NBT == 1 || NBT == 2) && NBUF >= 3, "narrow layers only");
+    constexpr int PLANES = CIN / 32, KSTEPS = CIN / 16;
+    constexpr bool SPLITN = CIN * NBT > 64;                   // 64 -> 64: a wave keeps ONE 32-channel block (144 weight registers) ...
+    constexpr int MB = SPLITN ? 2 : 1;                        // ... for both column halves of its row pair; otherwise one row block,
+    constexpr int NB = SPLITN ? 1 : NBT;                      // every channel block
+    constexpr int TILE_BYTES = PLANES * LPR::PLANE_BYTES;
+    constexpr int TILE_LOADS = PLANES * LPR::PLANE_LOADS;
+    constexpr int DMA_ITERS = (TILE_LOADS + 7) / 8;
+    constexpr int LEAD = NBUF - 1;
+    constexpr int TROW = LPR::TROW;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int li = lane & 31, lh = lane >> 5;
+    const int rp = wave >> 1;                                 // row pair of the tile: image rows y0 + 2 rp, + 1
+    const int ch0 = SPLITN ? 0 : (wave & 1);                  // first 16-column half
+    const int blk0 = SPLITN ? (wave & 1) : 0;                 // first 32-channel block
+    T *const Ts = reinterpret_cast<T *>(smem + NBUF * TILE_BYTES + wave * LPR::SCR_BYTES);
+    T *const Ps = Ts + 32 * TROW;
+
+    // ---- the layer's weights, as MFMA B fragments: lane (li, lh) holds w[tap][16 ks + 8 lh .. + 8][32 (blk0 + j) + li]
+    const T *const wpk = reinterpret_cast<const T *>(a.wpk);
+    x8 wreg[9][KSTEPS][NB];
+    float bias[NB];
+#pragma unroll
+    for (int j = 0; j < NB; ++j) {
+        const int n = 32 * (blk0 + j) + li;
+        bias[j] = a.bias[n];
+#pragma unroll
+        for (int tap = 0; tap < 9; ++tap)
+#pragma unroll
+            for (int ks = 0; ks < KSTEPS; ++ks)
+                wreg[tap][ks][j] = *reinterpret_cast<const x8 *>(wpk + ((size_t)((ks >> 1) * 9 + tap) * a.CoutPad + n) * KC_BF16 + 16 * (ks & 1) + 8 * lh);
+    }
+
+    // ---- per-lane LDS byte offsets of the A fragments inside a plane: pixel p = row block's (row li >> 4, column li & 15)
+    // displaced by the tap; 16-byte piece q = 2 g + lh sits in slot q ^ ((p >> 1) & 3)
+    unsigned aoff[9][2];
+#pragma unroll
+    for (int tap = 0; tap < 9; ++tap) {
+        const int dy = tap / 3, dx = tap - 3 * dy;
+        const int p = (2 * rp + (li >> 4) + dy) * LPR::PW + 16 * ch0 + (li & 15) + dx;
+#pragma unroll
+        for (int g = 0; g < 2; ++g) aoff[tap][g] = (unsigned)(p * 64 + (((2 * g + lh) ^ ((p >> 1) & 3)) << 4));
+    }
+
+    // ---- per-lane global byte offsets of this wave's patch loads, relative to the patch origin (y0 - 1, x0 - 1): load i =
+    // wave + 8 k covers pixels 16 (i % 22) .. + 16 of plane i / 22, lane l = (pixel l >> 2, slot l & 3)
+    unsigned dvoff[DMA_ITERS];
+#pragma unroll
+    for (int k = 0; k < DMA_ITERS; ++k) {
+        const int i = wave + 8 * k, c = i / LPR::PLANE_LOADS, j = i - c * LPR::PLANE_LOADS;
+        const int p = 16 * j + (lane >> 2), q = (lane & 3) ^ ((p >> 1) & 3);
+        const int py = p / LPR::PW, px = p - py * LPR::PW;
+        dvoff[k] = (i < TILE_LOADS && p < LPR::NPIX) ? (unsigned)(((py * a.W + px) * a.ldc + 32 * c + 8 * q) * 2) : 0xFFFFFFFFu;
+    }
+    const int my_loads = (TILE_LOADS - wave + 7) / 8;        // loads this wave issues per tile
+
+    // ---- per-lane byte offsets of the 16-byte output pieces, relative to the tile origin: piece e = lane + 64 it of the
+    // [32 pixels][4 pieces] tile of row block mb, channel block j
+    unsigned ovoff[MB][NB][2], pvoff[MB][NB];
+    const int Hp = a.H >> 1, Wp = a.W >> 1;
+    const bool do_pool = a.pool_out != nullptr;
+#pragma unroll
+    for (int mb = 0; mb < MB; ++mb)
+#pragma unroll
+        for (int j = 0; j < NB; ++j) {
+#pragma unroll
+            for (int it = 0; it < 2; ++it) {
+                const int e = lane + 64 * it, m = e >> 2, q = e & 3;
+                ovoff[mb][j][it] = (unsigned)((((2 * rp + (m >> 4)) * a.W + 16 * (ch0 + mb) + (m & 15)) * a.ldo + a.co_off + 32 * (blk0 + j) + 8 * q) * 2);
+            }
+            const int m = lane >> 2, q = lane & 3;           // pooled: row rp, columns 8 (ch0 + mb) + m, lanes 0..31
+            pvoff[mb][j] = lane < 32 ? (unsigned)(((rp * Wp + 8 * (ch0 + mb) + m) * a.pool_ld + 32 * (blk0 + j) + 8 * q) * 2) : 0xFFFFFFFFu;
+        }
+    const float relu_lo = a.relu ? 0.f : -3.402823466e+38f;
+
+    // ---- this workgroup's tiles: its XCD's logical range (blocks b and b + 8 share an XCD), walked with a stride, so the
+    // 32 CUs of an XCD work on neighbouring tiles at any time and share their halos through that XCD's L2
+    const int G = gridDim.x, xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+    const int slots = (G >> 3) + (xcd < (G & 7) ? 1 : 0);
+    const int q_ = ntiles >> 3, r_ = ntiles & 7;
+    const int t_start = (xcd < r_) ? xcd * (q_ + 1) : r_ * (q_ + 1) + (xcd - r_) * q_;
+    const int t_count = q_ + (xcd < r_ ? 1 : 0);
+    const int nt = slot < t_count ? (t_count - slot + slots - 1) / slots : 0;
+    const T *const in = reinterpret_cast<const T *>(a.in);
+
+    auto issue_dma = [&](const int n) {       // the patch of this workgroup's n-th tile -> ring slot n % NBUF
+        int L = t_start + slot + n * slots;
+        const int tx = L % tiles_x; L /= tiles_x;
+        const int ty = L % tiles_y;
+        const int b = L / tiles_y;
+        const int y0 = ty * LPR::TH, x0 = tx * 32;
+        const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(
+            const_cast<T *>(in + (size_t)b * a.H * a.W * a.ldc), 0, a.H * a.W * a.ldc * 2, 0x00020000);
+        char *const dst = smem + (n % NBUF) * TILE_BYTES;
+        if (y0 >= 1 && y0 + LPR::TH + 1 <= a.H && x0 >= 1 && x0 + 33 <= a.W) {
+            // interior: the precomputed offsets, the patch origin in the scalar offset (dead lanes keep 0xFFFFFFFF: the range
+            // check looks at the vector offset only and returns zeros)
+            const unsigned org = (unsigned)((((y0 - 1) * a.W + x0 - 1) * a.ldc) * 2);
+#pragma unroll
+            for (int k = 0; k < DMA_ITERS; ++k)
+                if (wave + 8 * k < TILE_LOADS) {
+                    const unsigned voff = dvoff[k];       // (a prvalue: hipcc's host pass silently drops the kernel when the array element is passed directly)
+                    __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lds_ptr)(dst + (wave + 8 * k) * 1024), 16, voff, org, 0, 0);
+                }
+        } else {                              // a tile on the image border: zero padding through the range check
+#pragma unroll
+            for (int k = 0; k < DMA_ITERS; ++k) {
+                const int i = wave + 8 * k, c = i / LPR::PLANE_LOADS, j = i - c * LPR::PLANE_LOADS;
+                const int p = 16 * j + (lane >> 2), q = (lane & 3) ^ ((p >> 1) & 3);
+                const int py = p / LPR::PW, px = p - py * LPR::PW;
+                const int gy = y0 - 1 + py, gx = x0 - 1 + px;
+                const bool inb = p < LPR::NPIX && gy >= 0 && gy < a.H && gx >= 0 && gx < a.W;
+                const unsigned voff = inb ? (unsigned)(((gy * a.W + gx) * a.ldc + 32 * c + 8 * q) * 2) : 0xFFFFFFFFu;
+                if (i < TILE_LOADS)
+                    __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lds_ptr)(dst + i * 1024), 16, voff, 0, 0, 0);
+            }
+        }
+    };
+
+    if (nt == 0) return;
+#pragma unroll
+    for (int n = 0; n < LEAD; ++n)
+        if (n < nt) issue_dma(n);
+    // tile 0 has landed when at most the loads of tiles 1 .. LEAD - 1 are outstanding
+    {
+        int later = 0;
+#pragma unroll
+        for (int n = 1; n < LEAD; ++n) later += (n < nt) ? my_loads : 0;
+        lpr_wait_vm_n(later);
+    }
+
+    for (int n = 0; n < nt; ++n) {
+        __syncthreads();                      // tile n is complete in LDS (every wave waited for its share); tile n - 1 is consumed
+        if (n + LEAD < nt) issue_dma(n + LEAD);               // ... into the slot tile n - 1 just left
+
+        // ---- tile n: 9 taps x Cin / 16 MFMAs per row block and channel block
+        const unsigned base = (unsigned)((n % NBUF) * TILE_BYTES);
+        f32x16 acc[MB][NB];
+#pragma unroll
+        for (int mb = 0; mb < MB; ++mb)
+#pragma unroll
+            for (int j = 0; j < NB; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[mb][j][r] = 0.f;
+#pragma unroll
+        for (int c = 0; c < PLANES; ++c)
+#pragma unroll
+            for (int tap = 0; tap < 9; ++tap)
+#pragma unroll
+                for (int g = 0; g < 2; ++g) {
+                    x8 af[MB];
+#pragma unroll
+                    for (int mb = 0; mb < MB; ++mb)
+                        af[mb] = *reinterpret_cast<const x8 *>(smem + (base + aoff[tap][g]) + c * LPR::PLANE_BYTES + mb * 1024);
+#pragma unroll
+                    for (int mb = 0; mb < MB; ++mb)
+#pragma unroll
+                        for (int j = 0; j < NB; ++j) acc[mb][j] = mfma_lpr(af[mb], wreg[tap][2 * c + g][j], acc[mb][j]);
+                }
+
+        // ---- this wave's loads of tile n + 1 (older than everything it issued for tiles n + 2 .. n + LEAD)
+        {
+            int later = 0;
+#pragma unroll
+            for (int d = 2; d <= LEAD; ++d) later += (n + d < nt) ? my_loads : 0;
+            lpr_wait_vm_n(later);
+        }
+
+        // ---- epilogue: + shift, ReLU, one rounding to 16 bits, [pixel][channel] tile in this wave's LDS scratch, 16-byte stores
+        int L = t_start + slot + n * slots;
+        const int tx = L % tiles_x; L /= tiles_x;
+        const int ty = L % tiles_y;
+        const int b = L / tiles_y;
+        const int y0 = ty * LPR::TH, x0 = tx * 32;
+        const __amdgpu_buffer_rsrc_t out_rsrc = __builtin_amdgcn_make_buffer_rsrc(
+            reinterpret_cast<T *>(a.out) + (size_t)b * a.H * a.W * a.ldo, 0, a.H * a.W * a.ldo * 2, 0x00020000);
+        const __amdgpu_buffer_rsrc_t pool_rsrc = __builtin_amdgcn_make_buffer_rsrc(
+            do_pool ? reinterpret_cast<T *>(a.pool_out) + (size_t)b * Hp * Wp * a.pool_ld : reinterpret_cast<T *>(a.out), 0,
+            do_pool ? Hp * Wp * a.pool_ld * 2 : 0, 0x00020000);
+        const unsigned osoff = (unsigned)(((y0 * a.W + x0) * a.ldo) * 2);
+        const unsigned psoff = (unsigned)((((y0 >> 1) * Wp + (x0 >> 1)) * a.pool_ld) * 2);
+        const bool edge = y0 + LPR::TH > a.H || x0 + 32 > a.W;
+#pragma unroll
+        for (int mb = 0; mb < MB; ++mb)
+#pragma unroll
+            for (int j = 0; j < NB; ++j) {
+                // accumulator register r = pixel m = (r & 3) + 8 (r >> 2) + 4 lh of the row block: row m >> 4, column m & 15
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int m = (r & 3) + 8 * (r >> 2) + 4 * lh;
+                    Ts[m * TROW + li] = (T)fmaxf(acc[mb][j][r] + bias[j], relu_lo);
+                }
+                if (do_pool) {                // the 2 x 2 block of (r, r+1, r+8, r+9), r even < 8: pooled column (m & 15) >> 1
+#pragma unroll
+                    for (int r = 0; r < 8; r += 2) {
+                        const float mx = fmaxf(fmaxf(acc[mb][j][r], acc[mb][j][r + 1]), fmaxf(acc[mb][j][r + 8], acc[mb][j][r + 9]));
+                        Ps[(((r & 3) >> 1) + 4 * (r >> 2) + 2 * lh) * TROW + li] = (T)fmaxf(mx + bias[j], relu_lo);
+                    }
+                }
+#pragma unroll
+                for (int it = 0; it < 2; ++it) {
+                    const int e = lane + 64 * it, m = e >> 2, q = e & 3;
+                    const u32x4 v = *reinterpret_cast<const u32x4 *>(Ts + m * TROW + 8 * q);
+                    unsigned voff = ovoff[mb][j][it];
+                    if (edge && !(y0 + 2 * rp + (m >> 4) < a.H && x0 + 16 * (ch0 + mb) + (m & 15) < a.W)) voff = 0xFFFFFFFFu;
+                    __builtin_amdgcn_raw_buffer_store_b128(v, out_rsrc, voff, osoff, 0);
+                }
+                if (do_pool) {
+                    const int m = (lane >> 2) & 7, q = lane & 3;
+                    const u32x4 v = *reinterpret_cast<const u32x4 *>(Ps + m * TROW + 8 * q);
+                    unsigned voff = pvoff[mb][j];
+                    if (edge && !(y0 + 2 * rp + 1 < a.H && x0 + 16 * (ch0 + mb) + 2 * m + 1 < a.W)) voff = 0xFFFFFFFFu;
+                    __builtin_amdgcn_raw_buffer_store_b128(v, pool_rsrc, voff, psoff, 0);
+                }
+            }
+    }
+}
+
+static int lpr_cus()
+{
+    static int cus[64] = {};
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return 256;
+    if (cus[dev] == 0) {
+        hipDeviceProp_t p;
+        cus[dev] = (hipGetDeviceProperties(&p, dev) == hipSuccess && p.multiProcessorCount > 0) ? p.multiProcessorCount : 256;
+    }
+    return cus[dev];
+}
+
+template <typename T, int CIN, int NBT, int NBUF>
+static hipError_t launch_lpr_cfg(const ConvArgs &a, hipStream_t s)
+{
+    const int tiles_x = (a.W + 31) / 32, tiles_y = (a.H + LPR::TH - 1) / LPR::TH;
+    const int ntiles = tiles_x * tiles_y * a.B;
+    const int grid = ntiles < lpr_cus() ? ntiles : lpr_cus();
+    constexpr size_t lds = LPR::lds_bytes(CIN, NBUF);
+    auto kern = conv3x3_lpr<T, CIN, NBT, NBUF>;
+    if (hipError_t e = ensure_dynamic_lds(kern, lds); e != hipSuccess) return e;
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(512), lds, s, a, tiles_x, tiles_y, ntiles);
+    return hipGetLastError();
+}
+
+static bool lpr_shape_ok(const ConvArgs &a)
+{
+    if (a.head_w != nullptr || !a.out_lp || a.wpk == nullptr) return false;
+    if ((a.Cin != 32 && a.Cin != 64) || (a.Cout != 32 && a.Cout != 64)) return false;
+    if (a.ldc % 8 || a.ldo % 8 || a.co_off % 8 || a.CoutPad < a.Cout) return false;
+    if (a.pool_out != nullptr && (a.pool_ld % 8 || (a.H & 1) || (a.W & 1))) return false;
+    // 32-bit byte offsets inside one image
+    return (long long)a.H * a.W * a.ldc * 2 < (1ll << 31) && (long long)a.H * a.W * a.ldo * 2 < (1ll << 31);
+}
+
+// MIUNET_LPR = 0: never; 1 (default): the shapes above when the tiles fill the chip four times over; 2: whatever the grid
+// (parity tests on small inputs)
+bool conv3x3_lpr_takes(const ConvArgs &a)
+{
+    const char *e = getenv("MIUNET_LPR");
+    const int mode = e ? atoi(e) : 1;
+    if (mode == 0 || !lpr_shape_ok(a)) return false;
+    const long long ntiles = (long long)((a.W + 31) / 32) * ((a.H + LPR::TH - 1) / LPR::TH) * a.B;
+    return mode == 2 || ntiles >= 4 * lpr_cus();
+}
+
+template <typename T>
+static hipError_t launch_lpr(const ConvArgs &a, hipStream_t s)
+{
+    if (a.Cin == 32) return a.Cout == 32 ? launch_lpr_cfg<T, 32, 1, 4>(a, s) : launch_lpr_cfg<T, 32, 2, 4>(a, s);
+    return a.Cout == 32 ? launch_lpr_cfg<T, 64, 1, 3>(a, s) : launch_lpr_cfg<T, 64, 2, 3>(a, s);
+}
+
+hipError_t launch_conv3x3_lpr(const ConvArgs &a, bool fp16, hipStream_t s)
+{
+    if (!lpr_shape_ok(a)) return hipErrorInvalidValue;
+    return fp16 ? launch_lpr<_Float16>(a, s) : launch_lpr<__bf16>(a, s);
+}
+
+}  // namespace miunet

@@ -91,6 +91,10 @@ hipError_t launch_convT2x2_fp16(const ConvArgs &a, hipStream_t s);
 // per MFMA.  Same packing (a.wpk), same arithmetic; conv3x3_lp2_takes says whether the layer's grid fills the chip.
 bool conv3x3_lp2_takes(const ConvArgs &a);
 hipError_t launch_conv3x3_lp2(const ConvArgs &a, bool fp16, hipStream_t s);
+// The narrow layers (Cin, Cout in {32, 64}, 16-bit output, no fused head) with the weights resident in registers and a
+// persistent workgroup per CU streaming input patches through an LDS ring (conv_lpr.hip).  Same packing, same arithmetic.
+bool conv3x3_lpr_takes(const ConvArgs &a);
+hipError_t launch_conv3x3_lpr(const ConvArgs &a, bool fp16, hipStream_t s);
 
 // First layer: u8 image -> (LUT /255) -> conv3x3 (Cin = 1..4) + shift + ReLU.  w is [9][Cin][Cout] (BN scale folded).
 // out_kind: 0 = fp32 output, 1 = bf16, 2 = fp16 (the 16-bit pipelines keep every activation tensor 16-bit in HBM)

@@ -377,7 +377,7 @@ def layer_debug(op, x, w=None, scale=None, shift=None, relu=False, device=0):
     full_op = op
     if op.endswith("_lpout"):         # 16-bit conv ops: the output tensor is 16-bit on the device too (converted back here)
         op = op[:-6]
-    if op in ("conv3x3", "conv3x3_wino", "conv3x3_wino16", "conv3x3_wino4", "conv3x3_wino4s", "conv3x3_bf16", "conv3x3_fp16", "conv3x3_bf16w", "conv3x3_fp16w"):
+    if op in ("conv3x3", "conv3x3_wino", "conv3x3_wino16", "conv3x3_wino4", "conv3x3_wino4s", "conv3x3_bf16", "conv3x3_fp16", "conv3x3_bf16w", "conv3x3_fp16w", "conv3x3_bf16r", "conv3x3_fp16r"):
         w = np.ascontiguousarray(w, np.float32)
         cout = w.shape[0]
         out = np.empty((b, h, ww, cout), np.float32)
