@@ -48,7 +48,12 @@ struct LPR {
     static constexpr int PLANE_BYTES = PLANE_LOADS * 1024;
     static constexpr int TROW = 40;                               // 16-bit elements per pixel of the output tile (32 + 8 pad)
     static constexpr int SCR_BYTES = (32 + 8) * TROW * 2;         // per wave: [32 pixels][TROW] + pooled [8][TROW]
-    static constexpr size_t lds_bytes(int cin, int nbuf) { return (size_t)nbuf * (cin / 32) * PLANE_BYTES + 8 * SCR_BYTES; }
+    static constexpr int HEAD_ROW = 32 + 4;                       // floats per pixel of the fused head's tile (conflict-free b128 rows)
+    static constexpr int HEAD_SCR_BYTES = 32 * HEAD_ROW * 4;      // per wave: [32 pixels][HEAD_ROW] fp32
+    static constexpr size_t lds_bytes(int cin, int nbuf, bool head)
+    {
+        return (size_t)nbuf * (cin / 32) * PLANE_BYTES + 8 * (head ? HEAD_SCR_BYTES : SCR_BYTES);
+    }
 };
 
 template <int N> __device__ __forceinline__ void lpr_wait_vm()
@@ -71,13 +76,18 @@ __device__ __forceinline__ void lpr_wait_vm_n(int n)      // uniform n
 }
 
 // CIN = 32 or 64 input channels (exactly), NBT = 1 or 2 blocks of 32 output channels (Cout = 32 NBT exactly), NBUF = patch ring
-template <typename T, int CIN, int NBT, int NBUF>
+// HEAD (Cout = 32, at most three classes): the layer feeds the network's fp32 1x1 head + argmax (ConvArgs::head_w).  The
+// post-ReLU fp32 row block crosses the wave's LDS scratch, lane = pixel, the head's weights stay in registers (96), the sums
+// run in the order of conv_mfma_bf16's fused head (four interleaved partial sums per class, folded at the end): the same
+// logits bit for bit.  `out` is never written.
+template <typename T, int CIN, int NBT, int NBUF, bool HEAD = false>
 __global__ __launch_bounds__(512, 1) void conv3x3_lpr(const ConvArgs a, const int tiles_x, const int tiles_y, const int ntiles)
 {
     typedef typename LprVec<T>::x8 x8;
     typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
     typedef __attribute__((address_space(3))) void *lds_ptr;
     static_assert((CIN == 32 || CIN == 64) && (NBT == 1 || NBT == 2) && NBUF >= 3, "narrow layers only");
+    static_assert(!HEAD || NBT == 1, "the fused head needs every channel of a pixel in one wave");
     constexpr int PLANES = CIN / 32, KSTEPS = CIN / 16;
     constexpr bool SPLITN = CIN * NBT > 64;                   // 64 -> 64: a wave keeps ONE 32-channel block (144 weight registers) ...
     constexpr int MB = SPLITN ? 2 : 1;                        // ... for both column halves of its row pair; otherwise one row block,
@@ -95,8 +105,9 @@ __global__ __launch_bounds__(512, 1) void conv3x3_lpr(const ConvArgs a, const in
     const int rp = wave >> 1;                                 // row pair of the tile: image rows y0 + 2 rp, + 1
     const int ch0 = SPLITN ? 0 : (wave & 1);                  // first 16-column half
     const int blk0 = SPLITN ? (wave & 1) : 0;                 // first 32-channel block
-    T *const Ts = reinterpret_cast<T *>(smem + NBUF * TILE_BYTES + wave * LPR::SCR_BYTES);
+    T *const Ts = reinterpret_cast<T *>(smem + NBUF * TILE_BYTES + wave * (HEAD ? LPR::HEAD_SCR_BYTES : LPR::SCR_BYTES));
     T *const Ps = Ts + 32 * TROW;
+    float *const Ys = reinterpret_cast<float *>(Ts);          // HEAD: [32 pixels][HEAD_ROW] fp32
 
     // ---- the layer's weights, as MFMA B fragments: lane (li, lh) holds w[tap][16 ks + 8 lh .. + 8][32 (blk0 + j) + li]
     const T *const wpk = reinterpret_cast<const T *>(a.wpk);
@@ -154,6 +165,17 @@ __global__ __launch_bounds__(512, 1) void conv3x3_lpr(const ConvArgs a, const in
             pvoff[mb][j] = lane < 32 ? (unsigned)(((rp * Wp + 8 * (ch0 + mb) + m) * a.pool_ld + 32 * (blk0 + j) + 8 * q) * 2) : 0xFFFFFFFFu;
         }
     const float relu_lo = a.relu ? 0.f : -3.402823466e+38f;
+    f32x4 wh[HEAD ? 3 : 1][8];                                // HEAD: head_w[k][4 c4 .. + 4], classes past head_classes = 0
+    float hb[3] = { 0.f, 0.f, 0.f };
+    if constexpr (HEAD) {
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            if (k < a.head_classes) hb[k] = a.head_b[k];
+#pragma unroll
+            for (int c4 = 0; c4 < 8; ++c4)
+                wh[k][c4] = k < a.head_classes ? *reinterpret_cast<const f32x4 *>(a.head_w + k * 32 + 4 * c4) : f32x4{ 0.f, 0.f, 0.f, 0.f };
+        }
+    }
 
     // ---- this workgroup's tiles: its XCD's logical range (blocks b and b + 8 share an XCD), walked with a stride, so the
     // 32 CUs of an XCD work on neighbouring tiles at any time and share their halos through that XCD's L2
@@ -267,6 +289,40 @@ __global__ __launch_bounds__(512, 1) void conv3x3_lpr(const ConvArgs a, const in
 #pragma unroll
             for (int j = 0; j < NB; ++j) {
                 // accumulator register r = pixel m = (r & 3) + 8 (r >> 2) + 4 lh of the row block: row m >> 4, column m & 15
+                if constexpr (HEAD) {
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const int m = (r & 3) + 8 * (r >> 2) + 4 * lh;
+                        Ys[m * LPR::HEAD_ROW + li] = fmaxf(acc[mb][j][r] + bias[j], relu_lo);
+                    }
+                    // lane = pixel (lanes 32..63 repeat 0..31 and store nothing); first maximum wins (src/process.cpp:158-170)
+                    const int m = lane & 31;
+                    f32x4 d4[3];
+#pragma unroll
+                    for (int k = 0; k < 3; ++k) d4[k] = f32x4{ 0.f, 0.f, 0.f, 0.f };
+#pragma unroll
+                    for (int c4 = 0; c4 < 8; ++c4) {
+                        const f32x4 yv = *reinterpret_cast<const f32x4 *>(Ys + m * LPR::HEAD_ROW + 4 * c4);
+#pragma unroll
+                        for (int k = 0; k < 3; ++k) d4[k] += yv * wh[k][c4];
+                    }
+                    const int py = y0 + 2 * rp + (m >> 4), px = x0 + 16 * (ch0 + mb) + (m & 15);
+                    if (lane < 32 && py < a.H && px < a.W) {
+                        const size_t hw = (size_t)a.H * a.W, pin = (size_t)py * a.W + px;
+                        float best = -3.402823466e+38f;
+                        int idx = 0;
+#pragma unroll
+                        for (int k = 0; k < 3; ++k) {
+                            if (k < a.head_classes) {
+                                const float d = ((d4[k].x + d4[k].y) + (d4[k].z + d4[k].w)) + hb[k];
+                                if (a.head_logits != nullptr) a.head_logits[((size_t)b * a.head_classes + k) * hw + pin] = d;
+                                if (d > best) { best = d; idx = k; }
+                            }
+                        }
+                        a.head_labels[(size_t)b * hw + pin] = (uint8_t)idx;
+                    }
+                    continue;
+                }
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
                     const int m = (r & 3) + 8 * (r >> 2) + 4 * lh;
@@ -310,14 +366,14 @@ static int lpr_cus()
     return cus[dev];
 }
 
-template <typename T, int CIN, int NBT, int NBUF>
+template <typename T, int CIN, int NBT, int NBUF, bool HEAD = false>
 static hipError_t launch_lpr_cfg(const ConvArgs &a, hipStream_t s)
 {
     const int tiles_x = (a.W + 31) / 32, tiles_y = (a.H + LPR::TH - 1) / LPR::TH;
     const int ntiles = tiles_x * tiles_y * a.B;
     const int grid = ntiles < lpr_cus() ? ntiles : lpr_cus();
-    constexpr size_t lds = LPR::lds_bytes(CIN, NBUF);
-    auto kern = conv3x3_lpr<T, CIN, NBT, NBUF>;
+    constexpr size_t lds = LPR::lds_bytes(CIN, NBUF, HEAD);
+    auto kern = conv3x3_lpr<T, CIN, NBT, NBUF, HEAD>;
     if (hipError_t e = ensure_dynamic_lds(kern, lds); e != hipSuccess) return e;
     hipLaunchKernelGGL(kern, dim3(grid), dim3(512), lds, s, a, tiles_x, tiles_y, ntiles);
     return hipGetLastError();
@@ -325,7 +381,14 @@ static hipError_t launch_lpr_cfg(const ConvArgs &a, hipStream_t s)
 
 static bool lpr_shape_ok(const ConvArgs &a)
 {
-    if (a.head_w != nullptr || !a.out_lp || a.wpk == nullptr) return false;
+    if (a.wpk == nullptr) return false;
+    if (a.head_w != nullptr) {                // fused head: 32 -> 32 channels, at most three classes, fp32 tile (never stored), no pooling
+        if (a.Cin != 32 || a.Cout != 32 || a.head_classes < 1 || a.head_classes > 3 || a.out_lp || a.pool_out != nullptr || a.head_labels == nullptr ||
+            a.head_b == nullptr)
+            return false;
+    } else if (!a.out_lp) {
+        return false;
+    }
     if ((a.Cin != 32 && a.Cin != 64) || (a.Cout != 32 && a.Cout != 64)) return false;
     if (a.ldc % 8 || a.ldo % 8 || a.co_off % 8 || a.CoutPad < a.Cout) return false;
     if (a.pool_out != nullptr && (a.pool_ld % 8 || (a.H & 1) || (a.W & 1))) return false;
@@ -347,6 +410,7 @@ bool conv3x3_lpr_takes(const ConvArgs &a)
 template <typename T>
 static hipError_t launch_lpr(const ConvArgs &a, hipStream_t s)
 {
+    if (a.head_w != nullptr) return launch_lpr_cfg<T, 32, 1, 4, true>(a, s);
     if (a.Cin == 32) return a.Cout == 32 ? launch_lpr_cfg<T, 32, 1, 4>(a, s) : launch_lpr_cfg<T, 32, 2, 4>(a, s);
     return a.Cout == 32 ? launch_lpr_cfg<T, 64, 1, 3>(a, s) : launch_lpr_cfg<T, 64, 2, 3>(a, s);
 }

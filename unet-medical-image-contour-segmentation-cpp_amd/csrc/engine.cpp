@@ -582,7 +582,7 @@ int launch_plan(mi_unet *h, const uint8_t *d_imgs, int B, uint8_t *d_labels, flo
                 e = launch_conv3x3_lp2(a, lp_kind == 2, s);
             }
             else if (lp_kind != 0 && conv3x3_lpr_takes(a)) {     // narrow layer: weights in registers, persistent (conv_lpr.hip)
-                kname = lp_kind == 1 ? "conv3x3_bf16r" : "conv3x3_fp16r";
+                kname = lp_kind == 1 ? (head_done ? "conv3x3_bf16r+head" : "conv3x3_bf16r") : (head_done ? "conv3x3_fp16r+head" : "conv3x3_fp16r");
                 e = launch_conv3x3_lpr(a, lp_kind == 2, s);
             }
             else if (h->algo == MI_UNET_CONV_BF16) { kname = head_done ? "conv3x3_bf16+head" : "conv3x3_bf16"; e = launch_conv3x3_bf16(a, s); }
