@@ -244,3 +244,24 @@ def test_resident_weight_kernel_in_the_whole_network(algo, in_ch, levels, monkey
     # inc.c2, down1.c1, down1.c2, the second-level up.c2, the top up.c1 -- and the last conv with the 1x1 head fused
     assert used["0"] == [] and used["2"] == [f"conv3x3_{algo}r"] * 5 + [f"conv3x3_{algo}r+head"]
     assert np.array_equal(out["0"][1], out["2"][1]) and np.array_equal(out["0"][0], out["2"][0])
+
+
+@pytest.mark.parametrize("op,B,H,W,Cin,Cout", [
+    ("conv3x3_fp16", 3, 96, 80, 32, 32),        # 16-row tiles (two row blocks per wave), a 16-column tile column
+    ("conv3x3_bf16", 2, 256, 512, 32, 32),      # 512 tiles: two per persistent workgroup
+    ("conv3x3_bf16", 2, 40, 96, 64, 64),        # 64 -> 64 (8-row tiles)
+    ("conv3x3_fp16", 1, 24, 64, 32, 64),        # 32 -> 64
+])
+def test_conv3x3_resident_weights_fused_pooling(op, B, H, W, Cin, Cout):
+    """The 2 x 2 max pooling fused into the epilogue (in-lane: a row block is 2 rows x 16 columns): the pooled 16-bit tensor
+    equals the one-tile-per-workgroup kernel's bit for bit, and the max pooling of the full-size tensor."""
+    r = np.random.default_rng(11 * B + H + W + Cin + Cout)
+    x = r.standard_normal((B, H, W, Cin), dtype=np.float32)
+    w = (r.standard_normal((Cout, Cin, 3, 3), dtype=np.float32) * np.sqrt(2.0 / (9 * Cin))).astype(np.float32)
+    shift = (0.1 * r.standard_normal(Cout)).astype(np.float32)
+    full = binding.layer_debug(op + "r_lpout", x, w, None, shift, relu=True)
+    for _ in range(3):                        # (a race between waves would not show every time)
+        pooled = binding.layer_debug(op + "r_pool_lpout", x, w, None, shift, relu=True)
+        assert not np.isnan(pooled).any(), "unwritten (NaN-poisoned) pooled outputs"
+        assert np.array_equal(pooled, orc.maxpool2x2(full))
+    assert np.array_equal(pooled, binding.layer_debug(op + "_pool_lpout", x, w, None, shift, relu=True))

@@ -42,17 +42,25 @@ __device__ __forceinline__ f32x16 mfma_lpr(LprVec<_Float16>::x8 a, LprVec<_Float
     return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0);
 }
 
-struct LPR {
-    static constexpr int TH = 8, PW = 34, NPIX = 340;            // (8 + 2) x (32 + 2) pixels per patch
-    static constexpr int PLANE_LOADS = 22;                        // wave-wide LDS-DMA loads per 32-channel plane: 16 pixels each
+// RB = row blocks (2 image rows x 16 columns each) a wave owns per tile: the tile is 8 RB rows x 32 columns.  RB = 2 halves
+// the halo re-read (18 x 34 pixels for 16 x 32 outputs: 1.20 x instead of 1.33 x), the barriers and the per-tile address
+// work per pixel, and gives a wave two independent accumulator chains; it needs a 39 KB patch per 32-channel plane, so it is
+// for the Cin = 32 layers.
+template <int RB>
+struct LprGeom {
+    static constexpr int TH = 8 * RB, PW = 34, PH = TH + 2, NPIX = PW * PH;
+    static constexpr int PLANE_LOADS = (NPIX + 15) / 16;          // wave-wide LDS-DMA loads per 32-channel plane: 16 pixels each
     static constexpr int PLANE_BYTES = PLANE_LOADS * 1024;
+    static constexpr int RB_BYTES = 8 * PW * 64;                  // the next row block of the same wave: 8 patch rows further
+};
+struct LPR {
     static constexpr int TROW = 40;                               // 16-bit elements per pixel of the output tile (32 + 8 pad)
     static constexpr int SCR_BYTES = (32 + 8) * TROW * 2;         // per wave: [32 pixels][TROW] + pooled [8][TROW]
     static constexpr int HEAD_ROW = 32 + 4;                       // floats per pixel of the fused head's tile (conflict-free b128 rows)
     static constexpr int HEAD_SCR_BYTES = 32 * HEAD_ROW * 4;      // per wave: [32 pixels][HEAD_ROW] fp32
-    static constexpr size_t lds_bytes(int cin, int nbuf, bool head)
+    static constexpr size_t lds_bytes(int plane_bytes, int cin, int nbuf, bool head)
     {
-        return (size_t)nbuf * (cin / 32) * PLANE_BYTES + 8 * (head ? HEAD_SCR_BYTES : SCR_BYTES);
+        return (size_t)nbuf * (cin / 32) * plane_bytes + 8 * (head ? HEAD_SCR_BYTES : SCR_BYTES);
     }
 };
 
@@ -64,12 +72,17 @@ __device__ __forceinline__ void lpr_wait_vm_n(int n)      // uniform n
 {
     switch (n) {
     case 0: lpr_wait_vm<0>(); break;
+    case 1: lpr_wait_vm<1>(); break;
     case 2: lpr_wait_vm<2>(); break;
     case 3: lpr_wait_vm<3>(); break;
     case 4: lpr_wait_vm<4>(); break;
     case 5: lpr_wait_vm<5>(); break;
     case 6: lpr_wait_vm<6>(); break;
+    case 7: lpr_wait_vm<7>(); break;
+    case 8: lpr_wait_vm<8>(); break;
+    case 9: lpr_wait_vm<9>(); break;
     case 10: lpr_wait_vm<10>(); break;
+    case 11: lpr_wait_vm<11>(); break;
     case 12: lpr_wait_vm<12>(); break;
     default: lpr_wait_vm<0>(); break;
     }
@@ -80,7 +93,7 @@ __device__ __forceinline__ void lpr_wait_vm_n(int n)      // uniform n
 // post-ReLU fp32 row block crosses the wave's LDS scratch, lane = pixel, the head's weights stay in registers (96), the sums
 // run in the order of conv_mfma_bf16's fused head (four interleaved partial sums per class, folded at the end): the same
 // logits bit for bit.  `out` is never written.
-template <typename T, int CIN, int NBT, int NBUF, bool HEAD = false>
+template <typename T, int CIN, int NBT, int NBUF, int RB, bool HEAD = false>
 __global__ __launch_bounds__(512, 1) void conv3x3_lpr(const ConvArgs a, const int tiles_x, const int tiles_y, const int ntiles)
 {
     typedef typename LprVec<T>::x8 x8;
@@ -88,12 +101,14 @@ __global__ __launch_bounds__(512, 1) void conv3x3_lpr(const ConvArgs a, const in
     typedef __attribute__((address_space(3))) void *lds_ptr;
     static_assert((CIN == 32 || CIN == 64) && (NBT == 1 || NBT == 2) && NBUF >= 3, "narrow layers only");
     static_assert(!HEAD || NBT == 1, "the fused head needs every channel of a pixel in one wave");
+    static_assert(RB == 1 || CIN == 32, "two row blocks per wave: one 32-channel plane only (immediate LDS offsets, LDS size)");
+    using GEO = LprGeom<RB>;
     constexpr int PLANES = CIN / 32, KSTEPS = CIN / 16;
     constexpr bool SPLITN = CIN * NBT > 64;                   // 64 -> 64: a wave keeps ONE 32-channel block (144 weight registers) ...
     constexpr int MB = SPLITN ? 2 : 1;                        // ... for both column halves of its row pair; otherwise one row block,
     constexpr int NB = SPLITN ? 1 : NBT;                      // every channel block
-    constexpr int TILE_BYTES = PLANES * LPR::PLANE_BYTES;
-    constexpr int TILE_LOADS = PLANES * LPR::PLANE_LOADS;
+    constexpr int TILE_BYTES = PLANES * GEO::PLANE_BYTES;
+    constexpr int TILE_LOADS = PLANES * GEO::PLANE_LOADS;
     constexpr int DMA_ITERS = (TILE_LOADS + 7) / 8;
     constexpr int LEAD = NBUF - 1;
     constexpr int TROW = LPR::TROW;
@@ -130,7 +145,7 @@ __global__ __launch_bounds__(512, 1) void conv3x3_lpr(const ConvArgs a, const in
 #pragma unroll
     for (int tap = 0; tap < 9; ++tap) {
         const int dy = tap / 3, dx = tap - 3 * dy;
-        const int p = (2 * rp + (li >> 4) + dy) * LPR::PW + 16 * ch0 + (li & 15) + dx;
+        const int p = (2 * rp + (li >> 4) + dy) * GEO::PW + 16 * ch0 + (li & 15) + dx;
 #pragma unroll
         for (int g = 0; g < 2; ++g) aoff[tap][g] = (unsigned)(p * 64 + (((2 * g + lh) ^ ((p >> 1) & 3)) << 4));
     }
@@ -140,10 +155,10 @@ __global__ __launch_bounds__(512, 1) void conv3x3_lpr(const ConvArgs a, const in
     unsigned dvoff[DMA_ITERS];
 #pragma unroll
     for (int k = 0; k < DMA_ITERS; ++k) {
-        const int i = wave + 8 * k, c = i / LPR::PLANE_LOADS, j = i - c * LPR::PLANE_LOADS;
+        const int i = wave + 8 * k, c = i / GEO::PLANE_LOADS, j = i - c * GEO::PLANE_LOADS;
         const int p = 16 * j + (lane >> 2), q = (lane & 3) ^ ((p >> 1) & 3);
-        const int py = p / LPR::PW, px = p - py * LPR::PW;
-        dvoff[k] = (i < TILE_LOADS && p < LPR::NPIX) ? (unsigned)(((py * a.W + px) * a.ldc + 32 * c + 8 * q) * 2) : 0xFFFFFFFFu;
+        const int py = p / GEO::PW, px = p - py * GEO::PW;
+        dvoff[k] = (i < TILE_LOADS && p < GEO::NPIX) ? (unsigned)(((py * a.W + px) * a.ldc + 32 * c + 8 * q) * 2) : 0xFFFFFFFFu;
     }
     const int my_loads = (TILE_LOADS - wave + 7) / 8;        // loads this wave issues per tile
 
@@ -192,11 +207,11 @@ __global__ __launch_bounds__(512, 1) void conv3x3_lpr(const ConvArgs a, const in
         const int tx = L % tiles_x; L /= tiles_x;
         const int ty = L % tiles_y;
         const int b = L / tiles_y;
-        const int y0 = ty * LPR::TH, x0 = tx * 32;
+        const int y0 = ty * GEO::TH, x0 = tx * 32;
         const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(
             const_cast<T *>(in + (size_t)b * a.H * a.W * a.ldc), 0, a.H * a.W * a.ldc * 2, 0x00020000);
         char *const dst = smem + (n % NBUF) * TILE_BYTES;
-        if (y0 >= 1 && y0 + LPR::TH + 1 <= a.H && x0 >= 1 && x0 + 33 <= a.W) {
+        if (y0 >= 1 && y0 + GEO::TH + 1 <= a.H && x0 >= 1 && x0 + 33 <= a.W) {
             // interior: the precomputed offsets, the patch origin in the scalar offset (dead lanes keep 0xFFFFFFFF: the range
             // check looks at the vector offset only and returns zeros)
             const unsigned org = (unsigned)((((y0 - 1) * a.W + x0 - 1) * a.ldc) * 2);
@@ -209,11 +224,11 @@ __global__ __launch_bounds__(512, 1) void conv3x3_lpr(const ConvArgs a, const in
         } else {                              // a tile on the image border: zero padding through the range check
 #pragma unroll
             for (int k = 0; k < DMA_ITERS; ++k) {
-                const int i = wave + 8 * k, c = i / LPR::PLANE_LOADS, j = i - c * LPR::PLANE_LOADS;
+                const int i = wave + 8 * k, c = i / GEO::PLANE_LOADS, j = i - c * GEO::PLANE_LOADS;
                 const int p = 16 * j + (lane >> 2), q = (lane & 3) ^ ((p >> 1) & 3);
-                const int py = p / LPR::PW, px = p - py * LPR::PW;
+                const int py = p / GEO::PW, px = p - py * GEO::PW;
                 const int gy = y0 - 1 + py, gx = x0 - 1 + px;
-                const bool inb = p < LPR::NPIX && gy >= 0 && gy < a.H && gx >= 0 && gx < a.W;
+                const bool inb = p < GEO::NPIX && gy >= 0 && gy < a.H && gx >= 0 && gx < a.W;
                 const unsigned voff = inb ? (unsigned)(((gy * a.W + gx) * a.ldc + 32 * c + 8 * q) * 2) : 0xFFFFFFFFu;
                 if (i < TILE_LOADS)
                     __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lds_ptr)(dst + i * 1024), 16, voff, 0, 0, 0);
@@ -239,27 +254,33 @@ __global__ __launch_bounds__(512, 1) void conv3x3_lpr(const ConvArgs a, const in
 
         // ---- tile n: 9 taps x Cin / 16 MFMAs per row block and channel block
         const unsigned base = (unsigned)((n % NBUF) * TILE_BYTES);
-        f32x16 acc[MB][NB];
+        f32x16 acc[RB][MB][NB];
 #pragma unroll
-        for (int mb = 0; mb < MB; ++mb)
+        for (int rb = 0; rb < RB; ++rb)
 #pragma unroll
-            for (int j = 0; j < NB; ++j)
+            for (int mb = 0; mb < MB; ++mb)
 #pragma unroll
-                for (int r = 0; r < 16; ++r) acc[mb][j][r] = 0.f;
+                for (int j = 0; j < NB; ++j)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) acc[rb][mb][j][r] = 0.f;
 #pragma unroll
         for (int c = 0; c < PLANES; ++c)
 #pragma unroll
             for (int tap = 0; tap < 9; ++tap)
 #pragma unroll
                 for (int g = 0; g < 2; ++g) {
-                    x8 af[MB];
+                    x8 af[RB][MB];
 #pragma unroll
-                    for (int mb = 0; mb < MB; ++mb)
-                        af[mb] = *reinterpret_cast<const x8 *>(smem + (base + aoff[tap][g]) + c * LPR::PLANE_BYTES + mb * 1024);
+                    for (int rb = 0; rb < RB; ++rb)
 #pragma unroll
-                    for (int mb = 0; mb < MB; ++mb)
+                        for (int mb = 0; mb < MB; ++mb)
+                            af[rb][mb] = *reinterpret_cast<const x8 *>(smem + (base + aoff[tap][g]) + c * GEO::PLANE_BYTES + rb * GEO::RB_BYTES + mb * 1024);
 #pragma unroll
-                        for (int j = 0; j < NB; ++j) acc[mb][j] = mfma_lpr(af[mb], wreg[tap][2 * c + g][j], acc[mb][j]);
+                    for (int rb = 0; rb < RB; ++rb)
+#pragma unroll
+                        for (int mb = 0; mb < MB; ++mb)
+#pragma unroll
+                            for (int j = 0; j < NB; ++j) acc[rb][mb][j] = mfma_lpr(af[rb][mb], wreg[tap][2 * c + g][j], acc[rb][mb][j]);
                 }
 
         // ---- this wave's loads of tile n + 1 (older than everything it issued for tiles n + 2 .. n + LEAD)
@@ -275,7 +296,7 @@ __global__ __launch_bounds__(512, 1) void conv3x3_lpr(const ConvArgs a, const in
         const int tx = L % tiles_x; L /= tiles_x;
         const int ty = L % tiles_y;
         const int b = L / tiles_y;
-        const int y0 = ty * LPR::TH, x0 = tx * 32;
+        const int y0 = ty * GEO::TH, x0 = tx * 32;
         const __amdgpu_buffer_rsrc_t out_rsrc = __builtin_amdgcn_make_buffer_rsrc(
             reinterpret_cast<T *>(a.out) + (size_t)b * a.H * a.W * a.ldo, 0, a.H * a.W * a.ldo * 2, 0x00020000);
         const __amdgpu_buffer_rsrc_t pool_rsrc = __builtin_amdgcn_make_buffer_rsrc(
@@ -283,17 +304,20 @@ __global__ __launch_bounds__(512, 1) void conv3x3_lpr(const ConvArgs a, const in
             do_pool ? Hp * Wp * a.pool_ld * 2 : 0, 0x00020000);
         const unsigned osoff = (unsigned)(((y0 * a.W + x0) * a.ldo) * 2);
         const unsigned psoff = (unsigned)((((y0 >> 1) * Wp + (x0 >> 1)) * a.pool_ld) * 2);
-        const bool edge = y0 + LPR::TH > a.H || x0 + 32 > a.W;
+        const bool edge = y0 + GEO::TH > a.H || x0 + 32 > a.W;
+#pragma unroll
+        for (int rb = 0; rb < RB; ++rb)
 #pragma unroll
         for (int mb = 0; mb < MB; ++mb)
 #pragma unroll
             for (int j = 0; j < NB; ++j) {
+                const int yb = y0 + 8 * rb;                   // first image row of this row block's group of four row pairs
                 // accumulator register r = pixel m = (r & 3) + 8 (r >> 2) + 4 lh of the row block: row m >> 4, column m & 15
                 if constexpr (HEAD) {
 #pragma unroll
                     for (int r = 0; r < 16; ++r) {
                         const int m = (r & 3) + 8 * (r >> 2) + 4 * lh;
-                        Ys[m * LPR::HEAD_ROW + li] = fmaxf(acc[mb][j][r] + bias[j], relu_lo);
+                        Ys[m * LPR::HEAD_ROW + li] = fmaxf(acc[rb][mb][j][r] + bias[j], relu_lo);
                     }
                     // lane = pixel (lanes 32..63 repeat 0..31 and store nothing); first maximum wins (src/process.cpp:158-170)
                     const int m = lane & 31;
@@ -306,7 +330,7 @@ __global__ __launch_bounds__(512, 1) void conv3x3_lpr(const ConvArgs a, const in
 #pragma unroll
                         for (int k = 0; k < 3; ++k) d4[k] += yv * wh[k][c4];
                     }
-                    const int py = y0 + 2 * rp + (m >> 4), px = x0 + 16 * (ch0 + mb) + (m & 15);
+                    const int py = yb + 2 * rp + (m >> 4), px = x0 + 16 * (ch0 + mb) + (m & 15);
                     if (lane < 32 && py < a.H && px < a.W) {
                         const size_t hw = (size_t)a.H * a.W, pin = (size_t)py * a.W + px;
                         float best = -3.402823466e+38f;
@@ -326,12 +350,12 @@ __global__ __launch_bounds__(512, 1) void conv3x3_lpr(const ConvArgs a, const in
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
                     const int m = (r & 3) + 8 * (r >> 2) + 4 * lh;
-                    Ts[m * TROW + li] = (T)fmaxf(acc[mb][j][r] + bias[j], relu_lo);
+                    Ts[m * TROW + li] = (T)fmaxf(acc[rb][mb][j][r] + bias[j], relu_lo);
                 }
                 if (do_pool) {                // the 2 x 2 block of (r, r+1, r+8, r+9), r even < 8: pooled column (m & 15) >> 1
 #pragma unroll
                     for (int r = 0; r < 8; r += 2) {
-                        const float mx = fmaxf(fmaxf(acc[mb][j][r], acc[mb][j][r + 1]), fmaxf(acc[mb][j][r + 8], acc[mb][j][r + 9]));
+                        const float mx = fmaxf(fmaxf(acc[rb][mb][j][r], acc[rb][mb][j][r + 1]), fmaxf(acc[rb][mb][j][r + 8], acc[rb][mb][j][r + 9]));
                         Ps[(((r & 3) >> 1) + 4 * (r >> 2) + 2 * lh) * TROW + li] = (T)fmaxf(mx + bias[j], relu_lo);
                     }
                 }
@@ -340,15 +364,17 @@ __global__ __launch_bounds__(512, 1) void conv3x3_lpr(const ConvArgs a, const in
                     const int e = lane + 64 * it, m = e >> 2, q = e & 3;
                     const u32x4 v = *reinterpret_cast<const u32x4 *>(Ts + m * TROW + 8 * q);
                     unsigned voff = ovoff[mb][j][it];
-                    if (edge && !(y0 + 2 * rp + (m >> 4) < a.H && x0 + 16 * (ch0 + mb) + (m & 15) < a.W)) voff = 0xFFFFFFFFu;
-                    __builtin_amdgcn_raw_buffer_store_b128(v, out_rsrc, voff, osoff, 0);
+                    if (edge && !(yb + 2 * rp + (m >> 4) < a.H && x0 + 16 * (ch0 + mb) + (m & 15) < a.W)) voff = 0xFFFFFFFFu;
+                    __builtin_amdgcn_raw_buffer_store_b128(v, out_rsrc, voff, osoff + (unsigned)(8 * rb * a.W * a.ldo * 2), 0);
+                    wide_store_guard();
                 }
                 if (do_pool) {
                     const int m = (lane >> 2) & 7, q = lane & 3;
                     const u32x4 v = *reinterpret_cast<const u32x4 *>(Ps + m * TROW + 8 * q);
                     unsigned voff = pvoff[mb][j];
-                    if (edge && !(y0 + 2 * rp + 1 < a.H && x0 + 16 * (ch0 + mb) + 2 * m + 1 < a.W)) voff = 0xFFFFFFFFu;
-                    __builtin_amdgcn_raw_buffer_store_b128(v, pool_rsrc, voff, psoff, 0);
+                    if (edge && !(yb + 2 * rp + 1 < a.H && x0 + 16 * (ch0 + mb) + 2 * m + 1 < a.W)) voff = 0xFFFFFFFFu;
+                    __builtin_amdgcn_raw_buffer_store_b128(v, pool_rsrc, voff, psoff + (unsigned)(4 * rb * Wp * a.pool_ld * 2), 0);
+                    wide_store_guard();
                 }
             }
     }
@@ -366,14 +392,16 @@ static int lpr_cus()
     return cus[dev];
 }
 
-template <typename T, int CIN, int NBT, int NBUF, bool HEAD = false>
+template <typename T, int CIN, int NBT, int NBUF, int RB, bool HEAD = false>
 static hipError_t launch_lpr_cfg(const ConvArgs &a, hipStream_t s)
 {
-    const int tiles_x = (a.W + 31) / 32, tiles_y = (a.H + LPR::TH - 1) / LPR::TH;
+    using GEO = LprGeom<RB>;
+    const int tiles_x = (a.W + 31) / 32, tiles_y = (a.H + GEO::TH - 1) / GEO::TH;
     const int ntiles = tiles_x * tiles_y * a.B;
     const int grid = ntiles < lpr_cus() ? ntiles : lpr_cus();
-    constexpr size_t lds = LPR::lds_bytes(CIN, NBUF, HEAD);
-    auto kern = conv3x3_lpr<T, CIN, NBT, NBUF, HEAD>;
+    constexpr size_t lds = LPR::lds_bytes(GEO::PLANE_BYTES, CIN, NBUF, HEAD);
+    static_assert(lds <= 160 * 1024, "LDS of one CU");
+    auto kern = conv3x3_lpr<T, CIN, NBT, NBUF, RB, HEAD>;
     if (hipError_t e = ensure_dynamic_lds(kern, lds); e != hipSuccess) return e;
     hipLaunchKernelGGL(kern, dim3(grid), dim3(512), lds, s, a, tiles_x, tiles_y, ntiles);
     return hipGetLastError();
@@ -403,16 +431,24 @@ bool conv3x3_lpr_takes(const ConvArgs &a)
     const char *e = getenv("MIUNET_LPR");
     const int mode = e ? atoi(e) : 1;
     if (mode == 0 || !lpr_shape_ok(a)) return false;
-    const long long ntiles = (long long)((a.W + 31) / 32) * ((a.H + LPR::TH - 1) / LPR::TH) * a.B;
+    const long long ntiles = (long long)((a.W + 31) / 32) * ((a.H + 15) / 16) * a.B;     // 16-row tiles (Cin = 32); twice as many of 8 rows
     return mode == 2 || ntiles >= 4 * lpr_cus();
 }
 
 template <typename T>
 static hipError_t launch_lpr(const ConvArgs &a, hipStream_t s)
 {
-    if (a.head_w != nullptr) return launch_lpr_cfg<T, 32, 1, 4, true>(a, s);
-    if (a.Cin == 32) return a.Cout == 32 ? launch_lpr_cfg<T, 32, 1, 4>(a, s) : launch_lpr_cfg<T, 32, 2, 4>(a, s);
-    return a.Cout == 32 ? launch_lpr_cfg<T, 64, 1, 3>(a, s) : launch_lpr_cfg<T, 64, 2, 3>(a, s);
+    const char *rb_e = getenv("MIUNET_LPR_RB");             // 1: 8-row tiles for every shape (A/B, parity tests)
+    const int rb_env = rb_e ? atoi(rb_e) : 2;
+    if (rb_env == 2) {
+        if (a.head_w != nullptr) return launch_lpr_cfg<T, 32, 1, 3, 2, true>(a, s);
+        if (a.Cin == 32 && a.Cout == 32) return launch_lpr_cfg<T, 32, 1, 3, 2>(a, s);
+        if (a.Cin == 32) return launch_lpr_cfg<T, 32, 2, 4, 1>(a, s);      // 32 -> 64 with two row blocks spills (144 weight + 64 accumulator registers)
+    } else {
+        if (a.head_w != nullptr) return launch_lpr_cfg<T, 32, 1, 4, 1, true>(a, s);
+        if (a.Cin == 32) return a.Cout == 32 ? launch_lpr_cfg<T, 32, 1, 4, 1>(a, s) : launch_lpr_cfg<T, 32, 2, 4, 1>(a, s);
+    }
+    return a.Cout == 32 ? launch_lpr_cfg<T, 64, 1, 3, 1>(a, s) : launch_lpr_cfg<T, 64, 2, 3, 1>(a, s);
 }
 
 hipError_t launch_conv3x3_lpr(const ConvArgs &a, bool fp16, hipStream_t s)

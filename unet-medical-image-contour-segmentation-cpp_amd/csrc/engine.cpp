@@ -1146,6 +1146,9 @@ int mi_unet_layer_debug(int device, const char *op, const float *in, int B, int 
     std::string o(op);
     bool lp_out = false;
     if (o.size() > 6 && o.compare(o.size() - 6, 6, "_lpout") == 0) { lp_out = true; o.resize(o.size() - 6); }
+    bool want_pool = false;                    // "<conv op>_pool": return the fused 2x2 max-pooled tensor [B][H/2][W/2][Cout] instead
+    if (o.size() > 5 && o.compare(o.size() - 5, 5, "_pool") == 0) { want_pool = true; o.resize(o.size() - 5); }
+    float *d_pool = nullptr;
     const size_t in_n = (size_t)B * H * W * Cin;
     float *d_in = nullptr, *d_out = nullptr, *d_w = nullptr, *d_b = nullptr;
     std::vector<float> wpk, bias;
@@ -1248,6 +1251,12 @@ int mi_unet_layer_debug(int device, const char *op, const float *in, int B, int 
         DBG_TRY(hipMemcpy(d_in, in, sizeof(float) * in_n, hipMemcpyHostToDevice));
     }
     DBG_TRY(hipMemset(d_out, 0xFF, sizeof(float) * out_n));      // NaN poison: unwritten outputs are visible
+    if (want_pool) {
+        if (wpk.empty() || (H & 1) || (W & 1) || out_n != (size_t)B * H * W * Cout) { rc = fail(MI_UNET_EARG, "layer_debug: _pool is for the conv3x3 ops on even sizes"); goto done; }
+        DBG_TRY(hipMalloc(&d_pool, sizeof(float) * out_n / 4));
+        DBG_TRY(hipMemset(d_pool, 0xFF, sizeof(float) * out_n / 4));
+        a.pool_out = d_pool; a.pool_ld = Cout;
+    }
     if (!wpk.empty()) {
         DBG_TRY(hipMalloc(&d_w, sizeof(float) * wpk.size()));
         DBG_TRY(hipMalloc(&d_b, sizeof(float) * bias.size()));
@@ -1273,6 +1282,7 @@ int mi_unet_layer_debug(int device, const char *op, const float *in, int B, int 
         DBG_TRY(launch_maxpool2x2(d_in, Cin, d_out, B, H, W, Cin, nullptr));
     }
     DBG_TRY(hipDeviceSynchronize());
+    if (want_pool) { std::swap(d_out, d_pool); out_n /= 4; }
     if (lp_out) {
         std::vector<uint16_t> out16(out_n);
         DBG_TRY(hipMemcpy(out16.data(), d_out, sizeof(uint16_t) * out_n, hipMemcpyDeviceToHost));
@@ -1284,6 +1294,7 @@ int mi_unet_layer_debug(int device, const char *op, const float *in, int B, int 
 done:
     if (d_in) (void)hipFree(d_in);
     if (d_out) (void)hipFree(d_out);
+    if (d_pool) (void)hipFree(d_pool);
     if (d_w) (void)hipFree(d_w);
     if (d_b) (void)hipFree(d_b);
     return rc;

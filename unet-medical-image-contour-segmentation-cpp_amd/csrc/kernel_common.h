@@ -11,6 +11,17 @@ namespace miunet {
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
+// gfx950: a VMEM store of more than 64 bits reads its data registers AFTER it issues; a VALU write to one of them within two
+// wait states corrupts the stored value.  hipcc pads that itself inside a basic block, but not when the overwriting
+// instruction is the first of the block that follows a branch join (found in conv_lpr.hip: the pooled 16-byte store at
+// the end of an `if (do_pool)`, then the next row block's v_add into the same register -- first dword of random lanes
+// garbage, tests/test_gpu_bf16.py::test_conv3x3_resident_weights_fused_pooling).  Call this right after such a store.
+__device__ __forceinline__ void wide_store_guard()
+{
+    asm volatile("s_nop 1");
+    __builtin_amdgcn_sched_barrier(0);
+}
+
 // bijective XCD remap (cdna_hip_programming.md §5): blocks b and b+8 share an XCD; give XCD x the logical range
 // [start_x, start_x + count_x).
 __device__ __forceinline__ int xcd_remap(int bid, int nwg)

@@ -377,10 +377,13 @@ def layer_debug(op, x, w=None, scale=None, shift=None, relu=False, device=0):
     full_op = op
     if op.endswith("_lpout"):         # 16-bit conv ops: the output tensor is 16-bit on the device too (converted back here)
         op = op[:-6]
+    pooled = op.endswith("_pool")     # conv3x3 ops: return the fused 2x2 max-pooled tensor instead of the full-size one
+    if pooled:
+        op = op[:-5]
     if op in ("conv3x3", "conv3x3_wino", "conv3x3_wino16", "conv3x3_wino4", "conv3x3_wino4s", "conv3x3_bf16", "conv3x3_fp16", "conv3x3_bf16w", "conv3x3_fp16w", "conv3x3_bf16r", "conv3x3_fp16r"):
         w = np.ascontiguousarray(w, np.float32)
         cout = w.shape[0]
-        out = np.empty((b, h, ww, cout), np.float32)
+        out = np.empty((b, h // 2, ww // 2, cout) if pooled else (b, h, ww, cout), np.float32)
     elif op in ("convT2x2", "convT2x2_taps", "convT2x2_bf16", "convT2x2_fp16"):
         w = np.ascontiguousarray(w, np.float32)
         cout = w.shape[1]
