@@ -60,7 +60,7 @@ struct LPR {
     static constexpr int HEAD_SCR_BYTES = 32 * HEAD_ROW * 4;      // per wave: [32 pixels][HEAD_ROW] fp32
     static constexpr size_t lds_bytes(int plane_bytes, int cin, int nbuf, bool head)
     {
-        return (size_t)nbuf * (cin / 32) * plane_bytes + 8 * (head ? HEAD_SCR_BYTES : SCR_BYTES);
+        return (size_t)nbuf * (cin / 32) * plane_bytes + 8 * (head ? HEAD_SCR_BYTES : SCR_BYTES) + (head ? 3 * 32 * 4 : 0);
     }
 };
 
@@ -180,15 +180,20 @@ __global__ __launch_bounds__(512, 1) void conv3x3_lpr(const ConvArgs a, const in
             pvoff[mb][j] = lane < 32 ? (unsigned)(((rp * Wp + 8 * (ch0 + mb) + m) * a.pool_ld + 32 * (blk0 + j) + 8 * q) * 2) : 0xFFFFFFFFu;
         }
     const float relu_lo = a.relu ? 0.f : -3.402823466e+38f;
-    f32x4 wh[HEAD ? 3 : 1][8];                                // HEAD: head_w[k][4 c4 .. + 4], classes past head_classes = 0
+    // HEAD: head_w[k][c] (classes past head_classes = 0) goes through LDS once.  Read straight from global its address is
+    // uniform, so hipcc keeps the 96 values in SGPRs, spills them into VGPR lanes and restores each with a v_readlane per use
+    // (149 per tile); read back from LDS they are ordinary per-lane registers.
+    f32x4 wh[HEAD ? 3 : 1][8];
     float hb[3] = { 0.f, 0.f, 0.f };
     if constexpr (HEAD) {
+        float *const WhL = reinterpret_cast<float *>(smem + NBUF * TILE_BYTES + 8 * LPR::HEAD_SCR_BYTES);      // [3][32]
+        if (tid < 3 * 32) WhL[tid] = tid / 32 < a.head_classes ? a.head_w[tid] : 0.f;
+        __syncthreads();
 #pragma unroll
         for (int k = 0; k < 3; ++k) {
             if (k < a.head_classes) hb[k] = a.head_b[k];
 #pragma unroll
-            for (int c4 = 0; c4 < 8; ++c4)
-                wh[k][c4] = k < a.head_classes ? *reinterpret_cast<const f32x4 *>(a.head_w + k * 32 + 4 * c4) : f32x4{ 0.f, 0.f, 0.f, 0.f };
+            for (int c4 = 0; c4 < 8; ++c4) wh[k][c4] = *reinterpret_cast<const f32x4 *>(WhL + k * 32 + 4 * c4);
         }
     }
 
@@ -440,12 +445,13 @@ static hipError_t launch_lpr(const ConvArgs &a, hipStream_t s)
 {
     const char *rb_e = getenv("MIUNET_LPR_RB");             // 1: 8-row tiles for every shape (A/B, parity tests)
     const int rb_env = rb_e ? atoi(rb_e) : 2;
+    // the fused head keeps 8-row tiles: with two row blocks its 96 head-weight registers spill, and scratch traffic shares
+    // vmcnt with the patch DMA (the compiler's waits for it drain the ring: measured 0.27 -> 0.53 ms)
+    if (a.head_w != nullptr) return launch_lpr_cfg<T, 32, 1, 4, 1, true>(a, s);
     if (rb_env == 2) {
-        if (a.head_w != nullptr) return launch_lpr_cfg<T, 32, 1, 3, 2, true>(a, s);
         if (a.Cin == 32 && a.Cout == 32) return launch_lpr_cfg<T, 32, 1, 3, 2>(a, s);
         if (a.Cin == 32) return launch_lpr_cfg<T, 32, 2, 4, 1>(a, s);      // 32 -> 64 with two row blocks spills (144 weight + 64 accumulator registers)
     } else {
-        if (a.head_w != nullptr) return launch_lpr_cfg<T, 32, 1, 4, 1, true>(a, s);
         if (a.Cin == 32) return a.Cout == 32 ? launch_lpr_cfg<T, 32, 1, 4, 1>(a, s) : launch_lpr_cfg<T, 32, 2, 4, 1>(a, s);
     }
     return a.Cout == 32 ? launch_lpr_cfg<T, 64, 1, 3, 1>(a, s) : launch_lpr_cfg<T, 64, 2, 3, 1>(a, s);
