@@ -204,3 +204,37 @@ def test_maxpool(B, H, W, C):
     x = _rng(C).standard_normal((B, H, W, C), dtype=np.float32)
     got = binding.layer_debug("maxpool", x)
     assert np.array_equal(got, orc.maxpool2x2(x))
+
+
+@pytest.mark.parametrize("B,H,W,Cin,Cout", [
+    (1, 16, 32, 1, 64),        # exactly one 16 x 32 tile of the MFMA form
+    (2, 37, 70, 1, 64),        # ragged in x and y
+    (1, 40, 96, 3, 32),        # BASELINE config 5's first layer (K = 27: one padded K step)
+    (1, 9, 33, 3, 64),
+    (1, 24, 40, 1, 32),
+])
+def test_first_layer(B, H, W, Cin, Cout, monkeypatch):
+    """inc.c1: u8 image -> /255 table -> conv3x3 + shift + ReLU.  fp32 output (VALU kernel) against the oracle at fp32 tolerance;
+    the 16-bit outputs -- the fp32-MFMA form (default) and the VALU form (MIUNET_FIRST_MFMA=0) -- within one 16-bit rounding
+    of the oracle and of each other (same fp32 operands, a different order of the K sum)."""
+    from oracle_lib import bf16_round, fp16_round
+    r = _rng(H + 3 * W + Cin + Cout)
+    x = r.integers(0, 256, (B, H, W, Cin)).astype(np.float32)
+    w = (r.standard_normal((Cout, Cin, 3, 3), dtype=np.float32) * np.sqrt(2.0 / (9 * Cin))).astype(np.float32)
+    scale = (1.0 + 0.1 * r.standard_normal(Cout)).astype(np.float32)
+    shift = (0.1 * r.standard_normal(Cout)).astype(np.float32)
+    wf = (w.astype(np.float64) * scale.astype(np.float64)[:, None, None, None]).astype(np.float32)
+    ref = np.maximum(orc.conv3x3(x / np.float32(255.0), wf) + shift, 0.0)
+    got = binding.layer_debug("conv3x3_first", x, w, scale, shift, relu=True)
+    assert not np.isnan(got).any()
+    assert np.max(np.abs(got - ref)) < _tol(ref)
+    for op, rnd, ulp in (("conv3x3_first_bf16", bf16_round, 2.0 ** -7), ("conv3x3_first_fp16", fp16_round, 2.0 ** -10)):
+        out = {}
+        for mode in ("1", "0"):
+            monkeypatch.setenv("MIUNET_FIRST_MFMA", mode)
+            out[mode] = binding.layer_debug(op, x, w, scale, shift, relu=True)
+            assert not np.isnan(out[mode]).any(), "unwritten (NaN-poisoned) outputs"
+            assert np.max(np.abs(out[mode] - ref) / np.maximum(1.0, np.abs(ref))) < ulp
+        assert np.array_equal(out["0"], rnd(got))                 # the VALU form: one rounding of its own fp32 result
+        assert np.max(np.abs(out["1"] - out["0"]) / np.maximum(1.0, np.abs(ref))) < ulp
+        assert np.mean(out["1"] != out["0"]) < 0.02               # ... and the MFMA form differs from it by rare 1-ulp flips

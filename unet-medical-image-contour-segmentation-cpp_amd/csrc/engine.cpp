@@ -1150,6 +1150,48 @@ int mi_unet_layer_debug(int device, const char *op, const float *in, int B, int 
     if (o.size() > 5 && o.compare(o.size() - 5, 5, "_pool") == 0) { want_pool = true; o.resize(o.size() - 5); }
     float *d_pool = nullptr;
     const size_t in_n = (size_t)B * H * W * Cin;
+    if (o == "conv3x3_first" || o == "conv3x3_first_bf16" || o == "conv3x3_first_fp16") {
+        // the first layer: `in` holds byte values 0..255 (as floats), the kernel sees the u8 image and the /255 table;
+        // _bf16 / _fp16: the 16-bit pipelines' output tensor (converted back to float here)
+        if (!w || Cout <= 0 || Cout % 4 || (Cin != 1 && Cin != 3) || want_pool || lp_out) return fail(MI_UNET_EARG, "layer_debug: conv3x3_first needs weights, Cin 1 or 3, Cout % 4 == 0");
+        const int kind = o == "conv3x3_first" ? 0 : o == "conv3x3_first_bf16" ? 1 : 2;
+        std::vector<uint8_t> img(in_n);
+        for (size_t i = 0; i < in_n; ++i) img[i] = (uint8_t)in[i];
+        float lut[256];
+        for (int i = 0; i < 256; ++i) lut[i] = static_cast<float>(i) / 255.0f;
+        std::vector<float> wf((size_t)9 * Cin * Cout), sh(Cout);
+        for (int co = 0; co < Cout; ++co) {
+            sh[co] = shift ? shift[co] : 0.f;
+            for (int ci = 0; ci < Cin; ++ci)
+                for (int t = 0; t < 9; ++t)
+                    wf[((size_t)t * Cin + ci) * Cout + co] = (float)((double)w[((size_t)co * Cin + ci) * 9 + t] * (scale ? (double)scale[co] : 1.0));
+        }
+        const size_t n_out = (size_t)B * H * W * Cout;
+        uint8_t *d_img = nullptr; float *d_l = nullptr, *d_wf = nullptr, *d_sh = nullptr, *d_o = nullptr;
+        int rc1 = MI_UNET_OK;
+        hipError_t e1 = hipSuccess;
+        auto ok = [&](hipError_t e, const char *what) { if (e != hipSuccess && rc1 == MI_UNET_OK) { e1 = e; rc1 = fail(MI_UNET_EHIP, std::string(what) + ": " + hipGetErrorString(e)); } return rc1 == MI_UNET_OK; };
+        if (ok(hipMalloc(&d_img, in_n), "hipMalloc") && ok(hipMalloc(&d_l, sizeof lut), "hipMalloc") && ok(hipMalloc(&d_wf, sizeof(float) * wf.size()), "hipMalloc") &&
+            ok(hipMalloc(&d_sh, sizeof(float) * Cout), "hipMalloc") && ok(hipMalloc(&d_o, sizeof(float) * n_out), "hipMalloc") &&
+            ok(hipMemcpy(d_img, img.data(), in_n, hipMemcpyHostToDevice), "hipMemcpy") && ok(hipMemcpy(d_l, lut, sizeof lut, hipMemcpyHostToDevice), "hipMemcpy") &&
+            ok(hipMemcpy(d_wf, wf.data(), sizeof(float) * wf.size(), hipMemcpyHostToDevice), "hipMemcpy") &&
+            ok(hipMemcpy(d_sh, sh.data(), sizeof(float) * Cout, hipMemcpyHostToDevice), "hipMemcpy") &&
+            ok(hipMemset(d_o, 0xFF, sizeof(float) * n_out), "hipMemset") &&
+            ok(launch_conv3x3_first(d_img, d_l, d_wf, d_sh, d_o, B, H, W, Cin, Cout, Cout, kind, nullptr), "launch_conv3x3_first") &&
+            ok(hipDeviceSynchronize(), "hipDeviceSynchronize")) {
+            if (kind == 0) {
+                ok(hipMemcpy(out, d_o, sizeof(float) * n_out, hipMemcpyDeviceToHost), "hipMemcpy");
+            } else {
+                std::vector<uint16_t> o16(n_out);
+                if (ok(hipMemcpy(o16.data(), d_o, sizeof(uint16_t) * n_out, hipMemcpyDeviceToHost), "hipMemcpy"))
+                    for (size_t i = 0; i < n_out; ++i) out[i] = kind == 2 ? fp16_to_float(o16[i]) : bf16_to_float(o16[i]);
+            }
+        }
+        (void)e1;
+        void *fr[] = { d_img, d_l, d_wf, d_sh, d_o };
+        for (void *p : fr) if (p) (void)hipFree(p);
+        return rc1;
+    }
     float *d_in = nullptr, *d_out = nullptr, *d_w = nullptr, *d_b = nullptr;
     std::vector<float> wpk, bias;
     size_t out_n = 0;

@@ -1,4 +1,6 @@
 // layers_mem.hip -- the HBM-bound layers: first conv (K = 9), 2x2 max pooling, 1x1 head + argmax.  gfx950 only.
+#include <cstdlib>
+
 #include "kernel_common.h"
 
 namespace miunet {
@@ -121,10 +123,135 @@ static hipError_t launch_first_t(const uint8_t *img, const float *lut256, const 
     return hipGetLastError();
 }
 
+// --------------------------------------------------------------------------------------------------------------------
+// The same layer on the fp32 MFMA, for the 16-bit pipelines.  The kernel above is VALU-bound at Cout = 32 x K = 27 (BASELINE
+// config 5: 0.35 ms for a 0.54 GB write, 41 TFLOP/s) and at Cout = 64 x K = 9 (config 3: 0.18 ms).  As a GEMM it is tiny:
+// M = pixels, N = Cout, K = 9 Cin <= 27 -- K / 2 steps of v_mfma_f32_32x32x2_f32 per 32 pixels x 32 channels, operands and
+// accumulation still fp32 (only the ORDER of the K sum differs from the VALU kernel: tap-major instead of channel-major).
+//   * workgroup = 16 rows x 32 columns, wave w = rows 4w .. 4w + 3 (four row blocks of 1 x 32 pixels) x NBK channel blocks;
+//   * the (16 + 2) x 34-pixel patch goes through the /255 table into LDS as [pixel][Cin] floats (+ one zero word for the
+//     padded K step); lane (pixel i, k half h) reads A[i][2s + h] with one ds_read_b32 at patch offset + koff[s];
+//   * B[2s + h][n] = w[2s + h][n] sits in K / 2 x NBK registers per lane for the whole tile;
+//   * epilogue: + shift, ReLU, one rounding, [pixel][channel] tile in the wave's LDS scratch, 16-byte stores.
+template <int CIN, int NBK, typename OT>
+__global__ __launch_bounds__(256) void conv3x3_first_mfma(const uint8_t *__restrict__ img, const float *__restrict__ lut,
+                                                          const float *__restrict__ w, const float *__restrict__ shift,
+                                                          OT *__restrict__ out, int H, int W, int Cout, int ldo,
+                                                          int tiles_x, int tiles_y)
+{
+    static_assert(sizeof(OT) == 2, "16-bit outputs (the fp32 plan keeps the VALU kernel: its tensor is HBM-bound there)");
+    typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+    constexpr int K = 9 * CIN, KS = (K + 1) / 2;
+    constexpr int TH = 16, PW = 34, NPIX = (TH + 2) * PW;
+    constexpr int TROW = 40;                                  // 16-bit elements per pixel of the output scratch (32 + 8 pad)
+    __shared__ float s_lut[256];
+    __shared__ __attribute__((aligned(16))) float s_in[NPIX * CIN + 4];       // [pixel][CIN], then zeros
+    __shared__ __attribute__((aligned(16))) OT s_out[4][32 * TROW];
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int li = lane & 31, lh = lane >> 5;
+    s_lut[tid] = lut[tid];
+    int L = blockIdx.x;
+    const int tx = L % tiles_x; L /= tiles_x;
+    const int ty = L % tiles_y;
+    const int b = L / tiles_y;
+    const int y0 = ty * TH, x0 = tx * 32;
+
+    // B fragments and the per-step patch offsets of this lane's k = 2 s + lh
+    float bw[KS][NBK];
+    int koff[KS];
+#pragma unroll
+    for (int s = 0; s < KS; ++s) {
+        const int k = 2 * s + lh;
+        const int tap = k / CIN, c = k - tap * CIN, dy = tap / 3, dx = tap - 3 * dy;
+        koff[s] = k < K ? ((dy * PW + dx) * CIN + c) : -1;
+#pragma unroll
+        for (int j = 0; j < NBK; ++j) bw[s][j] = (k < K && 32 * j + li < Cout) ? w[(size_t)k * Cout + 32 * j + li] : 0.f;
+    }
+    __syncthreads();                              // the table is complete
+    const uint8_t *imgb = img + (size_t)b * H * W * CIN;
+    for (int e = tid; e < NPIX * CIN; e += 256) {
+        const int p = e / CIN, c = e - p * CIN, py = p / PW, px = p - py * PW;
+        const int gy = y0 - 1 + py, gx = x0 - 1 + px;
+        s_in[e] = (gy >= 0 && gy < H && gx >= 0 && gx < W) ? s_lut[imgb[((size_t)gy * W + gx) * CIN + c]] : 0.f;
+    }
+    if (tid < 4) s_in[NPIX * CIN + tid] = 0.f;
+    __syncthreads();
+
+    f32x16 acc[4][NBK];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < NBK; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+    const int pbase = ((4 * wave) * PW + li) * CIN;           // row block i adds i * PW * CIN
+#pragma unroll
+    for (int s = 0; s < KS; ++s) {
+        float av[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) av[i] = s_in[koff[s] >= 0 ? pbase + i * PW * CIN + koff[s] : NPIX * CIN];
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < NBK; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[i], bw[s][j], acc[i][j], 0, 0, 0);
+    }
+
+    // epilogue: accumulator register r = pixel column (r & 3) + 8 (r >> 2) + 4 lh of row y0 + 4 wave + i, lane = channel
+    OT *const Ts = s_out[wave];
+    const __amdgpu_buffer_rsrc_t out_rsrc = __builtin_amdgcn_make_buffer_rsrc(out + (size_t)b * H * W * ldo, 0, H * W * ldo * 2, 0x00020000);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int y = y0 + 4 * wave + i;
+#pragma unroll
+        for (int j = 0; j < NBK; ++j) {
+            const float sh = 32 * j + li < Cout ? shift[32 * j + li] : 0.f;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const float v = acc[i][j][r] + sh;
+                Ts[((r & 3) + 8 * (r >> 2) + 4 * lh) * TROW + li] = (OT)(v > 0.f ? v : 0.f);
+            }
+#pragma unroll
+            for (int it = 0; it < 2; ++it) {
+                const int e = lane + 64 * it, m = e >> 2, q = e & 3;
+                const u32x4 v = *reinterpret_cast<const u32x4 *>(Ts + m * TROW + 8 * q);
+                const bool ok = y < H && x0 + m < W && 32 * j + 8 * q < Cout;
+                __builtin_amdgcn_raw_buffer_store_b128(v, out_rsrc, ok ? (unsigned)((((y * W) + x0 + m) * ldo + 32 * j + 8 * q) * 2) : 0xFFFFFFFFu, 0, 0);
+                wide_store_guard();
+            }
+        }
+    }
+}
+
+template <typename OT>
+static hipError_t launch_first_mfma_t(const uint8_t *img, const float *lut256, const float *w, const float *shift, OT *out,
+                                      int B, int H, int W, int Cin, int Cout, int ldo, hipStream_t s)
+{
+    const int tiles_x = (W + 31) / 32, tiles_y = (H + 15) / 16;
+    const long long blocks = (long long)B * tiles_x * tiles_y;
+    if (blocks <= 0 || blocks > 0x7FFFFFFFLL) return hipErrorInvalidValue;
+    const dim3 g((unsigned)blocks), t(256);
+    if (Cin == 1 && Cout <= 32) hipLaunchKernelGGL((conv3x3_first_mfma<1, 1, OT>), g, t, 0, s, img, lut256, w, shift, out, H, W, Cout, ldo, tiles_x, tiles_y);
+    else if (Cin == 1) hipLaunchKernelGGL((conv3x3_first_mfma<1, 2, OT>), g, t, 0, s, img, lut256, w, shift, out, H, W, Cout, ldo, tiles_x, tiles_y);
+    else if (Cout <= 32) hipLaunchKernelGGL((conv3x3_first_mfma<3, 1, OT>), g, t, 0, s, img, lut256, w, shift, out, H, W, Cout, ldo, tiles_x, tiles_y);
+    else hipLaunchKernelGGL((conv3x3_first_mfma<3, 2, OT>), g, t, 0, s, img, lut256, w, shift, out, H, W, Cout, ldo, tiles_x, tiles_y);
+    return hipGetLastError();
+}
+
+// the MFMA form takes the 16-bit outputs it was built for (MIUNET_FIRST_MFMA=0: never)
+static bool first_mfma_takes(int Cin, int Cout, int ldo, int H, int W, int out_kind)
+{
+    const char *e = getenv("MIUNET_FIRST_MFMA");
+    if (e && e[0] == '0') return false;
+    return out_kind != 0 && (Cin == 1 || Cin == 3) && Cout % 8 == 0 && Cout <= 64 && ldo % 8 == 0 && (long long)H * W * ldo * 2 < (1ll << 31);
+}
+
 // out_kind: 0 = fp32, 1 = bf16, 2 = fp16 output tensor
 hipError_t launch_conv3x3_first(const uint8_t *img, const float *lut256, const float *w, const float *shift, float *out,
                                 int B, int H, int W, int Cin, int Cout, int ldo, int out_kind, hipStream_t s)
 {
+    if (first_mfma_takes(Cin, Cout, ldo, H, W, out_kind))
+        return out_kind == 1 ? launch_first_mfma_t(img, lut256, w, shift, reinterpret_cast<__bf16 *>(out), B, H, W, Cin, Cout, ldo, s)
+                             : launch_first_mfma_t(img, lut256, w, shift, reinterpret_cast<_Float16 *>(out), B, H, W, Cin, Cout, ldo, s);
     if (out_kind == 1) return launch_first_t(img, lut256, w, shift, reinterpret_cast<__bf16 *>(out), B, H, W, Cin, Cout, ldo, s);
     if (out_kind == 2) return launch_first_t(img, lut256, w, shift, reinterpret_cast<_Float16 *>(out), B, H, W, Cin, Cout, ldo, s);
     return launch_first_t(img, lut256, w, shift, out, B, H, W, Cin, Cout, ldo, s);
