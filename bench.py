@@ -47,7 +47,7 @@ WINOGRAD_REDUCTION = {"conv3x3_wino4": 4.0, "conv3x3_wino4s": 4.0, "conv3x3_wino
 CONV_FAMILIES = ("conv3x3_mfma", "conv3x3_wino", "conv3x3_wino16", "conv3x3_wino4", "conv3x3_wino4s", "conv3x3_bf16", "conv3x3_fp16",
                  "conv3x3_bf16w", "conv3x3_fp16w", "conv3x3_bf16r", "conv3x3_fp16r")
 LP_FAMILIES = ("conv3x3_bf16", "conv3x3_fp16", "conv3x3_bf16w", "conv3x3_fp16w", "conv3x3_bf16r", "conv3x3_fp16r", "convT2x2_bf16",
-               "convT2x2_fp16")
+               "convT2x2_fp16", "convT2x2_bf16r", "convT2x2_fp16r")
 ROCPROF_NAME = {"conv3x3_wino": "miunet::conv3x3_wino_f32<*>", "conv3x3_wino16": "miunet::conv3x3_wino16_f32",
                 "conv3x3_wino4": "miunet::conv3x3_wino4_f32<*>", "conv3x3_wino4s": "miunet::conv3x3_wino4s_f32<*>",
                 "conv3x3_mfma": "miunet::conv_mfma_f32<*>", "convT2x2_taps": "miunet::convT2x2_taps_f32<*>",
@@ -55,7 +55,8 @@ ROCPROF_NAME = {"conv3x3_wino": "miunet::conv3x3_wino_f32<*>", "conv3x3_wino16":
                 "conv3x3_bf16": "miunet::conv_mfma_bf16<*>", "conv3x3_fp16": "miunet::conv_mfma_bf16<*>",
                 "convT2x2_bf16": "miunet::conv_mfma_bf16<*>", "convT2x2_fp16": "miunet::conv_mfma_bf16<*>",
                 "conv3x3_bf16w": "miunet::conv3x3_lp2<*>", "conv3x3_fp16w": "miunet::conv3x3_lp2<*>",
-                "conv3x3_bf16r": "miunet::conv3x3_lpr<*>", "conv3x3_fp16r": "miunet::conv3x3_lpr<*>"}
+                "conv3x3_bf16r": "miunet::conv3x3_lpr<*>", "conv3x3_fp16r": "miunet::conv3x3_lpr<*>",
+                "convT2x2_bf16r": "miunet::convT2x2_lpr<*>", "convT2x2_fp16r": "miunet::convT2x2_lpr<*>"}
 
 
 def family(kernel):

@@ -44,9 +44,10 @@ def test_resident_weight_kernels_do_not_spill(tmp_path):
     """conv_lpr.hip counts its own LDS-DMA loads with vmcnt; a register spill adds scratch loads and stores to the same
     counter, and hipcc's waits for THOSE drain the patch ring (measured: the fused-head variant 0.27 -> 0.53 ms with 24 scratch
     accesses per tile).  Every instantiation must fit its register budget."""
-    asm = tmp_path / "conv_lpr.s"
-    subprocess.run([HIPCC, "-O3", "-std=c++17", "--offload-arch=gfx950", "-S", "--cuda-device-only", "-o", str(asm),
-                    os.path.join(CSRC, "conv_lpr.hip")], check=True, capture_output=True, timeout=600)
-    text = asm.read_text()
-    assert text.count(".amdhsa_kernel ") >= 12                 # six shapes x two operand types
-    assert "scratch_" not in text, [l for l in text.splitlines() if "scratch_" in l][:5]
+    for src, kernels in (("conv_lpr.hip", 12), ("convt_lpr.hip", 6)):       # shapes x two operand types
+        asm = tmp_path / (src + ".s")
+        subprocess.run([HIPCC, "-O3", "-std=c++17", "--offload-arch=gfx950", "-S", "--cuda-device-only", "-o", str(asm),
+                        os.path.join(CSRC, src)], check=True, capture_output=True, timeout=600)
+        text = asm.read_text()
+        assert text.count(".amdhsa_kernel ") >= kernels
+        assert "scratch_" not in text, [l for l in text.splitlines() if "scratch_" in l][:5]

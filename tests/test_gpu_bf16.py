@@ -265,3 +265,62 @@ def test_conv3x3_resident_weights_fused_pooling(op, B, H, W, Cin, Cout):
         assert not np.isnan(pooled).any(), "unwritten (NaN-poisoned) pooled outputs"
         assert np.array_equal(pooled, orc.maxpool2x2(full))
     assert np.array_equal(pooled, binding.layer_debug(op + "_pool_lpout", x, w, None, shift, relu=True))
+
+
+# ---------------------------------------------------------------- the large transposed convolutions with resident weights (convt_lpr.hip)
+@pytest.mark.parametrize("op,B,H,W,Cin,Cout", [
+    ("convT2x2_bf16", 1, 8, 32, 64, 32),        # exactly one 8 x 32 tile: wave = tap x half of the row blocks
+    ("convT2x2_fp16", 2, 9, 40, 64, 32),        # ragged in x and y
+    ("convT2x2_bf16", 1, 8, 64, 128, 64),       # 4 x 32 tiles, two channel blocks per wave
+    ("convT2x2_fp16", 1, 5, 33, 128, 64),
+    ("convT2x2_bf16", 1, 6, 32, 256, 128),      # 2 x 32 tiles, wave = tap x half of the channels
+    ("convT2x2_fp16", 3, 3, 70, 256, 128),
+])
+def test_convT_resident_weights(op, B, H, W, Cin, Cout):
+    """Same products and accumulation order as the one-tile-per-workgroup kernel: its 16-bit tensor bit for bit, within one
+    16-bit rounding of the rounded-operand oracle."""
+    r = np.random.default_rng(5 * B + H + 3 * W + Cin + Cout)
+    x = r.standard_normal((B, H, W, Cin), dtype=np.float32)
+    w = (r.standard_normal((Cin, Cout, 2, 2), dtype=np.float32) / np.sqrt(Cin)).astype(np.float32)
+    bias = (0.1 * r.standard_normal(Cout)).astype(np.float32)
+    rnd = orc.bf16_round if op.endswith("bf16") else orc.fp16_round
+    got16 = binding.layer_debug(op + "r_lpout", x, w, None, bias)
+    assert not np.isnan(got16).any(), "unwritten (NaN-poisoned) outputs"
+    assert np.array_equal(got16, binding.layer_debug(op + "_lpout", x, w, None, bias))
+    ref = orc.convT2x2(rnd(x), rnd(w), bias)
+    ulp = 2.0 ** -7 if op.endswith("bf16") else 2.0 ** -10
+    assert np.max(np.abs(got16 - ref) / np.maximum(1.0, np.abs(ref))) < ulp
+
+
+@pytest.mark.parametrize("op,Cin,Cout,H,W", [("convT2x2_bf16", 128, 64, 256, 256), ("convT2x2_fp16", 64, 32, 512, 256), ("convT2x2_bf16", 256, 128, 128, 128)])
+def test_convT_resident_weights_many_tiles_per_workgroup(op, Cin, Cout, H, W):
+    """Thousands of tiles on 256 persistent workgroups: the three-deep tile ring wraps, every wait and barrier of the steady
+    state runs; three runs (a race would not show every time), compared with the one-tile-per-workgroup kernel bit for bit."""
+    r = np.random.default_rng(Cin + Cout)
+    x = r.standard_normal((4, H, W, Cin), dtype=np.float32)
+    w = (r.standard_normal((Cin, Cout, 2, 2), dtype=np.float32) / np.sqrt(Cin)).astype(np.float32)
+    bias = (0.1 * r.standard_normal(Cout)).astype(np.float32)
+    ref = binding.layer_debug(op + "_lpout", x, w, None, bias)
+    for _ in range(3):
+        got16 = binding.layer_debug(op + "r_lpout", x, w, None, bias)
+        assert not np.isnan(got16).any()
+        assert np.array_equal(got16, ref)
+
+
+@pytest.mark.parametrize("algo", ["bf16", "fp16"])
+def test_resident_weight_convT_in_the_whole_network(algo, monkeypatch):
+    """base 32, three levels: up1.t (256 -> 128), up2.t (128 -> 64) and up3.t (64 -> 32) are the three shapes of convt_lpr.hip,
+    writing the upper halves of the concat buffers.  MIUNET_CONVT_LPR=2 sends them there whatever the grid, =0 nowhere."""
+    spec = UNetSpec(1, 32, 3, 3)
+    blob = pack_weights(spec, synth.make_weights(spec, 78))
+    imgs = synth.make_images(3, 96, 80, 1, 0x52, "blobs")
+    out, used = {}, {}
+    for mode in ("0", "2"):
+        monkeypatch.setenv("MIUNET_CONVT_LPR", mode)
+        with binding.Engine(96, 80, 1, 32, 3, 3, max_batch=3, conv_algo=algo) as eng:
+            eng.load_weights(blob)
+            eng.set_profiling(True)
+            out[mode] = eng.infer(imgs, want_logits=True)
+            used[mode] = [s["kernel"] for s in eng.kernel_stats() if s["kernel"].startswith("convT") and s["kernel"].endswith("r")]
+    assert used["0"] == [] and used["2"] == [f"convT2x2_{algo}r"] * 3
+    assert np.array_equal(out["0"][1], out["2"][1]) and np.array_equal(out["0"][0], out["2"][0])

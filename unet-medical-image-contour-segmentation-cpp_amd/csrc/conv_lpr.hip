@@ -3,6 +3,7 @@
 #include <type_traits>
 
 #include "kernel_common.h"
+#include "lpr_common.h"
 
 namespace miunet {
 
@@ -31,17 +32,6 @@ namespace miunet {
 //   * outputs leave through a wave-private LDS tile as 16-byte stores (the conv_lp.hip epilogue, without its barrier).
 // Same products and the same fp32 accumulation order as conv_mfma_bf16 (chunks of 32 channels, taps in raster order, 16
 // channels per MFMA): bit-identical results (tests/test_gpu_bf16.py::test_conv3x3_resident_weights).
-template <typename T> struct LprVec { typedef T x8 __attribute__((ext_vector_type(8))); };
-
-__device__ __forceinline__ f32x16 mfma_lpr(LprVec<__bf16>::x8 a, LprVec<__bf16>::x8 b, f32x16 c)
-{
-    return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
-}
-__device__ __forceinline__ f32x16 mfma_lpr(LprVec<_Float16>::x8 a, LprVec<_Float16>::x8 b, f32x16 c)
-{
-    return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0);
-}
-
 // RB = row blocks (2 image rows x 16 columns each) a wave owns per tile: the tile is 8 RB rows x 32 columns.  RB = 2 halves
 // the halo re-read (18 x 34 pixels for 16 x 32 outputs: 1.20 x instead of 1.33 x), the barriers and the per-tile address
 // work per pixel, and gives a wave two independent accumulator chains; it needs a 39 KB patch per 32-channel plane, so it is
@@ -63,30 +53,6 @@ struct LPR {
         return (size_t)nbuf * (cin / 32) * plane_bytes + 8 * (head ? HEAD_SCR_BYTES : SCR_BYTES) + (head ? 3 * 32 * 4 : 0);
     }
 };
-
-template <int N> __device__ __forceinline__ void lpr_wait_vm()
-{
-    __builtin_amdgcn_s_waitcnt(0x0F70 | (N & 15) | ((N >> 4) << 14));      // vmcnt(N); expcnt / lgkmcnt untouched
-}
-__device__ __forceinline__ void lpr_wait_vm_n(int n)      // uniform n
-{
-    switch (n) {
-    case 0: lpr_wait_vm<0>(); break;
-    case 1: lpr_wait_vm<1>(); break;
-    case 2: lpr_wait_vm<2>(); break;
-    case 3: lpr_wait_vm<3>(); break;
-    case 4: lpr_wait_vm<4>(); break;
-    case 5: lpr_wait_vm<5>(); break;
-    case 6: lpr_wait_vm<6>(); break;
-    case 7: lpr_wait_vm<7>(); break;
-    case 8: lpr_wait_vm<8>(); break;
-    case 9: lpr_wait_vm<9>(); break;
-    case 10: lpr_wait_vm<10>(); break;
-    case 11: lpr_wait_vm<11>(); break;
-    case 12: lpr_wait_vm<12>(); break;
-    default: lpr_wait_vm<0>(); break;
-    }
-}
 
 // CIN = 32 or 64 input channels (exactly), NBT = 1 or 2 blocks of 32 output channels (Cout = 32 NBT exactly), NBUF = patch ring
 // HEAD (Cout = 32, at most three classes): the layer feeds the network's fp32 1x1 head + argmax (ConvArgs::head_w).  The

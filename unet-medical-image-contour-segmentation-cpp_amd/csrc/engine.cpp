@@ -615,7 +615,11 @@ int launch_plan(mi_unet *h, const uint8_t *d_imgs, int B, uint8_t *d_labels, flo
         case Step::CONVT: {
             ConvArgs a = st.a; a.B = B;
             a.out_lp = lp_kind != 0 ? 1 : 0;
-            if (h->algo == MI_UNET_CONV_BF16) { kname = "convT2x2_bf16"; e = launch_convT2x2_bf16(a, s); }
+            if (lp_kind != 0 && convT2x2_lpr_takes(a)) {          // the large 16-bit transposed convs: weights in registers (convt_lpr.hip)
+                kname = lp_kind == 1 ? "convT2x2_bf16r" : "convT2x2_fp16r";
+                e = launch_convT2x2_lpr(a, lp_kind == 2, s);
+            }
+            else if (h->algo == MI_UNET_CONV_BF16) { kname = "convT2x2_bf16"; e = launch_convT2x2_bf16(a, s); }
             else if (h->algo == MI_UNET_CONV_FP16) { kname = "convT2x2_fp16"; e = launch_convT2x2_fp16(a, s); }
             else if (a.wpk4 != nullptr && convT_taps_grid(a) >= 128) { kname = "convT2x2_taps"; e = launch_convT2x2_taps(a, s); }
             else { kname = "convT2x2_mfma"; e = launch_convT2x2_mfma(a, s); }
@@ -1230,10 +1234,10 @@ int mi_unet_layer_debug(int device, const char *op, const float *in, int B, int 
         out_n = (size_t)B * H * W * Cout;
         a.B = B; a.H = H; a.W = W; a.Cin = Cin; a.ldc = Cin; a.Cout = Cout; a.CoutPad = (int)npad; a.ldo = Cout; a.co_off = 0;
         a.relu = relu;
-    } else if (o == "conv3x3_bf16" || o == "convT2x2_bf16" || o == "conv3x3_fp16" || o == "convT2x2_fp16" || o == "conv3x3_bf16w" || o == "conv3x3_fp16w" || o == "conv3x3_bf16r" || o == "conv3x3_fp16r") {
+    } else if (o == "conv3x3_bf16" || o == "convT2x2_bf16" || o == "conv3x3_fp16" || o == "convT2x2_fp16" || o == "conv3x3_bf16w" || o == "conv3x3_fp16w" || o == "conv3x3_bf16r" || o == "conv3x3_fp16r" || o == "convT2x2_bf16r" || o == "convT2x2_fp16r") {
         if (!w || Cout <= 0 || Cin % 8) return fail(MI_UNET_EARG, "layer_debug: 16-bit conv needs weights and Cin % 8 == 0");
-        const bool T = (o == "convT2x2_bf16" || o == "convT2x2_fp16");
-        const lp_cvt_fn cvt = (o == "conv3x3_fp16" || o == "convT2x2_fp16" || o == "conv3x3_fp16w" || o == "conv3x3_fp16r") ? fp16_bits : bf16_bits;
+        const bool T = (o == "convT2x2_bf16" || o == "convT2x2_fp16" || o == "convT2x2_bf16r" || o == "convT2x2_fp16r");
+        const lp_cvt_fn cvt = (o == "conv3x3_fp16" || o == "convT2x2_fp16" || o == "conv3x3_fp16w" || o == "conv3x3_fp16r" || o == "convT2x2_fp16r") ? fp16_bits : bf16_bits;
         const int nch = (Cin + KC_BF16 - 1) / KC_BF16;
         const size_t npad = round_up(T ? (size_t)4 * Cout : (size_t)Cout, NPAD);
         wpk.assign(((size_t)nch * (T ? 1 : 9) * npad * KC_BF16 + 1) / 2, 0.f);
@@ -1275,8 +1279,8 @@ int mi_unet_layer_debug(int device, const char *op, const float *in, int B, int 
     } else {
         return fail(MI_UNET_EARG, "layer_debug: unknown op " + o);
     }
-    const bool lp_in = (o == "conv3x3_bf16" || o == "convT2x2_bf16" || o == "conv3x3_fp16" || o == "convT2x2_fp16" || o == "conv3x3_bf16w" || o == "conv3x3_fp16w" || o == "conv3x3_bf16r" || o == "conv3x3_fp16r");
-    const bool lp_fp16 = (o == "conv3x3_fp16" || o == "convT2x2_fp16" || o == "conv3x3_fp16w" || o == "conv3x3_fp16r");
+    const bool lp_in = (o == "conv3x3_bf16" || o == "convT2x2_bf16" || o == "conv3x3_fp16" || o == "convT2x2_fp16" || o == "conv3x3_bf16w" || o == "conv3x3_fp16w" || o == "conv3x3_bf16r" || o == "conv3x3_fp16r" || o == "convT2x2_bf16r" || o == "convT2x2_fp16r");
+    const bool lp_fp16 = (o == "conv3x3_fp16" || o == "convT2x2_fp16" || o == "conv3x3_fp16w" || o == "conv3x3_fp16r" || o == "convT2x2_fp16r");
     if (lp_out && !lp_in) return fail(MI_UNET_EARG, "layer_debug: _lpout is for the 16-bit conv ops");
     a.out_lp = lp_out ? 1 : 0;
     int rc = MI_UNET_OK;
@@ -1316,6 +1320,8 @@ int mi_unet_layer_debug(int device, const char *op, const float *in, int B, int 
                 : o == "conv3x3_fp16w" ? launch_conv3x3_lp2(a, true, nullptr)
                 : o == "conv3x3_bf16r" ? launch_conv3x3_lpr(a, false, nullptr)
                 : o == "conv3x3_fp16r" ? launch_conv3x3_lpr(a, true, nullptr)
+                : o == "convT2x2_bf16r" ? launch_convT2x2_lpr(a, false, nullptr)
+                : o == "convT2x2_fp16r" ? launch_convT2x2_lpr(a, true, nullptr)
                 : o == "conv3x3_bf16" ? launch_conv3x3_bf16(a, nullptr)
                 : o == "convT2x2_bf16" ? launch_convT2x2_bf16(a, nullptr)
                 : o == "conv3x3_fp16" ? launch_conv3x3_fp16(a, nullptr)

@@ -95,6 +95,9 @@ hipError_t launch_conv3x3_lp2(const ConvArgs &a, bool fp16, hipStream_t s);
 // persistent workgroup per CU streaming input patches through an LDS ring (conv_lpr.hip).  Same packing, same arithmetic.
 bool conv3x3_lpr_takes(const ConvArgs &a);
 hipError_t launch_conv3x3_lpr(const ConvArgs &a, bool fp16, hipStream_t s);
+// ... and the three largest transposed convolutions (Cin -> Cout = 64 -> 32, 128 -> 64, 256 -> 128; convt_lpr.hip)
+bool convT2x2_lpr_takes(const ConvArgs &a);
+hipError_t launch_convT2x2_lpr(const ConvArgs &a, bool fp16, hipStream_t s);
 
 // First layer: u8 image -> (LUT /255) -> conv3x3 (Cin = 1..4) + shift + ReLU.  w is [9][Cin][Cout] (BN scale folded).
 // out_kind: 0 = fp32 output, 1 = bf16, 2 = fp16 (the 16-bit pipelines keep every activation tensor 16-bit in HBM)

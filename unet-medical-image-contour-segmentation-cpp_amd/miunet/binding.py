@@ -384,7 +384,7 @@ def layer_debug(op, x, w=None, scale=None, shift=None, relu=False, device=0):
         w = np.ascontiguousarray(w, np.float32)
         cout = w.shape[0]
         out = np.empty((b, h // 2, ww // 2, cout) if pooled else (b, h, ww, cout), np.float32)
-    elif op in ("convT2x2", "convT2x2_taps", "convT2x2_bf16", "convT2x2_fp16"):
+    elif op in ("convT2x2", "convT2x2_taps", "convT2x2_bf16", "convT2x2_fp16", "convT2x2_bf16r", "convT2x2_fp16r"):
         w = np.ascontiguousarray(w, np.float32)
         cout = w.shape[1]
         out = np.empty((b, 2 * h, 2 * ww, cout), np.float32)
