@@ -1,6 +1,6 @@
 #!/bin/bash
 # Regenerates the judged profile artefacts of a round on the GPU box (run through gpurun from the repo root):
-#   tools/profile_round.sh r02 [fp32|bf16|all]
+#   tools/profile_round.sh r02 [fp32|bf16|fp16|all]
 # bench line + per-layer table, rocprofv3 kernel-trace stats of the same bench command, and the PMC passes (FETCH_SIZE,
 # WRITE_SIZE, SQ MFMA-busy group: separate runs, kernel-trace only) summarised by profiles/summarize_pmc.py.
 # The program sits directly behind `--` (the profiler's preloaded library has initialised the GPU by then: no env/bash hop).
@@ -36,5 +36,10 @@ fi
 if [ "$what" = "bf16" ] || [ "$what" = "all" ]; then
     python bench.py --conv-algo bf16 --batch 128 --steps 5 --no-cpu-baseline --no-extras --per-layer > $out/bf16_bench.json 2> $out/bf16_per_layer.txt
     passes bf16 --conv-algo bf16 --batch 128
+fi
+if [ "$what" = "fp16" ] || [ "$what" = "all" ]; then     # BASELINE config 5's network
+    C5="--conv-algo fp16 --size 1024 --in-ch 3 --base 32 --levels 5 --batch 8 --micro-batch 8"
+    python bench.py $C5 --steps 10 --no-cpu-baseline --no-extras --per-layer > $out/fp16_bench.json 2> $out/fp16_per_layer.txt
+    passes fp16 $C5
 fi
 ls -la $out
