@@ -530,9 +530,9 @@ def main():
             try:
                 out["configs"] = [
                     run_config(binding, synth, torch, dev, stream2, "BASELINE.json configs[2]: batch 128 x 512x512x1, bf16 operands / "
-                               "fp32 accumulate, micro-batches of 16", UNetSpec(1, 64, 4, 3), 512, 128, 16, "bf16", 3, 1, "bf16"),
+                               "fp32 accumulate, micro-batches of 16", UNetSpec(1, 64, 4, 3), 512, 128, 16, "bf16", 5, 2, "bf16"),
                     run_config(binding, synth, torch, dev, stream2, "BASELINE.json configs[4] (network half): batch 8 x 1024x1024x3, "
-                               "5-level base 32, fp16 operands / fp32 accumulate", UNetSpec(3, 32, 5, 3), 1024, 8, 8, "fp16", 3, 1, "fp16"),
+                               "5-level base 32, fp16 operands / fp32 accumulate", UNetSpec(3, 32, 5, 3), 1024, 8, 8, "fp16", 20, 5, "fp16"),
                 ]
             except Exception as e:                                            # an extra record never costs the headline
                 out["configs"] = {"error": repr(e)}
