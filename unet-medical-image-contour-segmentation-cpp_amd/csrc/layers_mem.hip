@@ -128,12 +128,12 @@ static hipError_t launch_first_t(const uint8_t *img, const float *lut256, const 
 // config 5: 0.35 ms for a 0.54 GB write, 41 TFLOP/s) and at Cout = 64 x K = 9 (config 3: 0.18 ms).  As a GEMM it is tiny:
 // M = pixels, N = Cout, K = 9 Cin <= 27 -- K / 2 steps of v_mfma_f32_32x32x2_f32 per 32 pixels x 32 channels, operands and
 // accumulation still fp32 (only the ORDER of the K sum differs from the VALU kernel: tap-major instead of channel-major).
-//   * workgroup = 16 rows x 32 columns, wave w = rows 4w .. 4w + 3 (four row blocks of 1 x 32 pixels) x NBK channel blocks;
-//   * the (16 + 2) x 34-pixel patch goes through the /255 table into LDS as [pixel][Cin] floats (+ one zero word for the
+//   * workgroup = 4 RBW rows x 32 columns, wave w = rows RBW w .. + RBW (row blocks of 1 x 32 pixels) x NBK channel blocks;
+//   * the (4 RBW + 2) x 34-pixel patch goes through the /255 table into LDS as [pixel][Cin] floats (+ one zero word for the
 //     padded K step); lane (pixel i, k half h) reads A[i][2s + h] with one ds_read_b32 at patch offset + koff[s];
 //   * B[2s + h][n] = w[2s + h][n] sits in K / 2 x NBK registers per lane for the whole tile;
 //   * epilogue: + shift, ReLU, one rounding, [pixel][channel] tile in the wave's LDS scratch, 16-byte stores.
-template <int CIN, int NBK, typename OT>
+template <int CIN, int NBK, int RBW, typename OT>
 __global__ __launch_bounds__(256) void conv3x3_first_mfma(const uint8_t *__restrict__ img, const float *__restrict__ lut,
                                                           const float *__restrict__ w, const float *__restrict__ shift,
                                                           OT *__restrict__ out, int H, int W, int Cout, int ldo,
@@ -142,7 +142,7 @@ __global__ __launch_bounds__(256) void conv3x3_first_mfma(const uint8_t *__restr
     static_assert(sizeof(OT) == 2, "16-bit outputs (the fp32 plan keeps the VALU kernel: its tensor is HBM-bound there)");
     typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
     constexpr int K = 9 * CIN, KS = (K + 1) / 2;
-    constexpr int TH = 16, PW = 34, NPIX = (TH + 2) * PW;
+    constexpr int TH = 4 * RBW, PW = 34, NPIX = (TH + 2) * PW;
     constexpr int TROW = 40;                                  // 16-bit elements per pixel of the output scratch (32 + 8 pad)
     __shared__ float s_lut[256];
     __shared__ __attribute__((aligned(16))) float s_in[NPIX * CIN + 4];       // [pixel][CIN], then zeros
@@ -167,31 +167,41 @@ __global__ __launch_bounds__(256) void conv3x3_first_mfma(const uint8_t *__restr
 #pragma unroll
         for (int j = 0; j < NBK; ++j) bw[s][j] = (k < K && 32 * j + li < Cout) ? w[(size_t)k * Cout + 32 * j + li] : 0.f;
     }
-    __syncthreads();                              // the table is complete
+    // the patch bytes are requested BEFORE the barrier that completes the table (one global round trip per workgroup, not two)
     const uint8_t *imgb = img + (size_t)b * H * W * CIN;
-    for (int e = tid; e < NPIX * CIN; e += 256) {
+    constexpr int SITERS = (NPIX * CIN + 255) / 256;
+    int sbyte[SITERS];                            // the byte, or -1 for zero padding / past the patch
+#pragma unroll
+    for (int it = 0; it < SITERS; ++it) {
+        const int e = tid + 256 * it;
         const int p = e / CIN, c = e - p * CIN, py = p / PW, px = p - py * PW;
         const int gy = y0 - 1 + py, gx = x0 - 1 + px;
-        s_in[e] = (gy >= 0 && gy < H && gx >= 0 && gx < W) ? s_lut[imgb[((size_t)gy * W + gx) * CIN + c]] : 0.f;
+        sbyte[it] = (e < NPIX * CIN && gy >= 0 && gy < H && gx >= 0 && gx < W) ? (int)imgb[((size_t)gy * W + gx) * CIN + c] : -1;
+    }
+    __syncthreads();                              // the table is complete
+#pragma unroll
+    for (int it = 0; it < SITERS; ++it) {
+        const int e = tid + 256 * it;
+        if (e < NPIX * CIN) s_in[e] = sbyte[it] >= 0 ? s_lut[sbyte[it]] : 0.f;
     }
     if (tid < 4) s_in[NPIX * CIN + tid] = 0.f;
     __syncthreads();
 
-    f32x16 acc[4][NBK];
+    f32x16 acc[RBW][NBK];
 #pragma unroll
-    for (int i = 0; i < 4; ++i)
+    for (int i = 0; i < RBW; ++i)
 #pragma unroll
         for (int j = 0; j < NBK; ++j)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-    const int pbase = ((4 * wave) * PW + li) * CIN;           // row block i adds i * PW * CIN
+    const int pbase = ((RBW * wave) * PW + li) * CIN;           // row block i adds i * PW * CIN
 #pragma unroll
     for (int s = 0; s < KS; ++s) {
-        float av[4];
+        float av[RBW];
 #pragma unroll
-        for (int i = 0; i < 4; ++i) av[i] = s_in[koff[s] >= 0 ? pbase + i * PW * CIN + koff[s] : NPIX * CIN];
+        for (int i = 0; i < RBW; ++i) av[i] = s_in[koff[s] >= 0 ? pbase + i * PW * CIN + koff[s] : NPIX * CIN];
 #pragma unroll
-        for (int i = 0; i < 4; ++i)
+        for (int i = 0; i < RBW; ++i)
 #pragma unroll
             for (int j = 0; j < NBK; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[i], bw[s][j], acc[i][j], 0, 0, 0);
     }
@@ -200,8 +210,8 @@ __global__ __launch_bounds__(256) void conv3x3_first_mfma(const uint8_t *__restr
     OT *const Ts = s_out[wave];
     const __amdgpu_buffer_rsrc_t out_rsrc = __builtin_amdgcn_make_buffer_rsrc(out + (size_t)b * H * W * ldo, 0, H * W * ldo * 2, 0x00020000);
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const int y = y0 + 4 * wave + i;
+    for (int i = 0; i < RBW; ++i) {
+        const int y = y0 + RBW * wave + i;
 #pragma unroll
         for (int j = 0; j < NBK; ++j) {
             const float sh = 32 * j + li < Cout ? shift[32 * j + li] : 0.f;
@@ -226,14 +236,17 @@ template <typename OT>
 static hipError_t launch_first_mfma_t(const uint8_t *img, const float *lut256, const float *w, const float *shift, OT *out,
                                       int B, int H, int W, int Cin, int Cout, int ldo, hipStream_t s)
 {
-    const int tiles_x = (W + 31) / 32, tiles_y = (H + 15) / 16;
+    // row blocks per wave: 2 (8-row tiles: 68-112 registers, five to seven waves per SIMD) measured 0.242 -> 0.223 ms on config
+    // 5's first layer against 4 (16-row tiles, 116-192 registers), same card; MIUNET_FIRST_RBW=4 keeps the taller tile
+    static const int rbw = [] { const char *e = getenv("MIUNET_FIRST_RBW"); return (e && atoi(e) == 4) ? 4 : 2; }();
+    const int tiles_x = (W + 31) / 32, tiles_y = (H + 4 * rbw - 1) / (4 * rbw);
     const long long blocks = (long long)B * tiles_x * tiles_y;
     if (blocks <= 0 || blocks > 0x7FFFFFFFLL) return hipErrorInvalidValue;
     const dim3 g((unsigned)blocks), t(256);
-    if (Cin == 1 && Cout <= 32) hipLaunchKernelGGL((conv3x3_first_mfma<1, 1, OT>), g, t, 0, s, img, lut256, w, shift, out, H, W, Cout, ldo, tiles_x, tiles_y);
-    else if (Cin == 1) hipLaunchKernelGGL((conv3x3_first_mfma<1, 2, OT>), g, t, 0, s, img, lut256, w, shift, out, H, W, Cout, ldo, tiles_x, tiles_y);
-    else if (Cout <= 32) hipLaunchKernelGGL((conv3x3_first_mfma<3, 1, OT>), g, t, 0, s, img, lut256, w, shift, out, H, W, Cout, ldo, tiles_x, tiles_y);
-    else hipLaunchKernelGGL((conv3x3_first_mfma<3, 2, OT>), g, t, 0, s, img, lut256, w, shift, out, H, W, Cout, ldo, tiles_x, tiles_y);
+    if (Cin == 1 && Cout <= 32) { if (rbw == 2) hipLaunchKernelGGL((conv3x3_first_mfma<1, 1, 2, OT>), g, t, 0, s, img, lut256, w, shift, out, H, W, Cout, ldo, tiles_x, tiles_y); else hipLaunchKernelGGL((conv3x3_first_mfma<1, 1, 4, OT>), g, t, 0, s, img, lut256, w, shift, out, H, W, Cout, ldo, tiles_x, tiles_y); }
+    else if (Cin == 1) { if (rbw == 2) hipLaunchKernelGGL((conv3x3_first_mfma<1, 2, 2, OT>), g, t, 0, s, img, lut256, w, shift, out, H, W, Cout, ldo, tiles_x, tiles_y); else hipLaunchKernelGGL((conv3x3_first_mfma<1, 2, 4, OT>), g, t, 0, s, img, lut256, w, shift, out, H, W, Cout, ldo, tiles_x, tiles_y); }
+    else if (Cout <= 32) { if (rbw == 2) hipLaunchKernelGGL((conv3x3_first_mfma<3, 1, 2, OT>), g, t, 0, s, img, lut256, w, shift, out, H, W, Cout, ldo, tiles_x, tiles_y); else hipLaunchKernelGGL((conv3x3_first_mfma<3, 1, 4, OT>), g, t, 0, s, img, lut256, w, shift, out, H, W, Cout, ldo, tiles_x, tiles_y); }
+    else { if (rbw == 2) hipLaunchKernelGGL((conv3x3_first_mfma<3, 2, 2, OT>), g, t, 0, s, img, lut256, w, shift, out, H, W, Cout, ldo, tiles_x, tiles_y); else hipLaunchKernelGGL((conv3x3_first_mfma<3, 2, 4, OT>), g, t, 0, s, img, lut256, w, shift, out, H, W, Cout, ldo, tiles_x, tiles_y); }
     return hipGetLastError();
 }
 
