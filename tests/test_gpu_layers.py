@@ -207,7 +207,7 @@ def test_maxpool(B, H, W, C):
 
 
 @pytest.mark.parametrize("B,H,W,Cin,Cout", [
-    (1, 16, 32, 1, 64),        # exactly one 16 x 32 tile of the MFMA form
+    (1, 16, 32, 1, 64),        # exactly two 8 x 32 tiles of the MFMA form
     (2, 37, 70, 1, 64),        # ragged in x and y
     (1, 40, 96, 3, 32),        # BASELINE config 5's first layer (K = 27: one padded K step)
     (1, 9, 33, 3, 64),
