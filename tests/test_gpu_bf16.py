@@ -324,3 +324,36 @@ def test_resident_weight_convT_in_the_whole_network(algo, monkeypatch):
             used[mode] = [s["kernel"] for s in eng.kernel_stats() if s["kernel"].startswith("convT") and s["kernel"].endswith("r")]
     assert used["0"] == [] and used["2"] == [f"convT2x2_{algo}r"] * 3
     assert np.array_equal(out["0"][1], out["2"][1]) and np.array_equal(out["0"][0], out["2"][0])
+
+
+@pytest.mark.parametrize("seed", range(12))
+def test_resident_weight_kernels_random_shapes(seed):
+    """Random batch / height / width (odd sizes, tiles past both image edges, tile counts that do not divide by the persistent
+    grid) for every shape the resident-weight kernels take: 3x3 conv, its fused pooling (even sizes) and the transposed conv,
+    each bit-identical to the one-tile-per-workgroup kernel."""
+    r = np.random.default_rng(1000 + seed)
+    kind = ("conv", "pool", "convT")[seed % 3]
+    fp16 = bool(r.integers(0, 2))
+    sfx = "fp16" if fp16 else "bf16"
+    B = int(r.integers(1, 4))
+    if kind == "convT":
+        Cin, Cout = [(64, 32), (128, 64), (256, 128)][int(r.integers(0, 3))]
+        H, W = int(r.integers(1, 40)), int(r.integers(1, 100))
+        x = r.standard_normal((B, H, W, Cin), dtype=np.float32)
+        w = (r.standard_normal((Cin, Cout, 2, 2), dtype=np.float32) / np.sqrt(Cin)).astype(np.float32)
+        bias = (0.1 * r.standard_normal(Cout)).astype(np.float32)
+        got = binding.layer_debug(f"convT2x2_{sfx}r_lpout", x, w, None, bias)
+        ref = binding.layer_debug(f"convT2x2_{sfx}_lpout", x, w, None, bias)
+    else:
+        Cin, Cout = [(32, 32), (32, 64), (64, 32), (64, 64)][int(r.integers(0, 4))]
+        H, W = int(r.integers(1, 60)), int(r.integers(1, 140))
+        if kind == "pool":
+            H, W = 2 * ((H + 1) // 2), 2 * ((W + 1) // 2)
+        x = r.standard_normal((B, H, W, Cin), dtype=np.float32)
+        w = (r.standard_normal((Cout, Cin, 3, 3), dtype=np.float32) * np.sqrt(2.0 / (9 * Cin))).astype(np.float32)
+        shift = (0.1 * r.standard_normal(Cout)).astype(np.float32)
+        op = "_pool_lpout" if kind == "pool" else "_lpout"
+        got = binding.layer_debug(f"conv3x3_{sfx}r{op}", x, w, None, shift, relu=True)
+        ref = binding.layer_debug(f"conv3x3_{sfx}{op}", x, w, None, shift, relu=True)
+    assert not np.isnan(got).any(), (kind, B, H, W, Cin, Cout)
+    assert np.array_equal(got, ref), (kind, B, H, W, Cin, Cout)
