@@ -22,7 +22,7 @@ def test_no_wide_store_data_hazard(src, tmp_path):
     import scan_store_hazard
     asm = tmp_path / (src + ".s")
     flags = ["-O3", "-std=c++17", "--offload-arch=gfx950", "-S", "--cuda-device-only"]
-XX
+    if src == "conv_wino4.hip":                # the Makefile's extra flag for this file
         flags += ["-mllvm", "-pragma-unroll-threshold=1000000"]
     subprocess.run([HIPCC, *flags, "-o", str(asm), os.path.join(CSRC, src)], check=True, capture_output=True, timeout=600)
     hits = scan_store_hazard.scan(str(asm))
