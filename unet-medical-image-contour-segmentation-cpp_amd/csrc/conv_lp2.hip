@@ -202,6 +202,53 @@ __global__ __launch_bounds__(256, 1) void conv3x3_lp2(const ConvArgs a, const in
         }
     };
     const bool interior = x0 + 32 <= a.W && y0 + TH <= a.H;
+    // 16-bit outputs leave through LDS (the patch buffers are dead: the K loop ended with a barrier): a wave drops one 32-pixel x
+    // 32-channel block at a time into its own [pixel][32 + 8 pad] tile with 2-byte writes and stores it as 16-byte pieces -- 32
+    // (+ 8 pooled) store instructions per wave and tile instead of 256 (+ 128).  Needs 16-byte aligned channel offsets.
+    if constexpr (OUT_LP) {
+        if (a.Cout % 8 == 0 && a.ldo % 8 == 0 && a.co_off % 8 == 0 && (!do_pool || a.pool_ld % 8 == 0)) {
+            typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+            constexpr int TROW = 40;
+            T *const Ts = As + wave * (48 * TROW);       // [32 pixels][TROW] + pooled [16][TROW], wave-private
+            T *const Ps = Ts + 32 * TROW;
+#pragma unroll
+            for (int j = 0; j < NT; ++j) {
+                const int co = n0 + 32 * j + li;
+                const float sh = co < a.Cout ? a.bias[co] : 0.f;
+#pragma unroll
+                for (int i = 0; i < MT; ++i) {
+#pragma unroll
+                    for (int r = 0; r < 16; ++r)
+                        Ts[((r & 3) + 8 * (r >> 2) + 4 * lh) * TROW + li] = (T)fmaxf(acc[i][j][r] + sh, relu_lo);
+                    if (do_pool && (i & 1)) {     // rows i - 1 and i: the 2 x 2 blocks of (r, r + 1) of both; pooled column x >> 1
+#pragma unroll
+                        for (int r = 0; r < 16; r += 2) {
+                            const float mx = fmaxf(fmaxf(acc[i - 1][j][r], acc[i - 1][j][r + 1]), fmaxf(acc[i][j][r], acc[i][j][r + 1]));
+                            Ps[((((r & 3) + 8 * (r >> 2)) >> 1) + 2 * lh) * TROW + li] = (T)fmaxf(mx + sh, relu_lo);
+                        }
+                    }
+#pragma unroll
+                    for (int it = 0; it < 2; ++it) {
+                        const int e = lane + 64 * it, m = e >> 2, q = e & 3;
+                        const u32x4 v = *reinterpret_cast<const u32x4 *>(Ts + m * TROW + 8 * q);
+                        const bool ok = yw + i < a.H && x0 + m < a.W && n0 + 32 * j + 8 * q < a.Cout;
+                        __builtin_amdgcn_raw_buffer_store_b128(v, out_rsrc,
+                            ok ? (unsigned)((((yw + i) * a.W + x0 + m) * a.ldo + a.co_off + n0 + 32 * j + 8 * q) * 2) : 0xFFFFFFFFu, 0, 0);
+                        wide_store_guard();
+                    }
+                    if (do_pool && (i & 1)) {
+                        const int m = lane >> 2, q = lane & 3;              // 16 pooled pixels x 4 pieces = 64 lanes
+                        const u32x4 v = *reinterpret_cast<const u32x4 *>(Ps + m * TROW + 8 * q);
+                        const bool ok = yw + i < a.H && x0 + 2 * m + 1 < a.W && n0 + 32 * j + 8 * q < a.Cout;
+                        __builtin_amdgcn_raw_buffer_store_b128(v, pool_rsrc,
+                            ok ? (unsigned)(((((yw + i) >> 1) * Wp + (x0 >> 1) + m) * a.pool_ld + n0 + 32 * j + 8 * q) * 2) : 0xFFFFFFFFu, 0, 0);
+                        wide_store_guard();
+                    }
+                }
+            }
+            return;
+        }
+    }
 #pragma unroll
     for (int j = 0; j < NT; ++j) {
         const int co = n0 + 32 * j + li;
