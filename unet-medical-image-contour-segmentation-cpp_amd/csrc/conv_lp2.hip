@@ -297,8 +297,8 @@ static hipError_t launch_lp2_cfg(const ConvArgs &a, hipStream_t s)
 }
 
 // Which layers it takes (measured per layer at batch 16, r02): faster than the 2 x 2 kernel of conv_lp.hip from Cin = 256 up
-// (down4.c2 0.280 -> 0.226 ms, up1.c1 0.552 -> 0.459), level with it at Cin = 128, slower below (fewer chunks to amortise its
-// 256-store epilogue).  MIUNET_LP2: 0 = never; 2 = every Cout % 128 == 0 layer whatever its size (parity tests).
+// (down4.c2 0.280 -> 0.226 ms, up1.c1 0.552 -> 0.459), 3-5 % faster at Cin = 128 with the LDS-transposed stores (level with the
+// 256-store epilogue it had first), slower below.  MIUNET_LP2: 0 = never; 2 = every Cout % 128 == 0 layer whatever its size (parity tests).
 bool conv3x3_lp2_takes(const ConvArgs &a)
 {
     const char *e = getenv("MIUNET_LP2");
@@ -306,7 +306,10 @@ bool conv3x3_lp2_takes(const ConvArgs &a)
     if (a.head_w != nullptr || a.Cout % 128 != 0 || a.Cin % 8 || a.CoutPad % NPAD) return false;
     if (e && e[0] == '2') return true;
     const long long nwg = (long long)((a.W + 31) / 32) * ((a.H + LP2::TH - 1) / LP2::TH) * a.B * (a.Cout / 128);
-    return a.Cin >= 256 && nwg >= 192;
+    // from Cin = 128 since the 16-byte-store epilogue (same card, config 3: down1.c2 0.333 -> 0.322 ms, up3.c2 0.313 -> 0.298, down2.c1
+    // 0.159 -> 0.154; config 5 unchanged); MIUNET_LP2_MINCIN moves the threshold
+    static const int min_cin = [] { const char *m = getenv("MIUNET_LP2_MINCIN"); return m ? atoi(m) : 128; }();
+    return a.Cin >= min_cin && nwg >= 192;
 }
 
 hipError_t launch_conv3x3_lp2(const ConvArgs &a, bool fp16, hipStream_t s)
