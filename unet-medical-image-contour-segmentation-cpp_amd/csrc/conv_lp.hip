@@ -193,6 +193,15 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_bf16(const ConvArgs a, const
     constexpr int TROW = BN + 8;                            // 16-bit elements per pixel row of the output tile
     T *const Ts = reinterpret_cast<T *>(lds);               // [TH * 32][TROW], then the pooled tile [TH * 8][TROW]
     T *const Ps = Ts + TH * 32 * TROW;
+    // the shifts of this lane's channels, loaded BEFORE the first store (a load issued behind stores makes hipcc wait for
+    // vmcnt(0): for every store in flight)
+    float shj[NT];
+#pragma unroll
+    for (int j = 0; j < NT; ++j) {
+        const int n = n0 + 32 * j + li;
+        const bool n_ok = (TAPS == 9) ? (n < a.Cout) : (n < 4 * a.Cout);
+        shj[j] = n_ok ? a.bias[(TAPS == 9) ? n : n % a.Cout] : 0.f;
+    }
     auto epilogue = [&](auto lds_tag) {           // one straight-line copy per route: no per-store branches
     constexpr bool TO_LDS = decltype(lds_tag)::value;
 #pragma unroll
@@ -207,7 +216,7 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_bf16(const ConvArgs a, const
             oy_off = kidx >> 1; ox_off = kidx & 1;
         }
         const bool n_ok = (TAPS == 9) ? (n < a.Cout) : (n < 4 * a.Cout);
-        const float sh = n_ok ? a.bias[co] : 0.f;
+        const float sh = shj[j];
         // per-lane byte offset of (row yw, column x0 + 4 lh) [conv] or of its 2x2 output block's (oy_off, ox_off) pixel [convT]
         const unsigned vbase = !n_ok ? 0xFFFFFFFFu
             : (TAPS == 9) ? (unsigned)(((yw * a.W + x0 + 4 * lh) * a.ldo + a.co_off + co) * ES)

@@ -202,6 +202,11 @@ __global__ __launch_bounds__(256, 1) void conv3x3_lp2(const ConvArgs a, const in
         }
     };
     const bool interior = x0 + 32 <= a.W && y0 + TH <= a.H;
+    // the four shifts of this lane's channels, loaded BEFORE the first store: a load issued behind stores makes hipcc wait for
+    // vmcnt(0), i.e. for every store in flight (measured with s_memtime stamps: the epilogue was 14.8 k cycles of a 120 k tile)
+    float shj[NT];
+#pragma unroll
+    for (int j = 0; j < NT; ++j) shj[j] = n0 + 32 * j + li < a.Cout ? a.bias[n0 + 32 * j + li] : 0.f;
     // 16-bit outputs leave through LDS (the patch buffers are dead: the K loop ended with a barrier): a wave drops one 32-pixel x
     // 32-channel block at a time into its own [pixel][32 + 8 pad] tile with 2-byte writes and stores it as 16-byte pieces -- 32
     // (+ 8 pooled) store instructions per wave and tile instead of 256 (+ 128).  Needs 16-byte aligned channel offsets.
@@ -213,8 +218,7 @@ __global__ __launch_bounds__(256, 1) void conv3x3_lp2(const ConvArgs a, const in
             T *const Ps = Ts + 32 * TROW;
 #pragma unroll
             for (int j = 0; j < NT; ++j) {
-                const int co = n0 + 32 * j + li;
-                const float sh = co < a.Cout ? a.bias[co] : 0.f;
+                const float sh = shj[j];
 #pragma unroll
                 for (int i = 0; i < MT; ++i) {
 #pragma unroll
@@ -253,7 +257,7 @@ __global__ __launch_bounds__(256, 1) void conv3x3_lp2(const ConvArgs a, const in
     for (int j = 0; j < NT; ++j) {
         const int co = n0 + 32 * j + li;
         const bool n_ok = co < a.Cout;
-        const float sh = n_ok ? a.bias[co] : 0.f;
+        const float sh = shj[j];
         const unsigned vbase = n_ok ? (unsigned)(((yw * a.W + x0 + 4 * lh) * a.ldo + a.co_off + co) * ES) : 0xFFFFFFFFu;
         if (do_pool) {
             const unsigned pbase = n_ok ? (unsigned)((((yw >> 1) * Wp + ((x0 + 4 * lh) >> 1)) * a.pool_ld + co) * ES) : 0xFFFFFFFFu;

@@ -167,13 +167,18 @@ __global__ __launch_bounds__(256, WPS) void convT2x2_taps_f32(const ConvArgs a, 
     const __amdgpu_buffer_rsrc_t out_rsrc = __builtin_amdgcn_make_buffer_rsrc(
         a.out + (size_t)b * 4 * a.H * a.W * a.ldo, 0, 4 * a.H * a.W * a.ldo * 4, 0x00020000);
     const unsigned pix_bytes = (unsigned)a.ldo * 4;
+    // this lane's biases, loaded BEFORE the first store: a load issued behind stores makes hipcc wait for vmcnt(0), i.e. for
+    // every store in flight, once per channel block
+    float biasv[NBK];
+#pragma unroll
+    for (int nb = 0; nb < NBK; ++nb) biasv[nb] = ncol0 + 32 * nb < a.Cout ? a.bias[ncol0 + 32 * nb] : 0.f;
     auto epilogue = [&](auto interior_tag) {
         constexpr bool INTERIOR = decltype(interior_tag)::value;
 #pragma unroll
         for (int nb = 0; nb < NBK; ++nb) {
             const int ncol = ncol0 + 32 * nb;
             const bool n_ok = ncol < a.Cout;
-            const float bias = n_ok ? a.bias[ncol] : 0.f;
+            const float bias = biasv[nb];
             // per-lane part: its column group (4 lh), the tap's (dy, dx) displacement, the channel
             const unsigned vbase = n_ok ? (unsigned)((((2 * y0 + dy) * W2 + 2 * (x0 + 4 * lh) + dx) * a.ldo + a.co_off + ncol) * 4) : 0xFFFFFFFFu;
 #pragma unroll
