@@ -17,9 +17,11 @@
 // path (4 KB per 16 MFMAs and wave = 32 B/clk per CU of the L1's 64).
 //
 // Workgroup = 4 waves = 16 rows x 32 columns of pixels x 128 output channels.  K is walked in chunks of 32 input channels:
-//   LDS: the 18 x 34 input patch of the chunk [pixel][32 + 8 pad], double-buffered (2 x 48,960 B); the next chunk's patch
-//        travels global -> registers at the start of a chunk and registers -> the other buffer at its end: ONE barrier per chunk
-//        = per 288 MFMAs of a wave;
+//   LDS: the 18 x 34 input patch of the chunk, 64 bytes per pixel, double-buffered (2 x 39,936 B); the next chunk's patch
+//        arrives by LDS-DMA (buffer_load ... lds, 16 bytes per lane: no staging registers, no ds_write), one load per group of
+//        16 MFMAs; rows cannot be padded that way, so the four 16-byte pieces of pixel p sit in slots piece ^ ((p >> 1) & 3)
+//        (conflict-free ds_read_b128; conv_lpr.hip).  ONE barrier per chunk = per 288 MFMAs of a wave.  (Register-staged
+//        patches in 80-byte padded rows, the first form of this kernel, measured 0.6-0.75 % slower on config 3, same card.)
 //   per chunk and wave: 18 groups (9 taps x 2 halves) of 4 ds_read_b128 + 4 buffer_load_b128 + 16 MFMAs; the patch fragments
 //        are read one group ahead, the weight fragments three.
 // Same arithmetic as conv_mfma_bf16 (same products, fp32 accumulation in k order inside a tap, taps in raster order, chunks in
@@ -45,12 +47,11 @@ __device__ __forceinline__ f32x16 mfma_lp2(Lp2Vec<_Float16>::x8 a, Lp2Vec<_Float
 
 struct LP2 {
     static constexpr int TH = 16, MT = 4;
-    static constexpr int ROW = KC_BF16 + 8;                  // 16-bit elements per LDS row (80 bytes: conflict-free b128 reads)
+    static constexpr int ROW = KC_BF16;                      // 16-bit elements per pixel (64 bytes, unpadded: pieces are swizzled)
     static constexpr int PW = 34, PH = TH + 2, NPIX = PW * PH;
-    static constexpr int A_ELEMS = NPIX * ROW;               // per patch buffer
-    static constexpr int NA8 = NPIX * 4;                     // 16-byte pieces of a patch
-    static constexpr int A_ITERS = (NA8 + 255) / 256;        // 10
-    static constexpr size_t lds_bytes(bool dbuf) { return 2 * (size_t)A_ELEMS * (dbuf ? 2 : 1); }
+    static constexpr int A_LOADS = (NPIX + 15) / 16;         // wave-wide LDS-DMA loads of 16 pixels
+    static constexpr int A_ELEMS = A_LOADS * 16 * ROW;       // per patch buffer (39 KB)
+    static constexpr size_t LDS_BYTES = 2 * 2 * (size_t)A_ELEMS;      // two patch buffers of 16-bit elements
 };
 
 // (A 4 x 2 variant -- 64 output channels, 128 accumulator registers, two workgroups per CU with one patch buffer each -- was
@@ -62,8 +63,6 @@ __global__ __launch_bounds__(256, 1) void conv3x3_lp2(const ConvArgs a, const in
     typedef typename Lp2Vec<T>::x8 x8;
     constexpr int ROW = LP2::ROW, PW = LP2::PW, MT = LP2::MT, BN = 32 * NT, TH = LP2::TH;
     static_assert(NT == 4, "4 x 4 blocks of 32 x 32 per wave");
-    constexpr bool DBUF = true;
-    constexpr int A_ITERS = LP2::A_ITERS;
     static_assert(18 % WD == 0, "ring depth must divide the group count");
     extern __shared__ __attribute__((aligned(16))) float lds[];
     T *const As = reinterpret_cast<T *>(lds);                // [2][NPIX][ROW]
@@ -82,36 +81,26 @@ __global__ __launch_bounds__(256, 1) void conv3x3_lp2(const ConvArgs a, const in
     const int x0 = tx * 32, y0 = ty * TH, n0 = n_tile * BN;
     const T *in_img = reinterpret_cast<const T *>(a.in) + (size_t)b * a.H * a.W * a.ldc;
 
-    // ---- patch staging map: 4 pieces of 8 channels per pixel
-    // (the LDS offset of piece s is linear in s -- pixel (tid >> 2) + 64 s -- so only the global offsets take registers)
-    int a_goff[A_ITERS];
+    // ---- patch loads: LDS-DMA (buffer_load ... lds, 16 bytes per lane: no staging registers, no ds_write); load i = wave + 4 k
+    // covers pixels 16 i .. + 16, lane l = (pixel l >> 2, slot l & 3), the piece in slot s of pixel p is piece s ^ ((p >> 1) & 3)
+    typedef __attribute__((address_space(3))) void *lds_ptr;
+    constexpr int DMA_ITERS = (LP2::A_LOADS + 3) / 4;
+    unsigned dvoff[DMA_ITERS];
 #pragma unroll
-    for (int s = 0; s < A_ITERS; ++s) {
-        const int e = tid + 256 * s;
-        const int pix = e >> 2, q = e & 3;
-        const int py = pix / PW, px = pix - py * PW;
+    for (int k = 0; k < DMA_ITERS; ++k) {
+        const int i = wave + 4 * k;
+        const int p = 16 * i + (lane >> 2), q = (lane & 3) ^ ((p >> 1) & 3);
+        const int py = p / PW, px = p - py * PW;
         const int gy = y0 - 1 + py, gx = x0 - 1 + px;
-        const bool inb = e < LP2::NA8 && gy >= 0 && gy < a.H && gx >= 0 && gx < a.W;
-        a_goff[s] = inb ? (gy * a.W + gx) * a.ldc + 8 * q : -1;
+        const bool inb = i < LP2::A_LOADS && p < LP2::NPIX && gy >= 0 && gy < a.H && gx >= 0 && gx < a.W;
+        dvoff[k] = inb ? (unsigned)(((gy * a.W + gx) * a.ldc + 8 * q) * 2) : 0xFFFFFFFFu;
     }
-    const int a_loff0 = (tid >> 2) * ROW + 8 * (tid & 3);
-    x8 a_reg[A_ITERS];
-    auto load_a = [&](int chunk) {
-        const int c0 = chunk * KC_BF16;
-#pragma unroll
-        for (int s = 0; s < A_ITERS; ++s) {
-            const int q8 = 8 * ((tid + 256 * s) & 3);
-            x8 v;
-#pragma unroll
-            for (int k = 0; k < 8; ++k) v[k] = (T)0.f;
-            if (a_goff[s] >= 0 && c0 + q8 < a.Cin) v = *reinterpret_cast<const x8 *>(in_img + a_goff[s] + c0);
-            a_reg[s] = v;
+    const __amdgpu_buffer_rsrc_t in_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<T *>(in_img), 0, a.H * a.W * a.ldc * 2, 0x00020000);
+    auto dma_a = [&](int chunk, int buf, int k) {             // this wave's k-th load of a chunk's patch
+        if (wave + 4 * k < LP2::A_LOADS) {
+            const unsigned voff = (chunk * KC_BF16 + 8 * ((lane & 3) ^ ((lane >> 3) & 3)) < a.Cin) ? dvoff[k] : 0xFFFFFFFFu;      // (a partial last chunk)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(in_rsrc, (lds_ptr)(As + buf * LP2::A_ELEMS + (wave + 4 * k) * 16 * ROW), 16, voff, chunk * KC_BF16 * 2, 0, 0);
         }
-    };
-    auto store_a = [&](int buf) {
-#pragma unroll
-        for (int s = 0; s < A_ITERS; ++s)
-            if (tid + 256 * s < LP2::NA8) *reinterpret_cast<x8 *>(As + buf * LP2::A_ELEMS + a_loff0 + 64 * s * ROW) = a_reg[s];
     };
 
     // ---- weight fragments straight from global memory: packed [chunk][tap][CoutPad][32]; lane (li, lh) of block j wants the
@@ -134,31 +123,39 @@ __global__ __launch_bounds__(256, 1) void conv3x3_lp2(const ConvArgs a, const in
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-    const T *a_frag = As + ((wave * MT) * PW + li) * ROW + 8 * lh;          // + abuf*A_ELEMS + ((i + dy)*PW + dx)*ROW + 16 g
-    load_a(0);
+    unsigned aoff[6][3];                          // byte offset of piece lh (g = 0; g = 1 is ^ 32) of pixel (4 wave + r) * 34 + li + dx
+#pragma unroll
+    for (int r = 0; r < 6; ++r)
+#pragma unroll
+        for (int dx = 0; dx < 3; ++dx) {
+            const int p = (wave * MT + r) * PW + li + dx;
+            aoff[r][dx] = (unsigned)(p * 64 + ((lh ^ ((p >> 1) & 3)) << 4));
+        }
+#pragma unroll
+    for (int k = 0; k < DMA_ITERS; ++k) dma_a(0, 0, k);
     x8 wf[WD][NT];
 #pragma unroll
     for (int k = 0; k < WD; ++k)
 #pragma unroll
         for (int j = 0; j < NT; ++j) wf[k][j] = w_load(0, k, j);
-    store_a(0);
+    __builtin_amdgcn_s_waitcnt(0x0F70 | ((WD * NT) & 15) | (((WD * NT) >> 4) << 14));      // the patch is older than the ring
     __syncthreads();
     for (int chunk = 0; chunk < nchunks; ++chunk) {
-        const int abuf = DBUF ? (chunk & 1) : 0;
+        const int abuf = chunk & 1;
         const bool more = chunk + 1 < nchunks;
         const int nxt = more ? chunk + 1 : chunk;                          // the last chunk prefetches itself: straight-line code
-        if (more) load_a(chunk + 1);              // global -> registers; they land during this chunk's 288 MFMAs
-        const T *af0 = a_frag + abuf * LP2::A_ELEMS;
+        const unsigned abase = (unsigned)(abuf * LP2::A_ELEMS * 2);
         auto read_a = [&](int grp, x8 *af) {      // patch fragments of group grp = 2 tap + g
             const int tap = grp >> 1, g = grp & 1, dy = tap / 3, dx = tap - 3 * dy;
 #pragma unroll
-            for (int i = 0; i < MT; ++i) af[i] = *reinterpret_cast<const x8 *>(af0 + ((i + dy) * PW + dx) * ROW + 16 * g);
+            for (int i = 0; i < MT; ++i) af[i] = *reinterpret_cast<const x8 *>(reinterpret_cast<const char *>(As) + ((abase + aoff[i + dy][dx]) ^ (g ? 32u : 0u)));
         };
         x8 af[2][MT];
         read_a(0, af[0]);
 #pragma unroll
         for (int k = 0; k < 18; ++k) {
             if (k + 1 < 18) read_a(k + 1, af[(k + 1) & 1]);               // one group ahead (LDS latency)
+            if (more && k < DMA_ITERS) dma_a(chunk + 1, abuf ^ 1, k);      // the next patch, one load per group
             __builtin_amdgcn_sched_barrier(0);    // ... issued here, not sunk next to their use
 #pragma unroll
             for (int i = 0; i < MT; ++i)
@@ -169,14 +166,9 @@ __global__ __launch_bounds__(256, 1) void conv3x3_lp2(const ConvArgs a, const in
             for (int j = 0; j < NT; ++j) wf[k % WD][j] = w_load(kn < 18 ? chunk : nxt, kn % 18, j);
             __builtin_amdgcn_sched_barrier(0);
         }
-        if constexpr (DBUF) {
-            if (more) store_a(abuf ^ 1);          // the other buffer: its last readers passed the previous barrier
-            __syncthreads();
-        } else {
-            __syncthreads();                      // every wave is done reading the one buffer
-            if (more) store_a(0);
-            __syncthreads();
-        }
+        // this wave's patch loads are older than the weight ring (the youngest WD * NT loads): landed
+        __builtin_amdgcn_s_waitcnt(0x0F70 | ((WD * NT) & 15) | (((WD * NT) >> 4) << 14));
+        __syncthreads();
     }
 
     // ---- epilogue: + shift, ReLU, (16-bit rounding), buffer stores.  Lane = channel li of block j, register r = pixel
@@ -216,6 +208,8 @@ __global__ __launch_bounds__(256, 1) void conv3x3_lp2(const ConvArgs a, const in
             constexpr int TROW = 40;
             T *const Ts = As + wave * (48 * TROW);       // [32 pixels][TROW] + pooled [16][TROW], wave-private
             T *const Ps = Ts + 32 * TROW;
+            auto lds_epilogue = [&](auto interior_tag) {      // interior tiles: no per-store edge predicates (Cout % 128 == 0: no channel ones either)
+            constexpr bool INTERIOR = decltype(interior_tag)::value;
 #pragma unroll
             for (int j = 0; j < NT; ++j) {
                 const float sh = shj[j];
@@ -235,7 +229,7 @@ __global__ __launch_bounds__(256, 1) void conv3x3_lp2(const ConvArgs a, const in
                     for (int it = 0; it < 2; ++it) {
                         const int e = lane + 64 * it, m = e >> 2, q = e & 3;
                         const u32x4 v = *reinterpret_cast<const u32x4 *>(Ts + m * TROW + 8 * q);
-                        const bool ok = yw + i < a.H && x0 + m < a.W && n0 + 32 * j + 8 * q < a.Cout;
+                        const bool ok = INTERIOR || (yw + i < a.H && x0 + m < a.W);
                         __builtin_amdgcn_raw_buffer_store_b128(v, out_rsrc,
                             ok ? (unsigned)((((yw + i) * a.W + x0 + m) * a.ldo + a.co_off + n0 + 32 * j + 8 * q) * 2) : 0xFFFFFFFFu, 0, 0);
                         wide_store_guard();
@@ -243,13 +237,16 @@ __global__ __launch_bounds__(256, 1) void conv3x3_lp2(const ConvArgs a, const in
                     if (do_pool && (i & 1)) {
                         const int m = lane >> 2, q = lane & 3;              // 16 pooled pixels x 4 pieces = 64 lanes
                         const u32x4 v = *reinterpret_cast<const u32x4 *>(Ps + m * TROW + 8 * q);
-                        const bool ok = yw + i < a.H && x0 + 2 * m + 1 < a.W && n0 + 32 * j + 8 * q < a.Cout;
+                        const bool ok = INTERIOR || (yw + i < a.H && x0 + 2 * m + 1 < a.W);
                         __builtin_amdgcn_raw_buffer_store_b128(v, pool_rsrc,
                             ok ? (unsigned)(((((yw + i) >> 1) * Wp + (x0 >> 1) + m) * a.pool_ld + n0 + 32 * j + 8 * q) * 2) : 0xFFFFFFFFu, 0, 0);
                         wide_store_guard();
                     }
                 }
             }
+            };
+            if (interior) lds_epilogue(std::true_type{});
+            else lds_epilogue(std::false_type{});
             return;
         }
     }
@@ -288,7 +285,7 @@ template <typename T, bool OUT_LP, int NT>
 static hipError_t launch_lp2_cfg(const ConvArgs &a, hipStream_t s)
 {
     constexpr int BN = 32 * NT;
-    constexpr size_t lds_bytes = LP2::lds_bytes(NT == 4);
+    constexpr size_t lds_bytes = LP2::LDS_BYTES;
     const int tiles_x = (a.W + 31) / 32, tiles_y = (a.H + LP2::TH - 1) / LP2::TH;
     const int m_tiles = tiles_x * tiles_y * a.B;
     const int n_tiles = (a.Cout + BN - 1) / BN;
