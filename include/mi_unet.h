@@ -153,6 +153,36 @@ int mi_unet_get_kernel_stats(mi_unet_t *h, mi_unet_kernel_stat *stats, int cap, 
 int mi_unet_layer_debug(int device, const char *op, const float *in, int B, int H, int W, int Cin, const float *w,
                         const float *scale, const float *shift, int Cout, int relu, float *out);
 
+/* In-situ parity hook (tests): what the engine's OWN launch plan does to its OWN activations, layer by layer, at any size.
+ * The opaque seam this opens is the reference's graph replay (src/process.cpp:143-155), whose intermediate tensors nobody
+ * can see.  A "layer" is one step of the plan in launch order (inc.c1, inc.c2, down1.pool, down1.c1, ... outc+argmax);
+ * steps whose work is fused into their producer (pooling, the head) are listed and flagged `skipped`.
+ *   mi_unet_debug_layer_count : number of steps
+ *   mi_unet_debug_layer_info  : static description of step `layer` (shapes are per image)
+ *   mi_unet_debug_capture     : uploads B <= max_batch images, runs the plan EAGERLY with exactly the kernels a batch of B
+ *       takes, stops after step `layer`, and returns for image `img` of the batch, converted to float, dense NHWC:
+ *         in     [in_h][in_w][in_c]      the tensor the step's kernel read (u8 image values 0..255 for the first layer)
+ *         out    [out_h][out_w][out_c]   what it stored; when the step ran the fused 1x1 head instead (info->fused_head),
+ *                                        the planar logits [classes][out_h][out_w]
+ *         pooled [out_h/2][out_w/2][out_c] the fused 2x2 max-pooled tensor (only when info->pooled; may be NULL)
+ *         labels [out_h][out_w]          argmax labels (only for head / fused-head steps; may be NULL)
+ *       and in *info the dynamic facts: kernel family launched, storage width of the tensors in HBM, flags. */
+typedef struct mi_unet_layer_info {
+    char name[48];
+    char kernel[32];       /* kernel family launched (capture only) */
+    int kind;              /* 0 first conv, 1 conv3x3, 2 convT2x2, 3 maxpool2x2, 4 head+argmax */
+    int in_h, in_w, in_c;
+    int out_h, out_w, out_c;
+    int in_bits, out_bits; /* 8 = u8 image, 16 = bf16 / fp16 (per conv_algo), 32 = fp32: storage type in HBM (capture only) */
+    int pooled;            /* the step also stored the 2x2 max-pooled tensor */
+    int fused_head;        /* the step ran the 1x1 head + argmax in its epilogue; its own activations never reached HBM */
+    int skipped;           /* not launched at this batch size: fused into its producer */
+} mi_unet_layer_info;
+int mi_unet_debug_layer_count(const mi_unet_t *h);
+int mi_unet_debug_layer_info(const mi_unet_t *h, int layer, mi_unet_layer_info *info);
+int mi_unet_debug_capture(mi_unet_t *h, const uint8_t *imgs, int B, int layer, int img, float *in, float *out, float *pooled,
+                          uint8_t *labels, mi_unet_layer_info *info);
+
 /* A second context on the SAME device that shares the source engine's weight blob (no second copy, no re-packing) but
  * owns its activation buffers, stream and graphs -- the counterpart of the reference's per-thread TensorRTContext over one
  * shared ICudaEngine (include/process.h:13-26, src/process.cpp:15, :69).  max_batch <= 0 keeps the source's.  The weights

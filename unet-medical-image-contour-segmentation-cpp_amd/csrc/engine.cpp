@@ -109,6 +109,14 @@ struct mi_unet {
     std::vector<hipEvent_t> ev_pool;
     size_t ev_used = 0;
     hipEvent_t tev0 = nullptr, tev1 = nullptr;
+    // mi_unet_debug_capture: stop launch_plan after step `layer` and hand its operands of image `img` to the host
+    struct Tap {
+        int layer = -1, img = 0;
+        float *in = nullptr, *out = nullptr, *pooled = nullptr;
+        uint8_t *labels = nullptr;
+        mi_unet_layer_info *info = nullptr;
+        bool hit = false;
+    } tap;
 };
 
 namespace {
@@ -540,15 +548,61 @@ int run_microbatch(mi_unet *h, const uint8_t *d_imgs, int B, uint8_t *d_labels, 
     return 0;
 }
 
+// one image's [npix][C] tensor (pixel stride `ld` elements of `bits` bits, kind: 1 = bf16, 2 = fp16 for 16-bit storage) -> dense floats
+int download_tensor(hipStream_t s, const void *d, int bits, int lp_kind, size_t npix, int C, int ld, float *dst)
+{
+    if (!dst) return 0;
+    const size_t eb = (size_t)bits / 8;
+    std::vector<unsigned char> raw(npix * C * eb);
+    HIP_TRY(hipStreamSynchronize(s));
+    HIP_TRY(hipMemcpy2D(raw.data(), C * eb, d, (size_t)ld * eb, C * eb, npix, hipMemcpyDeviceToHost));
+    const size_t n = npix * C;
+    if (bits == 32) memcpy(dst, raw.data(), n * 4);
+    else if (bits == 8) for (size_t i = 0; i < n; ++i) dst[i] = (float)raw[i];
+    else {
+        const uint16_t *r16 = reinterpret_cast<const uint16_t *>(raw.data());
+        for (size_t i = 0; i < n; ++i) dst[i] = lp_kind == 2 ? fp16_to_float(r16[i]) : bf16_to_float(r16[i]);
+    }
+    return 0;
+}
+
 int launch_plan(mi_unet *h, const uint8_t *d_imgs, int B, uint8_t *d_labels, float *d_logits)
 {
     hipStream_t s = h->stream;
     // 16-bit pipelines: every activation tensor is bf16 / fp16 in HBM except the last conv's output (the fp32 head's input)
     const int lp_kind = h->algo == MI_UNET_CONV_BF16 ? 1 : h->algo == MI_UNET_CONV_FP16 ? 2 : 0;
     bool head_done = false;
+    int step_index = -1;
     for (Step &st : h->plan) {
-        if (st.fused_away) continue;
-        if (st.kind == Step::HEAD && head_done) continue;
+        ++step_index;
+        const bool tapped = h->tap.layer == step_index;
+        if (st.fused_away || (st.kind == Step::HEAD && head_done)) {
+            if (tapped) { h->tap.info->skipped = 1; h->tap.hit = true; return 0; }
+            continue;
+        }
+        const bool head_was_done = head_done;
+        ConvArgs ta{};                             // the launched arguments of a tapped CONV / CONVT step
+        if (tapped) {                              // the tensor this step is about to read
+            const size_t im = (size_t)h->tap.img;
+            const int abits = lp_kind ? 16 : 32;
+            int rc = 0;
+            if (st.kind == Step::FIRST) {
+                h->tap.info->in_bits = 8;
+                rc = download_tensor(s, d_imgs + im * st.H * st.W * st.C, 8, 0, (size_t)st.H * st.W, st.C, st.C, h->tap.in);
+            } else if (st.kind == Step::CONV || st.kind == Step::CONVT) {
+                h->tap.info->in_bits = abits;
+                const size_t npix = (size_t)st.a.H * st.a.W;
+                rc = download_tensor(s, reinterpret_cast<const char *>(st.a.in) + im * npix * st.a.ldc * (abits / 8), abits, lp_kind, npix,
+                                     st.a.Cin, st.a.ldc, h->tap.in);
+            } else {                               // POOL (activation type), HEAD (always fp32)
+                const int b = st.kind == Step::HEAD ? 32 : abits;
+                h->tap.info->in_bits = b;
+                const size_t npix = (size_t)st.H * st.W;
+                const int ld = st.kind == Step::HEAD ? st.C : st.ld;
+                rc = download_tensor(s, reinterpret_cast<const char *>(st.src) + im * npix * ld * (b / 8), b, lp_kind, npix, st.C, ld, h->tap.in);
+            }
+            if (rc) return rc;
+        }
         hipEvent_t e0 = nullptr, e1 = nullptr;
         if (h->profiling) {
             while (h->ev_pool.size() < h->ev_used + 2) {
@@ -610,6 +664,7 @@ int launch_plan(mi_unet *h, const uint8_t *d_imgs, int B, uint8_t *d_labels, flo
                 else { kname = "conv3x3_wino"; e = launch_conv3x3_wino(a, s); }
             }
             else { kname = "conv3x3_mfma"; e = launch_conv3x3_mfma(a, s); }
+            ta = a;
             break;
         }
         case Step::CONVT: {
@@ -623,6 +678,7 @@ int launch_plan(mi_unet *h, const uint8_t *d_imgs, int B, uint8_t *d_labels, flo
             else if (h->algo == MI_UNET_CONV_FP16) { kname = "convT2x2_fp16"; e = launch_convT2x2_fp16(a, s); }
             else if (a.wpk4 != nullptr && convT_taps_grid(a) >= 128) { kname = "convT2x2_taps"; e = launch_convT2x2_taps(a, s); }
             else { kname = "convT2x2_mfma"; e = launch_convT2x2_mfma(a, s); }
+            ta = a;
             break;
         }
         case Step::POOL:
@@ -636,6 +692,46 @@ int launch_plan(mi_unet *h, const uint8_t *d_imgs, int B, uint8_t *d_labels, flo
             break;
         }
         if (e != hipSuccess) return fail(MI_UNET_EHIP, "launch " + st.name + ": " + hipGetErrorString(e));
+        if (tapped) {                              // what the step stored
+            mi_unet_layer_info *ti = h->tap.info;
+            snprintf(ti->kernel, sizeof ti->kernel, "%s", kname);
+            const size_t im = (size_t)h->tap.img;
+            const int abits = lp_kind ? 16 : 32;
+            const int classes = h->cfg.classes;
+            int rc = 0;
+            if (st.kind == Step::HEAD || (st.kind == Step::CONV && head_done && !head_was_done)) {
+                const size_t hw = (size_t)h->cfg.height * h->cfg.width;
+                ti->fused_head = st.kind == Step::CONV;
+                ti->out_bits = 32;
+                if (d_logits) rc = download_tensor(s, d_logits + im * classes * hw, 32, 0, classes * hw, 1, 1, h->tap.out);
+                if (!rc && h->tap.labels) {
+                    HIP_TRY(hipStreamSynchronize(s));
+                    HIP_TRY(hipMemcpy(h->tap.labels, d_labels + im * hw, hw, hipMemcpyDeviceToHost));
+                }
+            } else if (st.kind == Step::FIRST) {
+                ti->out_bits = abits;
+                const size_t npix = (size_t)st.H * st.W;
+                rc = download_tensor(s, reinterpret_cast<const char *>(st.dst) + im * npix * st.ld * (abits / 8), abits, lp_kind, npix, st.Cout, st.ld, h->tap.out);
+            } else if (st.kind == Step::CONV || st.kind == Step::CONVT) {
+                const int ob = (lp_kind && ta.out_lp) ? 16 : 32;
+                ti->out_bits = ob;
+                const size_t npix = (size_t)ta.H * ta.W * (st.kind == Step::CONVT ? 4 : 1);
+                rc = download_tensor(s, reinterpret_cast<const char *>(ta.out) + (im * npix * ta.ldo + ta.co_off) * (ob / 8), ob, lp_kind, npix, ta.Cout,
+                                     ta.ldo, h->tap.out);
+                if (!rc && st.kind == Step::CONV && ta.pool_out) {
+                    ti->pooled = 1;
+                    rc = download_tensor(s, reinterpret_cast<const char *>(ta.pool_out) + im * (npix / 4) * ta.pool_ld * (ob / 8), ob, lp_kind, npix / 4,
+                                         ta.Cout, ta.pool_ld, h->tap.pooled);
+                }
+            } else {                               // POOL
+                ti->out_bits = abits;
+                const size_t npix = (size_t)(st.H / 2) * (st.W / 2);
+                rc = download_tensor(s, reinterpret_cast<const char *>(st.dst) + im * npix * st.C * (abits / 8), abits, lp_kind, npix, st.C, st.C, h->tap.out);
+            }
+            if (rc) return rc;
+            h->tap.hit = true;
+            return 0;
+        }
         if (h->profiling) {
             HIP_TRY(hipEventRecord(e1, s));
             mi_unet_kernel_stat ks{};
@@ -1346,6 +1442,49 @@ done:
     if (d_w) (void)hipFree(d_w);
     if (d_b) (void)hipFree(d_b);
     return rc;
+}
+
+int mi_unet_debug_layer_count(const mi_unet_t *h) { return h ? (int)h->plan.size() : 0; }
+
+int mi_unet_debug_layer_info(const mi_unet_t *h, int layer, mi_unet_layer_info *info)
+{
+    if (!h || !info) return fail(MI_UNET_EARG, "mi_unet_debug_layer_info: null argument");
+    if (!h->weights_loaded) return fail(MI_UNET_ESTATE, "Engine not initialized: load weights before inference");
+    if (layer < 0 || layer >= (int)h->plan.size()) return fail(MI_UNET_EARG, "mi_unet_debug_layer_info: no such layer");
+    const Step &st = h->plan[layer];
+    *info = mi_unet_layer_info{};
+    snprintf(info->name, sizeof info->name, "%s", st.name.c_str());
+    switch (st.kind) {
+    case Step::FIRST: info->kind = 0; info->in_h = info->out_h = st.H; info->in_w = info->out_w = st.W; info->in_c = st.C; info->out_c = st.Cout; break;
+    case Step::CONV: info->kind = 1; info->in_h = info->out_h = st.a.H; info->in_w = info->out_w = st.a.W; info->in_c = st.a.Cin; info->out_c = st.a.Cout; break;
+    case Step::CONVT: info->kind = 2; info->in_h = st.a.H; info->in_w = st.a.W; info->out_h = 2 * st.a.H; info->out_w = 2 * st.a.W; info->in_c = st.a.Cin; info->out_c = st.a.Cout; break;
+    case Step::POOL: info->kind = 3; info->in_h = st.H; info->in_w = st.W; info->out_h = st.H / 2; info->out_w = st.W / 2; info->in_c = info->out_c = st.C; break;
+    case Step::HEAD: info->kind = 4; info->in_h = info->out_h = st.H; info->in_w = info->out_w = st.W; info->in_c = st.C; info->out_c = st.Cout; break;
+    }
+    return MI_UNET_OK;
+}
+
+int mi_unet_debug_capture(mi_unet_t *h, const uint8_t *imgs, int B, int layer, int img, float *in, float *out, float *pooled,
+                          uint8_t *labels, mi_unet_layer_info *info)
+{
+    if (int rc = check_handle(h, true)) return rc;
+    if (!imgs || !info || B < 1 || B > h->cfg.max_batch || img < 0 || img >= B)
+        return fail(MI_UNET_EARG, "mi_unet_debug_capture: bad argument (1 <= B <= max_batch, 0 <= img < B)");
+    if (int rc = mi_unet_debug_layer_info(h, layer, info)) return rc;
+    HIP_TRY(hipSetDevice(h->cfg.device));
+    const size_t in_bytes = (size_t)B * h->cfg.height * h->cfg.width * h->cfg.in_ch;
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    HIP_TRY(hipMemcpy(h->d_img, imgs, in_bytes, hipMemcpyHostToDevice));
+    h->tap = mi_unet::Tap{};
+    h->tap.layer = layer; h->tap.img = img; h->tap.in = in; h->tap.out = out; h->tap.pooled = pooled; h->tap.labels = labels; h->tap.info = info;
+    const int rc = launch_plan(h, h->d_img, B, h->d_labels, h->d_logits);       // eager: the kernels a batch of B takes
+    const bool hit = h->tap.hit;
+    h->tap = mi_unet::Tap{};
+    const hipError_t es = hipStreamSynchronize(h->stream);
+    if (rc) return rc;
+    if (es != hipSuccess) return fail(MI_UNET_EHIP, std::string("hipStreamSynchronize: ") + hipGetErrorString(es));
+    if (!hit) return fail(MI_UNET_ESTATE, "mi_unet_debug_capture: the plan never reached the layer");
+    return MI_UNET_OK;
 }
 
 void mi_unet_destroy(mi_unet_t *h)

@@ -2,9 +2,12 @@
 
 #include <zlib.h>
 
+#include <algorithm>
 #include <cstdio>
 #include <cstring>
 #include <fstream>
+#include <functional>
+#include <thread>
 #include <vector>
 
 namespace medseg {
@@ -30,7 +33,52 @@ int paeth(int a, int b, int c)
     return (pa <= pb && pa <= pc) ? a : (pb <= pc ? b : c);
 }
 
+// IDAT payload = the zlib stream of the filtered rows (filter byte 0 + samples), built in bands of whole rows that are
+// converted and deflated independently and then concatenated (the pigz construction: every band but the last ends in a sync
+// flush, i.e. on a byte boundary with no final block; the Adler-32 of the whole and the chunk's CRC-32 are combined from the
+// bands').  Any inflater reads it as one ordinary stream.  Bands run on their own threads unless the caller already is one of
+// several parallel writers (directory mode writes its images in parallel: `threads` = 1 there).
+struct Band {
+    int r0 = 0, r1 = 0;
+    std::vector<uint8_t> out;
+    uLong adler = 1, crc = 0;
+    size_t raw_len = 0;
+    bool ok = false;
+};
+
+void deflate_band(const Image8 &img, Band &bd, int level, int strategy, bool last)
+{
+    const size_t stride = (size_t)img.cols * img.channels;
+    std::vector<uint8_t> raw((stride + 1) * (bd.r1 - bd.r0));
+    for (int y = bd.r0; y < bd.r1; ++y) {
+        uint8_t *d = &raw[(stride + 1) * (y - bd.r0)];
+        *d++ = 0;                                                    // filter type None
+        if (img.channels == 1) {
+            memcpy(d, img.ptr(y), stride);
+        } else {                                                     // memory is B,G,R (OpenCV order); PNG wants R,G,B
+            const uint8_t *s = img.ptr(y);
+            for (int x = 0; x < img.cols; ++x) { d[3 * x] = s[3 * x + 2]; d[3 * x + 1] = s[3 * x + 1]; d[3 * x + 2] = s[3 * x]; }
+        }
+    }
+    bd.raw_len = raw.size();
+    z_stream zs;
+    memset(&zs, 0, sizeof(zs));
+    if (deflateInit2(&zs, level, Z_DEFLATED, -15, 8, strategy) != Z_OK) return;
+    bd.out.resize(deflateBound(&zs, (uLong)raw.size()) + 16);
+    zs.next_in = raw.data(); zs.avail_in = (uInt)raw.size();
+    zs.next_out = bd.out.data(); zs.avail_out = (uInt)bd.out.size();
+    const int rc = deflate(&zs, last ? Z_FINISH : Z_SYNC_FLUSH);
+    bd.ok = last ? rc == Z_STREAM_END : (rc == Z_OK && zs.avail_in == 0 && zs.avail_out > 0);
+    bd.out.resize(zs.total_out);
+    deflateEnd(&zs);
+    bd.adler = adler32(adler32(0L, Z_NULL, 0), raw.data(), (uInt)raw.size());
+    bd.crc = crc32(crc32(0L, Z_NULL, 0), bd.out.data(), (uInt)bd.out.size());
+}
+
 }  // namespace
+
+static thread_local int t_png_threads = 8;
+void set_png_threads(int n) { t_png_threads = n < 1 ? 1 : n; }
 
 bool write_png(const std::string &path, const Image8 &img, bool level0)
 {
@@ -40,37 +88,43 @@ bool write_png(const std::string &path, const Image8 &img, bool level0)
     put32(ihdr, img.cols); put32(ihdr, img.rows);
     ihdr.push_back(8); ihdr.push_back(img.channels == 1 ? 0 : 2); ihdr.push_back(0); ihdr.push_back(0); ihdr.push_back(0);
     chunk(out, "IHDR", ihdr);
-    const size_t stride = (size_t)img.cols * img.channels;
-    std::vector<uint8_t> raw((stride + 1) * img.rows);
-    for (int y = 0; y < img.rows; ++y) {
-        raw[(stride + 1) * y] = 0;                                   // filter type None
-        if (img.channels == 1) {
-            memcpy(&raw[(stride + 1) * y + 1], img.ptr(y), stride);
-        } else {                                                     // memory is B,G,R (OpenCV order); PNG wants R,G,B
-            const uint8_t *s = img.ptr(y);
-            uint8_t *d = &raw[(stride + 1) * y + 1];
-            for (int x = 0; x < img.cols; ++x) { d[3 * x] = s[3 * x + 2]; d[3 * x + 1] = s[3 * x + 1]; d[3 * x + 2] = s[3 * x]; }
-        }
-    }
     // level 0 = stored blocks (the reference's IMWRITE_PNG_COMPRESSION 0 files); otherwise OpenCV's imwrite defaults:
-    // level 1 with the run-length strategy -- fast, and the compressed bytes are not part of any contract
-    z_stream zs;
-    memset(&zs, 0, sizeof(zs));
-    if (deflateInit2(&zs, level0 ? 0 : 1, Z_DEFLATED, 15, 8, level0 ? Z_DEFAULT_STRATEGY : Z_RLE) != Z_OK) return false;
-    std::vector<uint8_t> z(deflateBound(&zs, (uLong)raw.size()));
-    zs.next_in = raw.data(); zs.avail_in = (uInt)raw.size();
-    zs.next_out = z.data(); zs.avail_out = (uInt)z.size();
-    const int zrc = deflate(&zs, Z_FINISH);
-    const size_t zlen = zs.total_out;
-    deflateEnd(&zs);
-    if (zrc != Z_STREAM_END) return false;
-    z.resize(zlen);
-    chunk(out, "IDAT", z);
+    // level 1 with the run-length strategy -- fast, and the compressed bytes are not part of any contract (the pixels are)
+    const int level = level0 ? 0 : 1, strategy = level0 ? Z_DEFAULT_STRATEGY : Z_RLE;
+    const size_t total = ((size_t)img.cols * img.channels + 1) * img.rows;
+    int nb = level0 ? 1 : (int)std::min<size_t>((size_t)t_png_threads, std::max<size_t>(1, total / (64u << 10)));   // bands of >= 64 KB
+    nb = std::max(1, std::min(nb, img.rows));
+    std::vector<Band> bands(nb);
+    for (int b = 0; b < nb; ++b) {
+        bands[b].r0 = (int)((long long)img.rows * b / nb);
+        bands[b].r1 = (int)((long long)img.rows * (b + 1) / nb);
+    }
+    std::vector<std::thread> workers;
+    for (int b = 1; b < nb; ++b) workers.emplace_back(deflate_band, std::cref(img), std::ref(bands[b]), level, strategy, b == nb - 1);
+    deflate_band(img, bands[0], level, strategy, nb == 1);
+    for (std::thread &w : workers) w.join();
+    size_t zlen = 2 + 4;
+    for (const Band &bd : bands) { if (!bd.ok) return false; zlen += bd.out.size(); }
+    // the IDAT chunk, written in place: length, type, zlib header, bands, Adler-32, CRC-32 (combined from the pieces)
+    out.reserve(out.size() + zlen + 12 + 12);
+    put32(out, (uint32_t)zlen);
+    const uint8_t head[6] = { 'I', 'D', 'A', 'T', 0x78, 0x01 };      // deflate, 32 KB window, no dictionary, check bits
+    out.insert(out.end(), head, head + 6);
+    uLong crc = crc32(crc32(0L, Z_NULL, 0), head, 6), ad = bands[0].adler;
+    for (int b = 0; b < nb; ++b) {
+        out.insert(out.end(), bands[b].out.begin(), bands[b].out.end());
+        crc = crc32_combine(crc, bands[b].crc, (z_off_t)bands[b].out.size());
+        if (b) ad = adler32_combine(ad, bands[b].adler, (z_off_t)bands[b].raw_len);
+    }
+    const uint8_t tail[4] = { (uint8_t)(ad >> 24), (uint8_t)(ad >> 16), (uint8_t)(ad >> 8), (uint8_t)ad };
+    out.insert(out.end(), tail, tail + 4);
+    crc = crc32(crc, tail, 4);
+    put32(out, (uint32_t)crc);
     chunk(out, "IEND", {});
-    std::ofstream f(path, std::ios::binary | std::ios::trunc);
-    if (!f.is_open()) return false;
-    f.write(reinterpret_cast<const char *>(out.data()), (std::streamsize)out.size());
-    return f.good();
+    FILE *f = fopen(path.c_str(), "wb");
+    if (!f) return false;
+    const bool ok = fwrite(out.data(), 1, out.size(), f) == out.size();
+    return fclose(f) == 0 && ok;
 }
 
 Image8 read_png(const std::string &path, bool as_color)

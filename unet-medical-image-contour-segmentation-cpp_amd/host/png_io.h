@@ -10,6 +10,9 @@
 namespace medseg {
 
 bool write_png(const std::string &path, const Image8 &img, bool level0);
+// A deflated PNG is compressed in up to n bands of rows on n threads (default 8).  Per calling thread: directory mode, which
+// already writes its images on several host threads, sets 1 on those.
+void set_png_threads(int n);
 // as_color = false: cv::IMREAD_GRAYSCALE (colour inputs are reduced with OpenCV's integer BT.601 weights);
 // as_color = true : default cv::imread -> 3 channels in B,G,R order (gray replicated).  Empty image on failure.
 Image8 read_png(const std::string &path, bool as_color);

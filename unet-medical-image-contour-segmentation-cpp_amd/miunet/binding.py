@@ -19,6 +19,7 @@ EXPORTS = [
     "mi_unet_infer_u8", "mi_unet_infer_u8_device", "mi_unet_infer_raw16", "mi_unet_set_postprocess", "mi_unet_postprocess_masks", "mi_unet_extract_contours", "mi_unet_segment_raw16", "mi_unet_set_stream", "mi_unet_sync", "mi_unet_timer_begin",
     "mi_unet_timer_end", "mi_unet_set_profiling", "mi_unet_get_kernel_stats", "mi_unet_layer_debug", "mi_unet_destroy",
     "mi_unet_last_error", "mi_unet_device_count", "mi_unet_clone",
+    "mi_unet_debug_layer_count", "mi_unet_debug_layer_info", "mi_unet_debug_capture",
     "mi_unet_group_create", "mi_unet_group_clone", "mi_unet_group_size", "mi_unet_group_handle", "mi_unet_group_load_weights",
     "mi_unet_group_load_weights_from_memory", "mi_unet_group_set_gather", "mi_unet_group_set_postprocess",
     "mi_unet_group_weight_transport", "mi_unet_group_gather", "mi_unet_group_infer_u8", "mi_unet_group_infer_raw16",
@@ -34,6 +35,19 @@ class Config(C.Structure):
 class KernelStat(C.Structure):
     _fields_ = [("name", C.c_char * 48), ("kernel", C.c_char * 32), ("flops", C.c_double), ("bytes", C.c_double),
                 ("ms", C.c_float)]
+
+
+class LayerInfo(C.Structure):
+    _fields_ = [("name", C.c_char * 48), ("kernel", C.c_char * 32), ("kind", C.c_int), ("in_h", C.c_int), ("in_w", C.c_int),
+                ("in_c", C.c_int), ("out_h", C.c_int), ("out_w", C.c_int), ("out_c", C.c_int), ("in_bits", C.c_int),
+                ("out_bits", C.c_int), ("pooled", C.c_int), ("fused_head", C.c_int), ("skipped", C.c_int)]
+
+    KINDS = ("first", "conv3x3", "convT2x2", "maxpool", "head")
+
+    def as_dict(self):
+        d = {k: getattr(self, k) for k, _ in self._fields_}
+        d["name"], d["kernel"], d["kind"] = self.name.decode(), self.kernel.decode(), self.KINDS[self.kind]
+        return d
 
 
 class MiUnetError(RuntimeError):
@@ -78,6 +92,10 @@ def lib():
         L.mi_unet_default_config.argtypes = [C.POINTER(Config)]
         L.mi_unet_default_config.restype = None
         L.mi_unet_clone.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_void_p)]
+        L.mi_unet_debug_layer_count.argtypes = [C.c_void_p]
+        L.mi_unet_debug_layer_info.argtypes = [C.c_void_p, C.c_int, C.POINTER(LayerInfo)]
+        L.mi_unet_debug_capture.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p,
+                                            C.c_void_p, C.POINTER(LayerInfo)]
         L.mi_unet_group_create.argtypes = [C.POINTER(Config), C.POINTER(C.c_int), C.c_int, C.POINTER(C.c_void_p)]
         L.mi_unet_group_clone.argtypes = [C.c_void_p, C.POINTER(C.c_void_p)]
         L.mi_unet_group_size.argtypes = [C.c_void_p]
@@ -267,6 +285,39 @@ class Engine:
         ms = C.c_float()
         _check(lib().mi_unet_timer_end(self._h, C.byref(ms)))
         return float(ms.value)
+
+    def layers(self):
+        """the launch plan, step by step (mi_unet_debug_layer_info): list of dicts with name / kind / per-image shapes"""
+        out = []
+        for i in range(lib().mi_unet_debug_layer_count(self._h)):
+            info = LayerInfo()
+            _check(lib().mi_unet_debug_layer_info(self._h, i, C.byref(info)))
+            out.append(info.as_dict())
+        return out
+
+    def capture(self, imgs: np.ndarray, layer: int, img: int = 0):
+        """mi_unet_debug_capture: run the plan eagerly on `imgs` up to step `layer`; returns (info dict, in, out, pooled, labels)
+        of image `img` as float32 NHWC arrays (out = planar logits [classes,H,W] when the step ran the fused head)."""
+        imgs = np.ascontiguousarray(imgs, dtype=np.uint8)
+        st = LayerInfo()
+        _check(lib().mi_unet_debug_layer_info(self._h, layer, C.byref(st)))
+        x = np.empty((st.in_h, st.in_w, st.in_c), np.float32)
+        n_out = max(st.out_c, self.cfg.classes)
+        y = np.full(st.out_h * st.out_w * n_out, np.nan, np.float32)
+        p = np.full((st.out_h // 2, st.out_w // 2, st.out_c), np.nan, np.float32)
+        lab = np.full((st.out_h, st.out_w), 255, np.uint8)
+        info = LayerInfo()
+        _check(lib().mi_unet_debug_capture(self._h, _ptr(imgs), imgs.shape[0], layer, img, _ptr(x), _ptr(y), _ptr(p), _ptr(lab),
+                                           C.byref(info)))
+        d = info.as_dict()
+        if d["skipped"]:
+            return d, None, None, None, None
+        if d["fused_head"] or d["kind"] == "head":
+            y = y[: self.cfg.classes * st.out_h * st.out_w].reshape(self.cfg.classes, st.out_h, st.out_w)
+        else:
+            y = y[: st.out_h * st.out_w * st.out_c].reshape(st.out_h, st.out_w, st.out_c)
+            lab = None
+        return d, x, y, (p if d["pooled"] else None), lab
 
     def set_profiling(self, on: bool):
         _check(lib().mi_unet_set_profiling(self._h, int(on)))
