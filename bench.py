@@ -22,6 +22,10 @@ What is timed, in this order (DESIGN.md "Measurement" describes every field of t
   4. `e2e_host`    the same batch through mi_unet_infer_u8 (pinned H2D + D2H inside), N = 1 only
   5. `configs`     short driver-measured runs of BASELINE configs[2] (bf16, batch 128) and configs[4] (fp16, 1024^2 x 3)
   6. `pipeline`    RAW16 -> polygons in one device call next to the facade's host route and the all-CPU chain
+  6b. `group`      mi_unet_group_infer_u8 (the C++ host's own multi-GPU path, ONE process) on a batch of 512 over every visible
+                   device, both gather modes -- in a child process with a deadline
+  With N > 1 ranks (or BENCH_FORCE_DIST=1) `configs` carries BASELINE configs[3] measured in the same launch: global batch
+  512 in contiguous shards, label maps gathered over RCCL inside the timed region ("scaling": "strong").
   7. `cpu_baseline` the oracle on the host cores over a bounded sample of the same workload
 """
 import argparse
@@ -195,7 +199,9 @@ def roofline_from_stats(stats, spec_macs, ips_per_gpu, tag):
         "achieved": executed, "peak": peak, "unit": "TFLOP/s", "frac": executed / peak,
         "achieved_basis": "executed MFMA FLOPs = algorithmic (direct-convolution) FLOPs / winograd_reduction",
         "algorithmic_tflops": algorithmic, "winograd_reduction": red,
-        "traffic": rk.get("hbm_bytes_per_launch"), "mfma_busy": rk.get("mfma_busy"), "pmc_source": pmc_src,
+        "traffic": rk.get("hbm_bytes_per_launch"), "mfma_busy": rk.get("mfma_busy"),
+        "mfma_busy_at_measured_clock": rk.get("mfma_busy_at_measured_clock"), "clock_ghz_from_sq_busy": rk.get("clock_ghz_from_sq_busy"),
+        "pmc_source": pmc_src,
         "launches": len(dom), "avg_launch_ms": dom_ms / max(1, len(dom)),
         "avg_launch_gflop": dom_flops / max(1, len(dom)) / 1e9,
         "share_of_device_time": dom_ms / all_ms if all_ms else None,
@@ -295,6 +301,8 @@ def run_pipeline(binding, synth, dev_index, nimg=16):
             r.tofile(p)
             paths.append(p)
         ws, hs = [2048] * nimg, [1536] * nimg
+        os.environ["MEDSEG_DEVICES"] = "1"                          # this record is a ONE-GPU figure whatever the node holds
+        out["facade_devices"] = 1
         for route, env in (("facade_device", "0"), ("facade_host", "1")):
             for k in ("MEDSEG_HOST_PREPROCESS", "MEDSEG_HOST_POSTPROCESS", "MEDSEG_HOST_CONTOURS"):
                 os.environ[k] = env
@@ -328,6 +336,93 @@ def run_pipeline(binding, synth, dev_index, nimg=16):
     return out
 
 
+def group_child_main():
+    """`bench.py --group-child`: the C++ host's own multi-GPU path (mi_unet_group_*: ONE process, one worker thread per device,
+    weights packed once and sent device-to-device, contiguous image shards -- the slot of the reference's sequential file
+    loop, src/main.cpp:148-164) timed on BASELINE configs[3]'s batch of 512 over every visible device, both gather modes.
+    Runs as a child that the parent started BEFORE it touched the GPU and that waits on stdin until the parent's own timed
+    regions are over; its one JSON line goes back on stdout.  A hang in a transport that has never met a second GPU costs
+    this record (the parent kills the child by PID after a deadline), never the headline."""
+    line = sys.stdin.readline()
+    if not line.startswith("go"):
+        return 0
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import numpy as np
+    from miunet import binding, synth
+    from miunet.spec import UNetSpec, pack_weights
+    spec = UNetSpec()
+    rec = {"what": "mi_unet_group_infer_u8, one process, host buffers in / out (PCIe-inclusive)", "global_batch": 512}
+    try:
+        ndev = binding.device_count()
+        blob = pack_weights(spec, synth.make_weights(spec, 1234))
+        imgs = synth.make_images(512, 512, 512, 1, 0x5EED, "bytes")
+        plans = [("all_visible_devices", None, ndev)]
+        if ndev == 1:
+            plans.append(("two_ranks_sharing_device_0 (rehearsal of the shard logic on one card)", [0, 0], 2))
+        rec["visible_devices"] = ndev
+        rec["runs"] = []
+        ref = None
+        for name, devs, n in plans:
+            with binding.Group(512, 512, max_batch=16, devices=devs, n_devices=0 if devs is None else len(devs)) as g:
+                g.load_weights(blob)
+                run = {"group": name, "ranks": g.size, "weight_transport": g.weight_transport}
+                for mode in ("host", "xgmi"):
+                    try:
+                        g.set_gather(mode)
+                    except binding.MiUnetError as e:
+                        run[mode + "_gather"] = {"skipped": str(e)}
+                        continue
+                    g.infer(imgs[:32 * g.size])                               # warm-up: buffers, graphs
+                    t0 = time.perf_counter()
+                    labels, _ = g.infer(imgs)
+                    labels, _ = g.infer(imgs)
+                    dt = (time.perf_counter() - t0) / 2
+                    if ref is None:
+                        ref = labels.copy()
+                    run[mode + "_gather"] = {"images_per_s": 512 / dt, "ms_per_step": dt * 1e3, "labels_equal_first_run": bool(np.array_equal(labels, ref))}
+                rec["runs"].append(run)
+        rec["measured_on_more_than_one_device"] = bool(ndev > 1)
+    except Exception as e:
+        rec["error"] = repr(e)
+    sys.stdout.write(json.dumps(rec) + "\n")
+    sys.stdout.flush()
+    return 0
+
+
+def start_group_child():
+    """started before this process initialises the GPU (a later fork + exec would be an exec from a GPU process); idles on stdin"""
+    env = dict(os.environ)
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT", "BENCH_FORCE_DIST", "TORCHELASTIC_RUN_ID", "GROUP_RANK",
+              "LOCAL_WORLD_SIZE", "ROLE_RANK", "ROLE_WORLD_SIZE"):
+        env.pop(k, None)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    return subprocess.Popen([sys.executable, os.path.abspath(__file__), "--group-child"], stdin=subprocess.PIPE, stdout=subprocess.PIPE,
+                            stderr=sys.stderr, env=env, text=True)
+
+
+def finish_group_child(child, run, deadline_s=240):
+    """tell the idle child to run (or to leave), read its one line with a deadline, kill exactly that PID if it overruns"""
+    if child is None:
+        return None
+    try:
+        child.stdin.write("go\n" if run else "no\n")
+        child.stdin.flush()
+        child.stdin.close()
+    except Exception:
+        pass
+    if not run:
+        child.wait(timeout=30)
+        return None
+    try:
+        out, _ = child.communicate(timeout=deadline_s)
+        lines = [l for l in out.splitlines() if l.startswith("{")]
+        return json.loads(lines[-1]) if lines else {"error": f"group child exited {child.returncode} without a record"}
+    except subprocess.TimeoutExpired:
+        child.kill()
+        child.wait()
+        return {"error": f"group child exceeded {deadline_s} s and was killed (a transport that never met a second GPU may hang)"}
+
+
 def spawn_torchrun(args):
     """--gpus N > 1 without a torchrun environment: run the documented launch line as a child process (this process has
     not touched the GPU yet, and never replaces itself) and hand back its exit code."""
@@ -357,10 +452,18 @@ def main():
     ap.add_argument("--no-extras", action="store_true", help="skip the e2e_host / configs / pipeline records")
     ap.add_argument("--per-layer", action="store_true", help="also print a per-layer table to stderr")
     ap.add_argument("--conv-algo", choices=["auto", "direct", "winograd", "winograd16", "bf16", "fp16"], default="auto")
+    ap.add_argument("--no-group", action="store_true", help="skip the `group` record (mi_unet_group_* in one process)")
+    ap.add_argument("--group-child", action="store_true", help=argparse.SUPPRESS)
     args = ap.parse_args()
 
+    if args.group_child:
+        raise SystemExit(group_child_main())
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         raise SystemExit(spawn_torchrun(args))
+    # the `group` record's process: started now, while this process has not touched the GPU; it idles until told to run
+    default_workload = (args.in_ch, args.base, args.levels, args.size, args.conv_algo, args.global_batch) == (1, 64, 4, 512, "auto", 0)
+    want_group = (int(os.environ.get("RANK", "0")) == 0 and not args.no_group and not args.no_extras and default_workload)
+    group_child = start_group_child() if want_group else None
 
     # stdout carries exactly ONE line, the JSON record: everything libraries print while the bench runs (RCCL's version
     # banner at the first collective, the facade's per-image lines) goes to stderr instead
@@ -481,6 +584,46 @@ def main():
         eng.set_profiling(False)
         stream.synchronize()
 
+        # ---- 3b. BASELINE configs[3] in the same launch: a GLOBAL batch of 512 cut into contiguous shards (strong scaling),
+        # each rank walking its shard in micro-batches, the label maps gathered to rank 0 inside the timed region
+        cfg4 = None
+        if use_dist and default_workload and 512 % world == 0:
+            lo4, hi4 = shard.shard_range(512, rank, world)
+            B4 = hi4 - lo4
+            imgs4 = torch.from_numpy(synth.make_images(512, H, W, spec.in_ch, 0xC0F4, "bytes")[lo4:hi4]).to(dev)
+            labels4 = torch.empty((B4, H, W), dtype=torch.uint8, device=dev)
+            gathered4 = [torch.empty_like(labels4) for _ in range(world)] if rank == 0 else None
+
+            def step4():
+                eng.infer_device(imgs4.data_ptr(), B4, labels4.data_ptr(), 0)
+                dist.gather(labels4, gathered4, dst=0)
+
+            step4(); step4()                                       # every micro-batch key: eager once, captured once
+            fence()
+            t4 = time.perf_counter()
+            steps4 = 3
+            for _ in range(steps4):
+                step4()
+            fence()
+            d4 = torch.tensor([time.perf_counter() - t4], dtype=torch.float64, device=dev)
+            dist.all_reduce(d4, op=dist.ReduceOp.MAX)
+            sums4 = [torch.zeros(1, dtype=torch.int64, device=dev) for _ in range(world)]
+            dist.all_gather(sums4, labels4.to(torch.int64).sum().reshape(1))
+            ok4 = True
+            if rank == 0:
+                ok4 = all(int(gathered4[r].to(torch.int64).sum()) == int(sums4[r]) for r in range(world))
+                # the shard's first micro-batch against the SAME images run on their own (a different graph key, batch 16)
+                probe = torch.empty((min(16, B4), H, W), dtype=torch.uint8, device=dev)
+                eng.infer_device(imgs4.data_ptr(), probe.shape[0], probe.data_ptr(), 0)
+                stream.synchronize()
+                ok4 = ok4 and bool(torch.equal(probe, gathered4[0][: probe.shape[0]]))
+                cfg4 = {"config": "BASELINE.json configs[3]: global batch 512 x 512x512x1 fp32, contiguous shards of 512 / N images "
+                                  "per rank in micro-batches of 16, RCCL label-map gather to rank 0 inside the timed region",
+                        "scaling": "strong", "n_gpus": world, "value": 512 * steps4 / float(d4.item()), "unit": "images/s",
+                        "ms_per_step": float(d4.item()) / steps4 * 1e3, "steps": steps4, "warmup": 2, "images_per_rank": B4,
+                        "gathered_label_maps_verified": bool(ok4)}
+            del imgs4, labels4, gathered4
+
     if rank == 0:
         images = B * world * args.steps
         ips = images / dt
@@ -504,10 +647,18 @@ def main():
         }
         prof_ms = sum(s["ms"] for s in stats) / args.steps
         out["roofline"]["kernel_ms_per_step_eager_profiled"] = prof_ms
+        if cfg4 is not None:
+            out["configs"] = [cfg4]
         if args.per_layer:
             per_layer_table(stats, args.steps, dt / args.steps * 1e3)
     if use_dist:
+        # the process group ends HERE: ranks > 0 leave (their GPUs are free for the one-process group record below), rank 0
+        # goes on alone with the records that need no collective
         dist.barrier()
+        dist.destroy_process_group()
+    if rank != 0:
+        eng.close()
+        sys.exit(0)
 
     if rank == 0:
         extras = world == 1 and not args.no_extras and not use_dist
@@ -528,18 +679,21 @@ def main():
         if extras:
             stream2 = torch.cuda.Stream(dev)
             try:
-                out["configs"] = [
+                out["configs"] = out.get("configs", []) + [
                     run_config(binding, synth, torch, dev, stream2, "BASELINE.json configs[2]: batch 128 x 512x512x1, bf16 operands / "
                                "fp32 accumulate, micro-batches of 16", UNetSpec(1, 64, 4, 3), 512, 128, 16, "bf16", 5, 2, "bf16"),
                     run_config(binding, synth, torch, dev, stream2, "BASELINE.json configs[4] (network half): batch 8 x 1024x1024x3, "
                                "5-level base 32, fp16 operands / fp32 accumulate", UNetSpec(3, 32, 5, 3), 1024, 8, 8, "fp16", 20, 5, "fp16"),
                 ]
             except Exception as e:                                            # an extra record never costs the headline
-                out["configs"] = {"error": repr(e)}
+                out["configs"] = out.get("configs", []) + [{"error": repr(e)}]
             try:
                 out["pipeline"] = run_pipeline(binding, synth, local_rank)
             except Exception as e:
                 out["pipeline"] = {"error": repr(e)}
+        if group_child is not None:
+            # ---- 6b. the C++ host's own multi-GPU path, one process over every visible device (a child process; see group_child_main)
+            out["group"] = finish_group_child(group_child, run=True)
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(blob, H, W, spec.in_ch, oracle_s)
         else:
@@ -549,7 +703,7 @@ def main():
         bad = [k for k in ("parity",) if out.get(k) and not out[k]["ok"]]
         if extras and isinstance(out.get("configs"), list):           # recorded; only the headline and the exact pipeline gate the exit code
             for c in out["configs"]:
-                if not c["parity"]["ok"]:
+                if "parity" in c and not c["parity"]["ok"]:
                     print("parity of an extra config outside its tolerance: " + c["config"], file=sys.stderr)
         if extras and isinstance(out.get("pipeline"), dict) and "parity" in out["pipeline"] and not out["pipeline"]["parity"]["ok"]:
             bad.append("pipeline")
@@ -558,12 +712,6 @@ def main():
             rc = 3
         else:
             rc = 0
-    else:
-        eng.close()
-        rc = 0
-    if use_dist:
-        dist.barrier()
-        dist.destroy_process_group()
     sys.exit(rc)
 
 

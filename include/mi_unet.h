@@ -120,6 +120,18 @@ int mi_unet_segment_raw16(mi_unet_t *h, const uint16_t *const *raws, const int *
                           uint8_t *tiles, uint8_t *masks, int32_t *xy, int cap_points, int32_t *start, int cap_contours,
                           int32_t *counts);
 
+/* Device time of the stages of the LAST mi_unet_infer_raw16 / mi_unet_segment_raw16 call on this handle, in milliseconds, summed
+ * over its micro-batches (hipEvent pairs on the streams the stages run on; the upload / preprocess stage of micro-batch k + 1
+ * runs on a second stream under the network of micro-batch k, so the stages may add up to more than the call took).  The
+ * reference logs two durations per image (src/process.cpp:223-228, :245-253); these are the terms of its "Inference time". */
+#define MI_UNET_STAGE_UPLOAD_PRE 0   /* host staging copy + H2D + min/max + bilinear resample (f1) */
+#define MI_UNET_STAGE_NETWORK 1      /* UNet + argmax (graph replay) */
+#define MI_UNET_STAGE_POSTPROCESS 2  /* postprocess_mask (f2) */
+#define MI_UNET_STAGE_CONTOURS 3     /* mask_to_image + extract_contours (f3) */
+#define MI_UNET_STAGE_DOWNLOAD 4     /* D2H of tiles, masks / label maps, contours, logits */
+#define MI_UNET_N_STAGES 5
+int mi_unet_last_stage_ms(const mi_unet_t *h, float *ms /* [MI_UNET_N_STAGES] */);
+
 /* Use an external hipStream_t (e.g. the caller framework's current stream) instead of the engine's own. NULL restores it. */
 int mi_unet_set_stream(mi_unet_t *h, void *hip_stream);
 int mi_unet_sync(mi_unet_t *h);

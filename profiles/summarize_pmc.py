@@ -10,7 +10,10 @@ per-kernel summary that bench.py quotes in its `roofline` object:
                               (64 per v_mfma_f32_32x32x2_f32, 32 per v_mfma_f32_16x16x4_f32 and per 32x32x16 bf16 --
                               checked against instruction counts of kernels whose MFMA count is known), so
                               mfma_busy = cycles / (1024 SIMDs x launch duration x 2.4 GHz), the launch duration taken from
-                              the same pass's dispatch timestamps.
+                              the same pass's dispatch timestamps -- the fraction of the NOMINAL peak, comparable with
+                              bench.py's roofline.frac.  The chip runs these kernels below 2.4 GHz, so the same pass's
+                              SQ_BUSY_CYCLES gives the clock (clock_ghz_from_sq_busy) and
+                              mfma_busy_at_measured_clock = cycles / (1024 SIMDs x SQ_BUSY_CYCLES / 32 shader engines).
 
 The output records a hash of the kernel sources it was measured on; bench.py refuses to quote a summary whose hash is not
 the tree's.
@@ -27,7 +30,8 @@ import re
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 SIMDS = 256 * 4
-CLOCK_HZ = 2.4e9
+CLOCK_HZ = 2.4e9              # nominal; bench.py prices its peaks (157.3 TF fp32, 2.5 PF 16-bit dense) at this clock too
+SHADER_ENGINES = 32           # 8 XCDs x 4
 
 
 def kernel_source_sha():
@@ -117,6 +121,13 @@ def main():
             busy, d_ns = mean(c["SQ_VALU_MFMA_BUSY_CYCLES"]), mean(c["__dur"])
             rec = {"sq_launches_sampled": len(c["__dur"]), "avg_launch_ns_under_pmc": d_ns, "mfma_busy_cycles_per_launch": busy,
                    "mfma_busy": busy / (SIMDS * d_ns * 1e-9 * CLOCK_HZ)}
+            if c.get("SQ_BUSY_CYCLES"):
+                # the denominator at the clock the launch actually ran at: SQ_BUSY_CYCLES counts, per shader engine (32 on
+                # the chip), the cycles its sequencers had work -- for a launch that fills the chip that is the launch's
+                # length in shader clocks (2.27-2.30 GHz on every long kernel of r02m, not the nominal 2.4)
+                sq_cycles = mean(c["SQ_BUSY_CYCLES"]) / SHADER_ENGINES
+                rec["clock_ghz_from_sq_busy"] = sq_cycles / d_ns
+                rec["mfma_busy_at_measured_clock"] = busy / (SIMDS * sq_cycles)
             for n in sorted(names - {"SQ_VALU_MFMA_BUSY_CYCLES"}):
                 if c.get(n):
                     rec[n.lower() + "_per_launch"] = mean(c[n])

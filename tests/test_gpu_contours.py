@@ -80,10 +80,19 @@ def test_segment_raw16_whole_device_half_of_the_pipeline():
 
     spec = UNetSpec()
     blob = pack_weights(spec, synth.make_threshold_weights(spec))
-    raws = [synth.make_raw16(1536, 2048, seed=21), synth.make_raw16(600, 800, seed=41), np.full((64, 64), 7, np.uint16)]
+    # five images through micro-batches of 2, 2, 1: the upload + preprocessing of micro-batch k + 1 runs on the second stream into
+    # the other tile buffer while the network works on k (the third micro-batch waits for the first one's readers)
+    raws = [synth.make_raw16(1536, 2048, seed=21), synth.make_raw16(600, 800, seed=41), np.full((64, 64), 7, np.uint16),
+            synth.make_raw16(700, 900, seed=5), synth.make_raw16(1536, 2048, seed=22)]
     with binding.Engine(512, 512, max_batch=2) as eng:
         eng.load_weights(blob)
-        tiles, masks, cont = eng.segment_raw16(raws)
+        first = eng.segment_raw16(raws)
+        eng.segment_raw16(raws[::-1])                       # other data through the same buffers and graphs
+        tiles, masks, cont = eng.segment_raw16(raws)        # hipGraph replays by now
+        stages = eng.last_stage_ms()
+    assert np.array_equal(first[0], tiles) and np.array_equal(first[1], masks) and first[2] == cont
+    assert set(stages) == {"upload_preprocess", "network", "postprocess", "contours", "download"}
+    assert all(v > 0.0 for v in stages.values()) and stages["network"] > stages["postprocess"]
     n_with_contours = 0
     for i, raw in enumerate(raws):
         tile = orc.preprocess_raw(raw)

@@ -14,6 +14,17 @@ from miunet.spec import UNetSpec, pack_weights
 pytestmark = pytest.mark.gpu
 
 
+def _expect_polygon_artefacts(tmp_path, out_dir, base, tile, contours, ow, oh):
+    """<base>.json byte-identical to generate_json (src/mask2polygon.cpp:68-109) of the oracle's contours mapped by
+    map_contour_points (:41-63); <base>_contour_overlay.png pixel-identical to create_overlay_image's picture (:114-129)"""
+    want = tmp_path / f"want_{base}.json"
+    mapped = [orc.map_points(c, ow / 512.0, oh / 512.0) for c in contours]
+    hostlib.generate_json(mapped, str(want), base, ow, oh)
+    assert (out_dir / f"{base}.json").read_bytes() == want.read_bytes()
+    ov = np.array(Image.open(out_dir / f"{base}_contour_overlay.png"))                 # R,G,B
+    assert np.array_equal(ov[..., ::-1], hostlib.draw_overlay(tile, contours))           # B,G,R as cv::Mat holds it
+
+
 @pytest.mark.parametrize("host_pre,host_post", [("0", "0"), ("1", "1"), ("0", "1")])
 def test_process_single_image_end_to_end(tmp_path, capfd, monkeypatch, host_pre, host_post):
     monkeypatch.setenv("MEDSEG_HOST_POSTPROCESS", host_post)     # "0": postprocess_mask on the device behind the argmax
@@ -59,7 +70,10 @@ def test_process_single_image_end_to_end(tmp_path, capfd, monkeypatch, host_pre,
     got = [[tuple(p) for p in s["points"]] for s in doc["shapes"]]
     assert got == [orc.map_points(c, 2048 / 512.0, 1536 / 512.0) for c in contours]
     assert doc["version"] == "1.0.2.812" and doc["imagePath"] == "caseA.raw"
-    assert (out_dir / "caseA_contour_overlay.png").exists()
+    # A13 / A14 exactly, on the GPU route too: the polygon file byte for byte against generate_json of the ORACLE's mapped
+    # contours (whose layout tests/test_host_cpu.py pins to the reference's nlohmann header), the overlay pixel for pixel
+    # against the closed red polylines of the oracle's contours on the oracle's tile
+    _expect_polygon_artefacts(tmp_path, out_dir, "caseA", tile, contours, 2048, 1536)
 
     # a second image whose label map is erased by postprocess: still success, no JSON, no overlay (src/mask2polygon.cpp:183-186)
     dark = np.full((600, 800), 100, np.uint16)
@@ -79,6 +93,8 @@ def test_process_single_image_end_to_end(tmp_path, capfd, monkeypatch, host_pre,
                  "Inference time: ", "Total processing time: ", "Processing completed for: caseA",
                  "=== Cleaning Up Resources ===", "All resources cleaned up successfully"):
         assert line in log
+    if host_pre == "0" and host_post == "0":           # the all-device route also logs where the time went, stage by stage
+        assert "Stage times (ms): read " in log and "network " in log and "overlay.png+polygon.json " in log
     assert not hostlib.process_single_image(str(rp), 2048, 1536, str(out_dir))       # engine is gone again
 
 
@@ -117,6 +133,7 @@ def test_process_image_batch(tmp_path, monkeypatch, host_contours):
             ov = np.array(Image.open(out_dir / f"b{k}_contour_overlay.png"))
             red = (ov[..., 0] == 255) & (ov[..., 1] == 0) & (ov[..., 2] == 0)
             assert red.any() and np.array_equal(ov[~red][:, 0], tile[~red])
+            _expect_polygon_artefacts(tmp_path, out_dir, f"b{k}", tile, contours, w, h)
         else:
             assert not (out_dir / f"b{k}.json").exists()
     if host_contours == "0":

@@ -302,10 +302,10 @@ static hipError_t launch_lp2_cfg(const ConvArgs &a, hipStream_t s)
 // 256-store epilogue it had first), slower below.  MIUNET_LP2: 0 = never; 2 = every Cout % 128 == 0 layer whatever its size (parity tests).
 bool conv3x3_lp2_takes(const ConvArgs &a)
 {
-    const char *e = getenv("MIUNET_LP2");
-    if (e && e[0] == '0') return false;
+    const int mode = routing_of(a).lp2;
+    if (mode == 0) return false;
     if (a.head_w != nullptr || a.Cout % 128 != 0 || a.Cin % 8 || a.CoutPad % NPAD) return false;
-    if (e && e[0] == '2') return true;
+    if (mode == 2) return true;
     const long long nwg = (long long)((a.W + 31) / 32) * ((a.H + LP2::TH - 1) / LP2::TH) * a.B * (a.Cout / 128);
     // from Cin = 128 since the 16-byte-store epilogue (same card, config 3: down1.c2 0.333 -> 0.322 ms, up3.c2 0.313 -> 0.298, down2.c1
     // 0.159 -> 0.154; config 5 unchanged); MIUNET_LP2_MINCIN moves the threshold

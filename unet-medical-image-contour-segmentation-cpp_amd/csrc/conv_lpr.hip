@@ -351,25 +351,14 @@ __global__ __launch_bounds__(512, 1) void conv3x3_lpr(const ConvArgs a, const in
     }
 }
 
-static int lpr_cus()
-{
-    static int cus[64] = {};
-    int dev = 0;
-    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return 256;
-    if (cus[dev] == 0) {
-        hipDeviceProp_t p;
-        cus[dev] = (hipGetDeviceProperties(&p, dev) == hipSuccess && p.multiProcessorCount > 0) ? p.multiProcessorCount : 256;
-    }
-    return cus[dev];
-}
-
 template <typename T, int CIN, int NBT, int NBUF, int RB, bool HEAD = false>
 static hipError_t launch_lpr_cfg(const ConvArgs &a, hipStream_t s)
 {
     using GEO = LprGeom<RB>;
     const int tiles_x = (a.W + 31) / 32, tiles_y = (a.H + GEO::TH - 1) / GEO::TH;
     const int ntiles = tiles_x * tiles_y * a.B;
-    const int grid = ntiles < lpr_cus() ? ntiles : lpr_cus();
+    const int cus = routing_of(a).cus;
+    const int grid = ntiles < cus ? ntiles : cus;
     constexpr size_t lds = LPR::lds_bytes(GEO::PLANE_BYTES, CIN, NBUF, HEAD);
     static_assert(lds <= 160 * 1024, "LDS of one CU");
     auto kern = conv3x3_lpr<T, CIN, NBT, NBUF, RB, HEAD>;
@@ -399,18 +388,17 @@ static bool lpr_shape_ok(const ConvArgs &a)
 // (parity tests on small inputs)
 bool conv3x3_lpr_takes(const ConvArgs &a)
 {
-    const char *e = getenv("MIUNET_LPR");
-    const int mode = e ? atoi(e) : 1;
+    const Routing rt = routing_of(a);
+    const int mode = rt.lpr;
     if (mode == 0 || !lpr_shape_ok(a)) return false;
     const long long ntiles = (long long)((a.W + 31) / 32) * ((a.H + 15) / 16) * a.B;     // 16-row tiles (Cin = 32); twice as many of 8 rows
-    return mode == 2 || ntiles >= 4 * lpr_cus();
+    return mode == 2 || ntiles >= 4 * rt.cus;
 }
 
 template <typename T>
 static hipError_t launch_lpr(const ConvArgs &a, hipStream_t s)
 {
-    const char *rb_e = getenv("MIUNET_LPR_RB");             // 1: 8-row tiles for every shape (A/B, parity tests)
-    const int rb_env = rb_e ? atoi(rb_e) : 2;
+    const int rb_env = routing_of(a).lpr_rb;                // MIUNET_LPR_RB = 1: 8-row tiles for every shape (A/B, parity tests)
     // the fused head keeps 8-row tiles: with two row blocks its 96 head-weight registers spill, and scratch traffic shares
     // vmcnt with the patch DMA (the compiler's waits for it drain the ring: measured 0.27 -> 0.53 ms)
     if (a.head_w != nullptr) return launch_lpr_cfg<T, 32, 1, 4, 1, true>(a, s);

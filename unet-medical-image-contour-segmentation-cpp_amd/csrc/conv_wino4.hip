@@ -455,18 +455,6 @@ __global__ __launch_bounds__(256, 1) void conv3x3_wino4_f32(const ConvArgs a, co
     }   // persistent tile loop
 }
 
-static int persistent_cus()
-{
-    static int cus[64] = {};
-    int dev = 0;
-    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return 256;
-    if (cus[dev] == 0) {
-        hipDeviceProp_t p;
-        cus[dev] = (hipGetDeviceProperties(&p, dev) == hipSuccess && p.multiProcessorCount > 0) ? p.multiProcessorCount : 256;
-    }
-    return cus[dev];
-}
-
 template <int NB, bool HEAD>
 static hipError_t launch_wino4_cfg(const ConvArgs &a0, hipStream_t s)
 {
@@ -496,7 +484,8 @@ static hipError_t launch_wino4_cfg(const ConvArgs &a0, hipStream_t s)
     auto kern = conv3x3_wino4_f32<NB, HEAD, false>;
     if (hipError_t e = ensure_dynamic_lds(kern, W4::LDS_BYTES); e != hipSuccess) return e;
     // one-block variant: persistent, one workgroup per CU (144 KB of LDS each); two-block variant: one tile per workgroup
-    const int grid = (NB == 1 && nwg > persistent_cus()) ? persistent_cus() : nwg;
+    const int cus = routing_of(a).cus;
+    const int grid = (NB == 1 && nwg > cus) ? cus : nwg;
     hipLaunchKernelGGL(kern, dim3(grid), dim3(256), W4::LDS_BYTES, s, a, tiles_x, tiles_y, m_tiles, nwg);
     return hipGetLastError();
 }
@@ -506,15 +495,15 @@ static hipError_t launch_wino4_cfg(const ConvArgs &a0, hipStream_t s)
 // (MIUNET_WINO4S = 0: never; 2: every one-block case whatever its grid -- for parity tests on small shapes)
 bool conv3x3_wino4_runs_staged(const ConvArgs &a)
 {
-    const char *w4s = getenv("MIUNET_WINO4S");
-    const int staged = w4s ? atoi(w4s) : 1;
+    const Routing rt = routing_of(a);
+    const int staged = rt.wino4s;
     const int rem = a.Cout % 128;
     const long long wg1 = (long long)((a.W + 15) / 16) * ((a.H + 15) / 16) * a.B * ((a.Cout + 63) / 64);
     // ... and wider layers whose K loop is at most four chunks (down1.c1, 64 -> 128: 0.521 -> 0.488 ms); with eight chunks and
     // more the two-block kernel's shared forward transform wins (measured on every such layer: 7-20 % slower staged)
     const bool one_block = a.head_w != nullptr || !(a.Cout >= 128 && (rem == 0 || rem > 64)) || a.Cin <= 64;
     // a.ksplit_ws == nullptr is the batch-invariant mode (MIUNET_SPLITK=0): there the choice must not depend on the batch
-    return one_block && (staged == 2 || (staged == 1 && (wg1 >= 2 * persistent_cus() || a.ksplit_ws == nullptr)));
+    return one_block && (staged == 2 || (staged == 1 && (wg1 >= 2 * rt.cus || a.ksplit_ws == nullptr)));
 }
 
 hipError_t launch_conv3x3_wino4(const ConvArgs &a, hipStream_t s)

@@ -177,25 +177,14 @@ __global__ __launch_bounds__(512, 1) void convT2x2_lpr(const ConvArgs a, const i
     }
 }
 
-static int convt_lpr_cus()
-{
-    static int cus[64] = {};
-    int dev = 0;
-    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return 256;
-    if (cus[dev] == 0) {
-        hipDeviceProp_t p;
-        cus[dev] = (hipGetDeviceProperties(&p, dev) == hipSuccess && p.multiProcessorCount > 0) ? p.multiProcessorCount : 256;
-    }
-    return cus[dev];
-}
-
 template <typename T, int CIN, int NBW, bool COSPLIT>
 static hipError_t launch_convt_lpr_cfg(const ConvArgs &a, hipStream_t s)
 {
     constexpr int TR = 32 * 1024 / (CIN * 2) / 32;
     const int tiles_x = (a.W + 31) / 32, tiles_y = (a.H + TR - 1) / TR;
     const int ntiles = tiles_x * tiles_y * a.B;
-    const int grid = ntiles < convt_lpr_cus() ? ntiles : convt_lpr_cus();
+    const int cus = routing_of(a).cus;
+    const int grid = ntiles < cus ? ntiles : cus;
     constexpr size_t lds = 3 * 32 * 1024 + 8 * (size_t)(32 * (32 * NBW + 8) * 2);
     static_assert(lds <= 160 * 1024, "LDS of one CU");
     auto kern = convT2x2_lpr<T, CIN, NBW, COSPLIT>;
@@ -217,12 +206,12 @@ static bool convt_lpr_shape_ok(const ConvArgs &a)
 // MIUNET_CONVT_LPR = 0: never; 1 (default): those shapes when the tiles fill the chip four times over; 2: whatever the grid
 bool convT2x2_lpr_takes(const ConvArgs &a)
 {
-    const char *e = getenv("MIUNET_CONVT_LPR");
-    const int mode = e ? atoi(e) : 1;
+    const Routing rt = routing_of(a);
+    const int mode = rt.convt_lpr;
     if (mode == 0 || !convt_lpr_shape_ok(a)) return false;
     const int tr = 32 * 1024 / (a.Cin * 2) / 32;
     const long long ntiles = (long long)((a.W + 31) / 32) * ((a.H + tr - 1) / tr) * a.B;
-    return mode == 2 || ntiles >= 4 * convt_lpr_cus();
+    return mode == 2 || ntiles >= 4 * rt.cus;
 }
 
 template <typename T>

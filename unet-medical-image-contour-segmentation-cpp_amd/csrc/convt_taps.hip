@@ -232,8 +232,8 @@ static TapsShape taps_shape(const ConvArgs &a)
         return { 8, 2, 1 };
     }
     const TapsShape big = a.Cout > 256 ? TapsShape{ 1, 8, 2 } : a.Cout > 64 ? TapsShape{ 2, 4, 2 } : TapsShape{ 4, 2, 2 };
-    const char *small = getenv("MIUNET_CONVT_SMALL");        // 0: never shrink (parity tests of the large shapes on small inputs)
-    if (taps_grid(a, big) >= 192 || (small && small[0] == '0')) return big;
+    // MIUNET_CONVT_SMALL = 0: never shrink (parity tests of the large shapes on small inputs)
+    if (taps_grid(a, big) >= 192 || !routing_of(a).convt_small) return big;
     if (a.Cout > 64 && taps_grid(a, { 1, 4, 4 }) >= 192) return { 1, 4, 4 };
     return { 1, 2, 4 };
 }

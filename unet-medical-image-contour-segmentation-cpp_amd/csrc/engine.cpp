@@ -5,6 +5,7 @@
 // initialize_context's buffers/stream (src/process.cpp:45-120) and execute_inference (src/process.cpp:123-175).
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -64,6 +65,7 @@ struct mi_unet {
     bool fuse_pool = true;          // MIUNET_FUSE_POOL=0 keeps the stand-alone pooling kernel (A/B and parity checks)
     int wino4_min_wg = 256;         // MIUNET_WINO4_MIN_WG: smallest grid the F(4x4,3x3) kernel takes (else F(2x2) + split-K)
     bool wino4_splitk = true;       // MIUNET_WINO4_SPLITK=0: small grids go to the F(2x2) kernel's split-K instead
+    Routing routing;                // kernel-routing switches + CU count, resolved at create (kernels.h)
     // device memory
     // one blob: every packed tensor (single allocation -> one broadcast / one free).  Owned by `weights`, which clones of
     // this handle share (mi_unet_clone: the reference's engine is shared by its per-thread contexts, src/process.cpp:15, :69)
@@ -88,7 +90,17 @@ struct mi_unet {
     float *d_ksplit = nullptr;      // split-K slabs of the Winograd kernel (small batches / deep levels only)
     size_t ksplit_bytes = 0;
     int *d_cont = nullptr;          // contour outputs of mi_unet_extract_contours (grown on demand)
+    int *h_cont = nullptr;          // pinned mirror: one async D2H, then only the points that exist are copied to the caller
     size_t cont_cap = 0;            // ints
+    // RAW-in entry points: a second stream uploads and preprocesses micro-batch k+1 into the other tile buffer while the
+    // network of micro-batch k runs (d_img / d_img2 alternate)
+    hipStream_t pre_stream = nullptr;
+    uint8_t *d_img2 = nullptr;
+    hipEvent_t tile_ready[2] = {}, tile_free[2] = {};
+    // stage timing of the last RAW-in call (mi_unet_last_stage_ms): event pairs per micro-batch, summed
+    hipEvent_t stage_ev[6] = {};
+    hipEvent_t pre_ev[2][2] = {};
+    float stage_ms[MI_UNET_N_STAGES] = {};
     // pinned host staging (the reference used pageable std::vector, src/process.cpp:138,152)
     uint8_t *h_img = nullptr;
     uint8_t *h_labels = nullptr;
@@ -619,10 +631,10 @@ int launch_plan(mi_unet *h, const uint8_t *d_imgs, int B, uint8_t *d_labels, flo
         switch (st.kind) {
         case Step::FIRST:
             kname = "conv3x3_first";
-            e = launch_conv3x3_first(d_imgs, h->d_lut, st.w, st.shift, st.dst, B, st.H, st.W, st.C, st.Cout, st.ld, lp_kind, s);
+            e = launch_conv3x3_first(d_imgs, h->d_lut, st.w, st.shift, st.dst, B, st.H, st.W, st.C, st.Cout, st.ld, lp_kind, s, &h->routing);
             break;
         case Step::CONV: {
-            ConvArgs a = st.a; a.B = B;
+            ConvArgs a = st.a; a.B = B; a.rt = h->routing;
             a.ksplit_ws = h->d_ksplit; a.ksplit_ws_bytes = h->ksplit_bytes;
             a.out_lp = (lp_kind != 0 && !st.feeds_head) ? 1 : 0;
             if (lp_kind != 0 && st.head_step >= 0) {   // fused 1x1 head + argmax: this layer's activations never reach HBM
@@ -668,7 +680,7 @@ int launch_plan(mi_unet *h, const uint8_t *d_imgs, int B, uint8_t *d_labels, flo
             break;
         }
         case Step::CONVT: {
-            ConvArgs a = st.a; a.B = B;
+            ConvArgs a = st.a; a.B = B; a.rt = h->routing;
             a.out_lp = lp_kind != 0 ? 1 : 0;
             if (lp_kind != 0 && convT2x2_lpr_takes(a)) {          // the large 16-bit transposed convs: weights in registers (convt_lpr.hip)
                 kname = lp_kind == 1 ? "convT2x2_bf16r" : "convT2x2_fp16r";
@@ -789,6 +801,25 @@ DeviceWeights::~DeviceWeights()
 
 int engine_fail(int code, const std::string &msg) { return fail(code, msg); }
 
+Routing Routing::from_env()
+{
+    Routing r;
+    auto num = [](const char *name, int fallback) { const char *e = getenv(name); return e ? atoi(e) : fallback; };
+    r.lp2 = num("MIUNET_LP2", 1);
+    r.lpr = num("MIUNET_LPR", 1);
+    r.lpr_rb = num("MIUNET_LPR_RB", 2);
+    r.convt_lpr = num("MIUNET_CONVT_LPR", 1);
+    r.wino4s = num("MIUNET_WINO4S", 1);
+    r.convt_small = num("MIUNET_CONVT_SMALL", 1) != 0;
+    r.first_mfma = num("MIUNET_FIRST_MFMA", 1) != 0;
+    int dev = 0;
+    hipDeviceProp_t p;
+    if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&p, dev) == hipSuccess && p.multiProcessorCount > 0)
+        r.cus = p.multiProcessorCount;
+    r.resolved = true;
+    return r;
+}
+
 int engine_pack_weights(const mi_unet_config &cfg, int algo, const void *blob, size_t len, HostWeights &hw)
 {
     return build_host_weights(cfg, algo, blob, len, hw);
@@ -826,6 +857,48 @@ const mi_unet_config &engine_config(const mi_unet_t *h) { return h->cfg; }
 hipStream_t engine_stream(const mi_unet_t *h) { return h->stream; }
 
 }  // namespace miunet
+
+namespace {
+
+// contour outputs of `bm` images: device -> pinned mirror (async, behind the kernels), and after the stream has been
+// synchronised only what exists goes on to the caller's arrays (the capacity is mostly air: 2 x 32768 ints per image)
+int grow_contour_buffers(mi_unet *h, int bm, int cap_points, int cap_contours)
+{
+    const size_t need = (size_t)bm * ((size_t)cap_points * 2 + cap_contours + 1 + 1);
+    if (need <= h->cont_cap) return 0;
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    if (h->d_cont) HIP_TRY(hipFree(h->d_cont));
+    if (h->h_cont) HIP_TRY(hipHostFree(h->h_cont));
+    h->d_cont = nullptr; h->h_cont = nullptr; h->cont_cap = 0;
+    HIP_TRY(hipMalloc(&h->d_cont, need * sizeof(int)));
+    HIP_TRY(hipHostMalloc(&h->h_cont, need * sizeof(int), hipHostMallocDefault));
+    h->cont_cap = need;
+    return 0;
+}
+
+int contours_to_pinned(mi_unet *h, int bm, int cap_points, int cap_contours)
+{
+    // counts and starts whole (small), the points whole as well: 4 MB at 16 images rides PCIe in 0.1 ms once it is pinned
+    const size_t n = (size_t)bm * ((size_t)cap_points * 2 + cap_contours + 1 + 1);
+    HIP_TRY(hipMemcpyAsync(h->h_cont, h->d_cont, n * sizeof(int), hipMemcpyDeviceToHost, h->stream));
+    return 0;
+}
+
+void contours_to_caller(const mi_unet *h, int bm, int cap_points, int cap_contours, int32_t *xy, int32_t *start, int32_t *counts)
+{
+    const int *p_xy = h->h_cont, *p_start = p_xy + (size_t)bm * cap_points * 2, *p_count = p_start + (size_t)bm * (cap_contours + 1);
+    for (int i = 0; i < bm; ++i) {
+        counts[i] = p_count[i];
+        memcpy(start + (size_t)i * (cap_contours + 1), p_start + (size_t)i * (cap_contours + 1), sizeof(int) * (cap_contours + 1));
+        if (p_count[i] > 0) {
+            const int npts = p_start[(size_t)i * (cap_contours + 1) + p_count[i]];
+            if (npts > 0 && npts <= cap_points)
+                memcpy(xy + (size_t)i * cap_points * 2, p_xy + (size_t)i * cap_points * 2, sizeof(int) * 2 * (size_t)npts);
+        }
+    }
+}
+
+}  // namespace
 
 extern "C" {
 
@@ -884,6 +957,7 @@ int mi_unet_create(const mi_unet_config *cfg, mi_unet_t **out)
         h->fuse_pool = !(fp && !strcmp(fp, "0"));
         if (const char *mw = getenv("MIUNET_WINO4_MIN_WG")) h->wino4_min_wg = atoi(mw);
         if (const char *sk4 = getenv("MIUNET_WINO4_SPLITK")) h->wino4_splitk = sk4[0] != '0';
+        h->routing = Routing::from_env();
         const char *gr = getenv("MIUNET_GRAPH");
         h->use_graph = !(gr && !strcmp(gr, "0"));
     }
@@ -957,6 +1031,7 @@ int mi_unet_clone(const mi_unet_t *src, int max_batch, mi_unet_t **out)
     mi_unet_t *h = nullptr;
     if (int rc = mi_unet_create(&cfg, &h)) return rc;
     h->fuse_pool = src->fuse_pool; h->wino4_min_wg = src->wino4_min_wg; h->wino4_splitk = src->wino4_splitk;
+    h->routing = src->routing;                       // a clone routes exactly as its source (same device)
     h->weights = src->weights;                       // shared: freed with the last handle that holds it
     h->d_weights = h->weights->d;
     h->weight_floats = h->weights->floats;
@@ -1045,23 +1120,15 @@ int mi_unet_extract_contours(mi_unet_t *h, const uint8_t *masks, int B, int32_t 
         const int bm = (B - b0) < h->cfg.max_batch ? (B - b0) : h->cfg.max_batch;
         if (contour_workspace_bytes(bm, H, W, cap_contours) > scratch)
             return fail(MI_UNET_EARG, "contour workspace does not fit the scratch buffer (cap_contours too large)");
-        const size_t need = (size_t)bm * ((size_t)cap_points * 2 + cap_contours + 1 + 1);
-        if (need > h->cont_cap) {
-            HIP_TRY(hipStreamSynchronize(s));
-            if (h->d_cont) HIP_TRY(hipFree(h->d_cont));
-            h->d_cont = nullptr; h->cont_cap = 0;
-            HIP_TRY(hipMalloc(&h->d_cont, need * sizeof(int)));
-            h->cont_cap = need;
-        }
+        if (int rc = grow_contour_buffers(h, bm, cap_points, cap_contours)) return rc;
         int *d_xy = h->d_cont, *d_start = d_xy + (size_t)bm * cap_points * 2, *d_count = d_start + (size_t)bm * (cap_contours + 1);
         memcpy(h->h_labels, masks + b0 * hw, bm * hw);
         HIP_TRY(hipMemcpyAsync(h->d_labels, h->h_labels, bm * hw, hipMemcpyHostToDevice, s));
         const hipError_t e = launch_extract_contours(h->d_labels, bm, H, W, d_xy, cap_points, d_start, cap_contours, d_count, h->d_s1, s);
         if (e != hipSuccess) return fail(MI_UNET_EHIP, std::string("contour launch: ") + hipGetErrorString(e));
-        HIP_TRY(hipMemcpyAsync(xy + (size_t)b0 * cap_points * 2, d_xy, sizeof(int) * (size_t)bm * cap_points * 2, hipMemcpyDeviceToHost, s));
-        HIP_TRY(hipMemcpyAsync(start + (size_t)b0 * (cap_contours + 1), d_start, sizeof(int) * (size_t)bm * (cap_contours + 1), hipMemcpyDeviceToHost, s));
-        HIP_TRY(hipMemcpyAsync(counts + b0, d_count, sizeof(int) * bm, hipMemcpyDeviceToHost, s));
+        if (int rc = contours_to_pinned(h, bm, cap_points, cap_contours)) return rc;
         HIP_TRY(hipStreamSynchronize(s));
+        contours_to_caller(h, bm, cap_points, cap_contours, xy + (size_t)b0 * cap_points * 2, start + (size_t)b0 * (cap_contours + 1), counts + b0);
     }
     return MI_UNET_OK;
 }
@@ -1073,12 +1140,12 @@ namespace {
 // (plane c of image i at index i*C + c, each with its own size and its own min/max, as if every plane went through
 // preprocess_raw on its own) and interleaves them into the HWC tile the first layer reads; a caller holding one plane per
 // image passes its pointer C times (the grey -> B,G,R replication cv::imread(IMREAD_COLOR) does at src/mask2polygon.cpp:117).
-int stage_raw16(mi_unet *h, const uint16_t *const *raws, const int *widths, const int *heights, int bm)
+int stage_raw16(mi_unet *h, const uint16_t *const *raws, const int *widths, const int *heights, int bm, hipStream_t s, uint8_t *d_tiles)
 {
     const int C = h->cfg.in_ch;
     const size_t hw = (size_t)h->cfg.height * h->cfg.width;
-    hipStream_t s = h->stream;
     if (!h->d_mnmx) HIP_TRY(hipMalloc(&h->d_mnmx, sizeof(unsigned) * 2 * h->cfg.max_batch * C));
+    int slot = mi_unet::RAW_RING - 1, mn_src = 0;
     for (int i = 0; i < bm * C; ++i) {
         const int w = widths[i], ht = heights[i];
         if (!raws[i] || w <= 0 || ht <= 0) return fail(MI_UNET_EARG, "RAW16 input: bad image description");
@@ -1098,13 +1165,19 @@ int stage_raw16(mi_unet *h, const uint16_t *const *raws, const int *widths, cons
             }
             h->raw_cap = n;
         }
-        const int r = i % mi_unet::RAW_RING;
-        if (h->raw_busy[r]) { HIP_TRY(hipEventSynchronize(h->raw_done[r])); h->raw_busy[r] = false; }   // slot consumed
-        memcpy(h->h_raw[r], raws[i], n * sizeof(uint16_t));
-        HIP_TRY(hipMemcpyAsync(h->d_raw[r], h->h_raw[r], n * sizeof(uint16_t), hipMemcpyHostToDevice, s));
-        hipError_t e = launch_minmax_u16(h->d_raw[r], n, h->d_mnmx + 2 * i, s);
+        // a caller holding one plane per image passes its pointer C times: upload and scan it once, resample it C times
+        const bool same_plane = i % C != 0 && raws[i] == raws[i - 1] && w == widths[i - 1] && ht == heights[i - 1];
+        if (!same_plane) {
+            slot = (slot + 1) % mi_unet::RAW_RING;
+            mn_src = i;
+            if (h->raw_busy[slot]) { HIP_TRY(hipEventSynchronize(h->raw_done[slot])); h->raw_busy[slot] = false; }   // slot consumed
+            memcpy(h->h_raw[slot], raws[i], n * sizeof(uint16_t));
+            HIP_TRY(hipMemcpyAsync(h->d_raw[slot], h->h_raw[slot], n * sizeof(uint16_t), hipMemcpyHostToDevice, s));
+        }
+        const int r = slot;
+        hipError_t e = same_plane ? hipSuccess : launch_minmax_u16(h->d_raw[r], n, h->d_mnmx + 2 * mn_src, s);
         if (e == hipSuccess)
-            e = launch_resample_u8(h->d_raw[r], w, ht, h->d_mnmx + 2 * i, h->d_img + (size_t)(i / C) * hw * C + i % C, h->cfg.width,
+            e = launch_resample_u8(h->d_raw[r], w, ht, h->d_mnmx + 2 * mn_src, d_tiles + (size_t)(i / C) * hw * C + i % C, h->cfg.width,
                                    h->cfg.height, C, s);
         if (e != hipSuccess) return fail(MI_UNET_EHIP, std::string("preprocess launch: ") + hipGetErrorString(e));
         HIP_TRY(hipEventRecord(h->raw_done[r], s));
@@ -1114,6 +1187,114 @@ int stage_raw16(mi_unet *h, const uint16_t *const *raws, const int *widths, cons
 }
 }  // namespace
 
+namespace {
+
+int ensure_raw_pipeline(mi_unet *h, bool two_buffers)
+{
+    if (!h->pre_stream) HIP_TRY(hipStreamCreateWithFlags(&h->pre_stream, hipStreamNonBlocking));
+    for (int i = 0; i < 2; ++i) {
+        if (!h->tile_ready[i]) HIP_TRY(hipEventCreateWithFlags(&h->tile_ready[i], hipEventDisableTiming));
+        if (!h->tile_free[i]) HIP_TRY(hipEventCreateWithFlags(&h->tile_free[i], hipEventDisableTiming));
+    }
+    for (hipEvent_t &e : h->stage_ev)
+        if (!e) HIP_TRY(hipEventCreate(&e));
+    for (int i = 0; i < 2; ++i)
+        for (int j = 0; j < 2; ++j)
+            if (!h->pre_ev[i][j]) HIP_TRY(hipEventCreate(&h->pre_ev[i][j]));
+    if (two_buffers && !h->d_img2)
+        HIP_TRY(hipMalloc(&h->d_img2, (size_t)h->cfg.max_batch * h->cfg.height * h->cfg.width * h->cfg.in_ch));
+    return 0;
+}
+
+// The RAW-in entry points as one loop over micro-batches.  Per micro-batch k on the engine's stream: network -> [postprocess ->
+// mask_to_image -> contours] -> D2H; on the second stream, meanwhile: the host staging copies, H2D transfers and
+// preprocessing kernels of micro-batch k + 1 into the other tile buffer.
+struct RawCall {
+    const uint16_t *const *raws; const int *widths, *heights; int B;
+    uint8_t *tiles, *out_u8; float *logits;            // out_u8: label maps (infer) or 0 / 255 masks (segment)
+    bool segment; int32_t *xy; int cap_points; int32_t *start; int cap_contours; int32_t *counts;
+};
+
+int run_raw_call(mi_unet *h, const RawCall &c)
+{
+    HIP_TRY(hipSetDevice(h->cfg.device));
+    const int H = h->cfg.height, W = h->cfg.width, Bm = h->cfg.max_batch;
+    const size_t hw = (size_t)H * W, C = (size_t)h->cfg.in_ch;
+    const size_t scratch = sizeof(float) * (size_t)Bm * hw * h->ch[0];
+    hipStream_t s = h->stream;
+    const int n_mb = (c.B + Bm - 1) / Bm;
+    if (int rc = ensure_raw_pipeline(h, n_mb > 1)) return rc;
+    for (float &m : h->stage_ms) m = 0.f;
+    auto tile_buf = [&](int k) { return (k & 1) ? h->d_img2 : h->d_img; };
+    auto mb_size = [&](int k) { return std::min(Bm, c.B - k * Bm); };
+    auto stage = [&](int k) -> int {                   // upload + preprocess micro-batch k on the second stream
+        const int bm = mb_size(k), par = k & 1;
+        const size_t b0 = (size_t)k * Bm;
+        if (k >= 2) HIP_TRY(hipStreamWaitEvent(h->pre_stream, h->tile_free[par], 0));      // its last reader: micro-batch k - 2
+        HIP_TRY(hipEventRecord(h->pre_ev[par][0], h->pre_stream));
+        if (int rc = stage_raw16(h, c.raws + b0 * C, c.widths + b0 * C, c.heights + b0 * C, bm, h->pre_stream, tile_buf(k))) return rc;
+        HIP_TRY(hipEventRecord(h->pre_ev[par][1], h->pre_stream));
+        HIP_TRY(hipEventRecord(h->tile_ready[par], h->pre_stream));
+        return 0;
+    };
+    if (c.B <= 0) return MI_UNET_OK;
+    if (c.segment)
+        if (int rc = grow_contour_buffers(h, std::min(Bm, c.B), c.cap_points, c.cap_contours)) return rc;
+    HIP_TRY(hipStreamSynchronize(s));                  // an external stream may still be reading the tile buffers
+    if (int rc = stage(0)) return rc;
+    for (int k = 0; k < n_mb; ++k) {
+        const int bm = mb_size(k), par = k & 1;
+        const size_t b0 = (size_t)k * Bm;
+        uint8_t *d_tiles = tile_buf(k);
+        if (c.segment && contour_workspace_bytes(bm, H, W, c.cap_contours) > scratch)
+            return fail(MI_UNET_EARG, "contour workspace does not fit the scratch buffer (cap_contours too large)");
+        HIP_TRY(hipStreamWaitEvent(s, h->tile_ready[par], 0));
+        HIP_TRY(hipEventRecord(h->stage_ev[0], s));
+        float *d_lg = c.logits ? h->d_logits : nullptr;
+        if (int rc = run_microbatch(h, d_tiles, bm, h->d_labels, d_lg)) return rc;             // UNet + argmax
+        HIP_TRY(hipEventRecord(h->stage_ev[1], s));
+        const uint8_t *d_result = h->d_labels;
+        int *d_xy = h->d_cont, *d_start = d_xy + (size_t)bm * c.cap_points * 2, *d_count = d_start + (size_t)bm * (c.cap_contours + 1);
+        if (c.segment || h->postprocess)
+            if (int rc = device_postprocess(h, h->d_labels, h->d_labels, bm)) return rc;       // {0, 2}
+        HIP_TRY(hipEventRecord(h->stage_ev[2], s));
+        if (c.segment) {
+            uint8_t *d_vis = reinterpret_cast<uint8_t *>(h->d_s0);                             // s0 is free after the head
+            hipError_t e = launch_mask_to_image(h->d_labels, d_vis, bm * hw, s);
+            if (e == hipSuccess)
+                e = launch_extract_contours(d_vis, bm, H, W, d_xy, c.cap_points, d_start, c.cap_contours, d_count, h->d_s1, s);
+            if (e != hipSuccess) return fail(MI_UNET_EHIP, std::string("segment launch: ") + hipGetErrorString(e));
+            d_result = d_vis;
+        }
+        HIP_TRY(hipEventRecord(h->stage_ev[3], s));
+        if (c.tiles) HIP_TRY(hipMemcpyAsync(c.tiles + b0 * hw * C, d_tiles, bm * hw * C, hipMemcpyDeviceToHost, s));
+        HIP_TRY(hipEventRecord(h->tile_free[par], s));
+        HIP_TRY(hipMemcpyAsync(h->h_labels, d_result, bm * hw, hipMemcpyDeviceToHost, s));
+        if (c.segment)
+            if (int rc = contours_to_pinned(h, bm, c.cap_points, c.cap_contours)) return rc;
+        if (c.logits)
+            HIP_TRY(hipMemcpyAsync(c.logits + b0 * hw * h->cfg.classes, h->d_logits, sizeof(float) * bm * hw * h->cfg.classes,
+                                   hipMemcpyDeviceToHost, s));
+        HIP_TRY(hipEventRecord(h->stage_ev[4], s));
+        if (k + 1 < n_mb)                              // the host's staging copies of k + 1 run while the device works on k
+            if (int rc = stage(k + 1)) return rc;
+        HIP_TRY(hipStreamSynchronize(s));
+        memcpy(c.out_u8 + b0 * hw, h->h_labels, bm * hw);
+        if (c.segment)
+            contours_to_caller(h, bm, c.cap_points, c.cap_contours, c.xy + b0 * c.cap_points * 2, c.start + b0 * (c.cap_contours + 1), c.counts + b0);
+        float ms = 0.f;
+        HIP_TRY(hipEventElapsedTime(&ms, h->pre_ev[par][0], h->pre_ev[par][1]));
+        h->stage_ms[MI_UNET_STAGE_UPLOAD_PRE] += ms;
+        for (int st = 0; st < 4; ++st) {
+            HIP_TRY(hipEventElapsedTime(&ms, h->stage_ev[st], h->stage_ev[st + 1]));
+            h->stage_ms[MI_UNET_STAGE_NETWORK + st] += ms;
+        }
+    }
+    return MI_UNET_OK;
+}
+
+}  // namespace
+
 extern "C" {
 
 int mi_unet_infer_raw16(mi_unet_t *h, const uint16_t *const *raws, const int *widths, const int *heights, int B,
@@ -1121,23 +1302,7 @@ int mi_unet_infer_raw16(mi_unet_t *h, const uint16_t *const *raws, const int *wi
 {
     if (int rc = check_handle(h, true)) return rc;
     if (!raws || !widths || !heights || !labels || B < 0) return fail(MI_UNET_EARG, "mi_unet_infer_raw16: bad argument");
-    HIP_TRY(hipSetDevice(h->cfg.device));
-    const size_t hw = (size_t)h->cfg.height * h->cfg.width;
-    hipStream_t s = h->stream;
-    for (int b0 = 0; b0 < B; b0 += h->cfg.max_batch) {
-        const int bm = (B - b0) < h->cfg.max_batch ? (B - b0) : h->cfg.max_batch;
-        const size_t C = (size_t)h->cfg.in_ch;
-        if (int rc = stage_raw16(h, raws + b0 * C, widths + b0 * C, heights + b0 * C, bm)) return rc;
-        if (int rc = infer_microbatch(h, h->d_img, bm, h->d_labels, logits ? h->d_logits : nullptr)) return rc;
-        if (tiles) HIP_TRY(hipMemcpyAsync(tiles + b0 * hw * C, h->d_img, bm * hw * C, hipMemcpyDeviceToHost, s));
-        HIP_TRY(hipMemcpyAsync(h->h_labels, h->d_labels, bm * hw, hipMemcpyDeviceToHost, s));
-        if (logits)
-            HIP_TRY(hipMemcpyAsync(logits + b0 * hw * h->cfg.classes, h->d_logits, sizeof(float) * bm * hw * h->cfg.classes,
-                                   hipMemcpyDeviceToHost, s));
-        HIP_TRY(hipStreamSynchronize(s));
-        memcpy(labels + b0 * hw, h->h_labels, bm * hw);
-    }
-    return MI_UNET_OK;
+    return run_raw_call(h, RawCall{ raws, widths, heights, B, tiles, labels, logits, false, nullptr, 0, nullptr, 0, nullptr });
 }
 
 int mi_unet_segment_raw16(mi_unet_t *h, const uint16_t *const *raws, const int *widths, const int *heights, int B,
@@ -1147,41 +1312,13 @@ int mi_unet_segment_raw16(mi_unet_t *h, const uint16_t *const *raws, const int *
     if (int rc = check_handle(h, true)) return rc;
     if (!raws || !widths || !heights || !masks || !xy || !start || !counts || B < 0 || cap_points <= 0 || cap_contours <= 0)
         return fail(MI_UNET_EARG, "mi_unet_segment_raw16: bad argument");
-    HIP_TRY(hipSetDevice(h->cfg.device));
-    const int H = h->cfg.height, W = h->cfg.width;
-    const size_t hw = (size_t)H * W;
-    const size_t scratch = sizeof(float) * (size_t)h->cfg.max_batch * hw * h->ch[0];
-    hipStream_t s = h->stream;
-    for (int b0 = 0; b0 < B; b0 += h->cfg.max_batch) {
-        const int bm = (B - b0) < h->cfg.max_batch ? (B - b0) : h->cfg.max_batch;
-        if (contour_workspace_bytes(bm, H, W, cap_contours) > scratch)
-            return fail(MI_UNET_EARG, "contour workspace does not fit the scratch buffer (cap_contours too large)");
-        const size_t need = (size_t)bm * ((size_t)cap_points * 2 + cap_contours + 1 + 1);
-        if (need > h->cont_cap) {
-            HIP_TRY(hipStreamSynchronize(s));
-            if (h->d_cont) HIP_TRY(hipFree(h->d_cont));
-            h->d_cont = nullptr; h->cont_cap = 0;
-            HIP_TRY(hipMalloc(&h->d_cont, need * sizeof(int)));
-            h->cont_cap = need;
-        }
-        int *d_xy = h->d_cont, *d_start = d_xy + (size_t)bm * cap_points * 2, *d_count = d_start + (size_t)bm * (cap_contours + 1);
-        const size_t C = (size_t)h->cfg.in_ch;
-        if (int rc = stage_raw16(h, raws + b0 * C, widths + b0 * C, heights + b0 * C, bm)) return rc;
-        if (int rc = run_microbatch(h, h->d_img, bm, h->d_labels, nullptr)) return rc;          // UNet + argmax
-        if (int rc = device_postprocess(h, h->d_labels, h->d_labels, bm)) return rc;             // {0, 2}
-        uint8_t *d_vis = reinterpret_cast<uint8_t *>(h->d_s0);                                   // s0 is free after the head
-        hipError_t e = launch_mask_to_image(h->d_labels, d_vis, bm * hw, s);
-        if (e == hipSuccess)
-            e = launch_extract_contours(d_vis, bm, H, W, d_xy, cap_points, d_start, cap_contours, d_count, h->d_s1, s);
-        if (e != hipSuccess) return fail(MI_UNET_EHIP, std::string("segment launch: ") + hipGetErrorString(e));
-        if (tiles) HIP_TRY(hipMemcpyAsync(tiles + b0 * hw * C, h->d_img, bm * hw * C, hipMemcpyDeviceToHost, s));
-        HIP_TRY(hipMemcpyAsync(h->h_labels, d_vis, bm * hw, hipMemcpyDeviceToHost, s));
-        HIP_TRY(hipMemcpyAsync(xy + (size_t)b0 * cap_points * 2, d_xy, sizeof(int) * (size_t)bm * cap_points * 2, hipMemcpyDeviceToHost, s));
-        HIP_TRY(hipMemcpyAsync(start + (size_t)b0 * (cap_contours + 1), d_start, sizeof(int) * (size_t)bm * (cap_contours + 1), hipMemcpyDeviceToHost, s));
-        HIP_TRY(hipMemcpyAsync(counts + b0, d_count, sizeof(int) * bm, hipMemcpyDeviceToHost, s));
-        HIP_TRY(hipStreamSynchronize(s));
-        memcpy(masks + b0 * hw, h->h_labels, bm * hw);
-    }
+    return run_raw_call(h, RawCall{ raws, widths, heights, B, tiles, masks, nullptr, true, xy, cap_points, start, cap_contours, counts });
+}
+
+int mi_unet_last_stage_ms(const mi_unet_t *h, float *ms)
+{
+    if (!h || !ms) return fail(MI_UNET_EARG, "mi_unet_last_stage_ms: null argument");
+    for (int i = 0; i < MI_UNET_N_STAGES; ++i) ms[i] = h->stage_ms[i];
     return MI_UNET_OK;
 }
 
@@ -1499,6 +1636,16 @@ void mi_unet_destroy(mi_unet_t *h)
         if (p) (void)hipFree(p);
     if (h->h_img) (void)hipHostFree(h->h_img);
     if (h->h_labels) (void)hipHostFree(h->h_labels);
+    if (h->h_cont) (void)hipHostFree(h->h_cont);
+    if (h->d_img2) (void)hipFree(h->d_img2);
+    if (h->pre_stream) { (void)hipStreamSynchronize(h->pre_stream); (void)hipStreamDestroy(h->pre_stream); }
+    for (int i = 0; i < 2; ++i) {
+        hipEvent_t evs2[] = { h->tile_ready[i], h->tile_free[i], h->pre_ev[i][0], h->pre_ev[i][1] };
+        for (hipEvent_t e : evs2)
+            if (e) (void)hipEventDestroy(e);
+    }
+    for (hipEvent_t e : h->stage_ev)
+        if (e) (void)hipEventDestroy(e);
     for (int r = 0; r < mi_unet::RAW_RING; ++r) {
         if (h->h_raw[r]) (void)hipHostFree(h->h_raw[r]);
         if (h->raw_done[r]) (void)hipEventDestroy(h->raw_done[r]);

@@ -8,6 +8,7 @@
 #include <dlfcn.h>
 #include <hip/hip_runtime.h>
 
+#include <cstdio>
 #include <cstdlib>
 #include <cstring>
 #include <fstream>
@@ -223,6 +224,7 @@ int mi_unet_group_set_gather(mi_unet_group_t *g, int mode)
     if (mode != MI_UNET_GATHER_HOST && mode != MI_UNET_GATHER_XGMI) return engine_fail(MI_UNET_EARG, "unknown gather mode");
     if (mode == MI_UNET_GATHER_XGMI && g->comms.empty())
         return engine_fail(MI_UNET_EARG, "MI_UNET_GATHER_XGMI needs RCCL communicators (distinct devices, librccl loadable)");
+    std::lock_guard<std::mutex> lk(g->call_mutex);       // never while a group call is in flight
     g->gather = mode;
     return MI_UNET_OK;
 }
@@ -230,6 +232,7 @@ int mi_unet_group_set_gather(mi_unet_group_t *g, int mode)
 int mi_unet_group_set_postprocess(mi_unet_group_t *g, int on)
 {
     if (!g) return engine_fail(MI_UNET_EARG, "null group");
+    std::lock_guard<std::mutex> lk(g->call_mutex);       // never while a group call is in flight
     g->postprocess = on != 0;
     for (mi_unet_t *h : g->eng)
         if (int rc = mi_unet_set_postprocess(h, on)) return rc;
@@ -252,7 +255,11 @@ int mi_unet_group_load_weights_from_memory(mi_unet_group_t *g, const void *blob,
     // the host blob.  A rung that fails is reported in the transport string and the next one is taken: the weights always
     // arrive, and a node whose RCCL or peer access is misconfigured still runs.
     bool done = false;
+    if (const char *v = getenv("MIUNET_GROUP_VERBOSE"); v && v[0] == '1')
+        fprintf(stderr, "[miunet group] %d ranks, weights %zu bytes to ranks > 0 by %s\n", R, bytes,
+                g->comms.empty() ? "peer copy" : "ncclBroadcast (RCCL)");
     if (!g->comms.empty()) {
+        g->transport = "rccl (broadcast in flight)";     // visible to a watchdog if the collective never returns
         // one contiguous broadcast, root = rank 0, every rank on its own engine stream (single-thread group call)
         int rc = g->rccl.GroupStart();
         for (int r = 0; r < R && rc == 0; ++r) {
@@ -311,6 +318,13 @@ int mi_unet_group_infer_u8(mi_unet_group_t *g, const uint8_t *imgs, int B, uint8
         });
     }
     // XGMI gather: shards stay on their devices, label maps travel device-to-device into rank 0, one D2H from there
+    if (B == 0) return MI_UNET_OK;
+    // a failure on one rank must not leave the other ranks' forward passes in flight on buffers the caller may free
+    auto drain = [&](int rc_keep) {
+        const std::string msg = mi_unet_last_error();
+        for (int r = 0; r < R; ++r) (void)mi_unet_sync(g->eng[r]);
+        return engine_fail(rc_keep, msg);
+    };
     if (int rc = grow(g->d_out[0], g->cap_out[0], (size_t)B * hw, g->devices[0])) return rc;
     if ((size_t)B * hw > g->cap_all) {
         HIP_TRY_G(hipSetDevice(g->devices[0]));
@@ -331,7 +345,7 @@ int mi_unet_group_infer_u8(mi_unet_group_t *g, const uint8_t *imgs, int B, uint8
         uint8_t *dst = r == 0 ? g->d_out[0] + lo * hw : g->d_out[r];
         return mi_unet_infer_u8_device(g->eng[r], g->d_in[r], (int)n, dst, nullptr);
     });
-    if (rc) return rc;
+    if (rc) return drain(rc);
     rc = g->rccl.GroupStart();
     for (int r = 1; r < R && rc == 0; ++r) {
         int lo, hi;
@@ -341,7 +355,7 @@ int mi_unet_group_infer_u8(mi_unet_group_t *g, const uint8_t *imgs, int B, uint8
         if (rc == 0) rc = g->rccl.Recv(g->d_out[0] + lo * hw, (size_t)(hi - lo) * hw, Rccl::kUint8, r, g->comms[0], engine_stream(g->eng[0]));
     }
     const int rc2 = g->rccl.GroupEnd();
-    if (rc || rc2) return nccl_fail(g, rc ? rc : rc2, "ncclSend/ncclRecv(label maps)");
+    if (rc || rc2) return drain(nccl_fail(g, rc ? rc : rc2, "ncclSend/ncclRecv(label maps)"));
     HIP_TRY_G(hipSetDevice(g->devices[0]));
     HIP_TRY_G(hipMemcpyAsync(g->h_all, g->d_out[0], (size_t)B * hw, hipMemcpyDeviceToHost, engine_stream(g->eng[0])));
     for (int r = 0; r < R; ++r)

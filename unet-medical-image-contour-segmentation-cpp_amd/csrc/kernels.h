@@ -10,6 +10,23 @@ namespace miunet {
 constexpr int KC = 16;        // input channels staged per K-chunk
 constexpr int NPAD = 128;     // packed Cout granule (covers both BN = 64 and BN = 128 tiles)
 
+// Kernel-routing switches (the MIUNET_* A/B variables) and the device's CU count, resolved ONCE per engine handle at
+// mi_unet_create and carried in every launch's arguments: a launch never calls getenv or touches shared tables, so cloned
+// contexts launching from several threads share nothing mutable, and an engine's routing cannot change under it.
+// A default-constructed Routing is unresolved: routing_of() then reads the environment at the call (mi_unet_layer_debug).
+struct Routing {
+    bool resolved = false;
+    int cus = 256;            // compute units of the launch device
+    int lp2 = 1;              // MIUNET_LP2: 0 never, 1 default thresholds, 2 every Cout % 128 == 0 layer
+    int lpr = 1;              // MIUNET_LPR: 0 never, 1 when the tiles fill the chip four times over, 2 whatever the grid
+    int lpr_rb = 2;           // MIUNET_LPR_RB: 1 = 8-row tiles for every shape
+    int convt_lpr = 1;        // MIUNET_CONVT_LPR: as lpr
+    int wino4s = 1;           // MIUNET_WINO4S: 0 never, 1 grids that fill the chip twice over, 2 every one-block case
+    bool convt_small = true;  // MIUNET_CONVT_SMALL=0: the per-tap transposed conv never shrinks its tile
+    bool first_mfma = true;   // MIUNET_FIRST_MFMA=0: the 16-bit pipelines' first layer stays on the VALU kernel
+    static Routing from_env();            // reads the environment and the current device's properties (engine.cpp)
+};
+
 // One implicit-GEMM launch: conv3x3 (taps = 9) or the 2x2-stride-2 transposed conv viewed as a 1-tap GEMM with
 // N = 4*Cout (taps = 1).  Activations are NHWC fp32; `ldc`/`ldo` are the channel strides of the input / output pixel
 // (so a tensor can live in one half of a concat buffer), `co_off` the first output channel written.
@@ -42,12 +59,15 @@ struct ConvArgs {
     // 16-bit kernels (conv_lp.hip): `in` always points at 16-bit activations (bf16 / fp16, NHWC, ldc in elements); out_lp
     // selects a 16-bit `out` / `pool_out` (everything but the layer in front of the fp32 head)
     int out_lp;
+    Routing rt;           // resolved by the engine; unresolved = read the environment at the call
     const float *head_w;
     const float *head_b;
     int head_classes;
     float *head_logits;
     uint8_t *head_labels;
 };
+
+inline Routing routing_of(const ConvArgs &a) { return a.rt.resolved ? a.rt : Routing::from_env(); }
 
 hipError_t launch_conv3x3_mfma(const ConvArgs &a, hipStream_t s);
 
@@ -102,7 +122,8 @@ hipError_t launch_convT2x2_lpr(const ConvArgs &a, bool fp16, hipStream_t s);
 // First layer: u8 image -> (LUT /255) -> conv3x3 (Cin = 1..4) + shift + ReLU.  w is [9][Cin][Cout] (BN scale folded).
 // out_kind: 0 = fp32 output, 1 = bf16, 2 = fp16 (the 16-bit pipelines keep every activation tensor 16-bit in HBM)
 hipError_t launch_conv3x3_first(const uint8_t *img, const float *lut256, const float *w, const float *shift, float *out,
-                                int B, int H, int W, int Cin, int Cout, int ldo, int out_kind, hipStream_t s);
+                                int B, int H, int W, int Cin, int Cout, int ldo, int out_kind, hipStream_t s,
+                                const Routing *rt = nullptr);
 // Same arithmetic on an fp32 NHWC input (layer_debug / small-Cin fallback is not needed elsewhere).
 
 hipError_t launch_maxpool2x2(const float *in, int ldc, float *out, int B, int H, int W, int C, hipStream_t s);

@@ -251,18 +251,17 @@ static hipError_t launch_first_mfma_t(const uint8_t *img, const float *lut256, c
 }
 
 // the MFMA form takes the 16-bit outputs it was built for (MIUNET_FIRST_MFMA=0: never)
-static bool first_mfma_takes(int Cin, int Cout, int ldo, int H, int W, int out_kind)
+static bool first_mfma_takes(int Cin, int Cout, int ldo, int H, int W, int out_kind, const Routing *rt)
 {
-    const char *e = getenv("MIUNET_FIRST_MFMA");
-    if (e && e[0] == '0') return false;
+    if (!(rt && rt->resolved ? *rt : Routing::from_env()).first_mfma) return false;
     return out_kind != 0 && (Cin == 1 || Cin == 3) && Cout % 8 == 0 && Cout <= 64 && ldo % 8 == 0 && (long long)H * W * ldo * 2 < (1ll << 31);
 }
 
 // out_kind: 0 = fp32, 1 = bf16, 2 = fp16 output tensor
 hipError_t launch_conv3x3_first(const uint8_t *img, const float *lut256, const float *w, const float *shift, float *out,
-                                int B, int H, int W, int Cin, int Cout, int ldo, int out_kind, hipStream_t s)
+                                int B, int H, int W, int Cin, int Cout, int ldo, int out_kind, hipStream_t s, const Routing *rt)
 {
-    if (first_mfma_takes(Cin, Cout, ldo, H, W, out_kind))
+    if (first_mfma_takes(Cin, Cout, ldo, H, W, out_kind, rt))
         return out_kind == 1 ? launch_first_mfma_t(img, lut256, w, shift, reinterpret_cast<__bf16 *>(out), B, H, W, Cin, Cout, ldo, s)
                              : launch_first_mfma_t(img, lut256, w, shift, reinterpret_cast<_Float16 *>(out), B, H, W, Cin, Cout, ldo, s);
     if (out_kind == 1) return launch_first_t(img, lut256, w, shift, reinterpret_cast<__bf16 *>(out), B, H, W, Cin, Cout, ldo, s);

@@ -185,9 +185,14 @@ private:
         }
         // the log directory sits next to the engine directory, as in the reference: <dir of the file>/../log
         const std::string log_dir = fs::path(w[1]).parent_path().string() + "/../log";
-        ready_ = MedicalSeg::initialize_engine(w[1], log_dir);      // a failed re-initialisation leaves no engine behind
-        if (ready_) std::cout << "Engine initialized successfully" << std::endl;
-        else std::cerr << "Engine initialization failed" << std::endl;
+        // as the reference (src/main.cpp:88-93): the flag is only ever set, so after a failed RE-initialisation `process` still
+        // reaches the facade (which reports "Engine not initialized" per image) and `exit` still runs cleanup_resources
+        if (MedicalSeg::initialize_engine(w[1], log_dir)) {
+            std::cout << "Engine initialized successfully" << std::endl;
+            ready_ = true;
+        } else {
+            std::cerr << "Engine initialization failed" << std::endl;
+        }
     }
 
     void cmd_process(const Words &w)

@@ -10,6 +10,7 @@
 //        -> process_image_batch: chunks of max_batch x devices images, sharded over the group
 #include <algorithm>
 #include <chrono>
+#include <cstdio>
 #include <cstdlib>
 #include <cstring>
 #include <filesystem>
@@ -93,7 +94,8 @@ bool read_weight_header(const std::string &path, mi_unet_config &cfg)
 //   MEDSEG_MAX_BATCH     images per device micro-batch in directory mode, default 16
 //   MEDSEG_THREAD_BATCH  capacity of a per-thread context (single-image calls), default 1
 //   MEDSEG_CONV_ALGO     auto | direct | winograd | bf16 | fp16 (the arithmetic of BASELINE configs 3 and 5)
-//   MEDSEG_DEVICES       number of devices in the group, default every visible one
+//   MEDSEG_DEVICES       number of devices in the group: default 1 (the reference's implicit device 0); N > 1 or 0 (= every
+//                        visible device) is opt-in -- the multi-device transports have not met a second GPU yet
 bool initialize_engine(const std::string &trt_cache_path, const std::string &log_dir)
 {
     std::lock_guard<std::mutex> state_lock(g_state_mutex);
@@ -127,7 +129,9 @@ bool initialize_engine(const std::string &trt_cache_path, const std::string &log
         g_cfg.max_batch = std::max(1, env_int("MEDSEG_MAX_BATCH", 16));
         g_cfg.conv_algo = env_algo();
         g_thread_batch = std::max(1, env_int("MEDSEG_THREAD_BATCH", 1));
-        const int n_devices = env_int("MEDSEG_DEVICES", 0);
+        const int n_devices = env_int("MEDSEG_DEVICES", 1);
+        g_log_file << "Device group requested: " << (n_devices <= 0 ? std::string("every visible device") : std::to_string(n_devices))
+                   << " (MEDSEG_DEVICES)" << std::endl;
         bool up = mi_unet_group_create(&g_cfg, nullptr, n_devices, &g_group) == MI_UNET_OK &&
                   mi_unet_group_load_weights(g_group, trt_cache_path.c_str()) == MI_UNET_OK;
         if (!up && n_devices != 1 && mi_unet_device_count() > 1) {
@@ -395,6 +399,7 @@ ChunkText artefact_chunk(const ChunkIn &in, const ChunkOut &out, const std::vect
     for (long long k = 0; k < (long long)m; ++k) {
         const size_t i = in.first + out.idx[k];
         std::ostringstream con, lg;
+        medseg::set_png_threads(m > 1 ? 1 : 8);    // the images of a chunk are already written in parallel: no band threads inside
         try {
             const std::string base_name = fs::path(paths[i]).stem().string();
             lg << "\n=== Processing Image: " << fs::path(paths[i]).filename().string() << " ===" << std::endl;
@@ -658,9 +663,87 @@ bool process_single_image(const std::string &raw_path, int width, int height, co
                                       std::chrono::high_resolution_clock::now() - infer_start).count();
             lg << "Inference time: " << infer_ms << " ms" << std::endl;
             finish_image(raw_path, width, height, output_dir, gray_img, std::move(pred_mask), false);
+        } else if (device_postprocess_requested() && device_contours_requested()) {
+            // all-device route: RAW16 -> tile -> UNet -> postprocess_mask -> mask_to_image -> contours in ONE call on this
+            // thread's context; the mapped file is copied once, into pinned staging; the five artefacts
+            // are written concurrently.  Per-stage times follow the reference's two log lines.
+            using clk = std::chrono::steady_clock;
+            auto ms_since = [](clk::time_point t0) { return std::chrono::duration<double, std::milli>(clk::now() - t0).count(); };
+            const auto t_read = clk::now();
+            std::unique_ptr<Preprocess::RawView> raw;
+            try {
+                raw.reset(new Preprocess::RawView(raw_path, width, height));
+            } catch (const std::exception &e) {
+                std::cerr << "preprocess_raw error: " << e.what() << '\n';
+                throw std::runtime_error("Preprocessing failed");
+            }
+            const double read_ms = ms_since(t_read);
+            const int C = g_cfg.in_ch;
+            const std::vector<const uint16_t *> planes(C, raw->data());   // one plane feeds every input channel
+            const std::vector<int> ws(C, width), hs(C, height);
+            const size_t hw = (size_t)g_cfg.height * g_cfg.width;
+            std::vector<uint8_t> tile_c(C > 1 ? hw * C : 0);
+            Image8 tile(g_cfg.height, g_cfg.width, 1), vis(g_cfg.height, g_cfg.width, 1);
+            std::vector<int32_t> xy((size_t)kCapPoints * 2), start(kCapContours + 1);
+            int32_t cnt = 0;
+            const auto infer_start = clk::now();
+            const int rc = mi_unet_segment_raw16(ctx, planes.data(), ws.data(), hs.data(), 1, C > 1 ? tile_c.data() : tile.data.data(),
+                                                 vis.data.data(), xy.data(), kCapPoints, start.data(), kCapContours, &cnt);
+            if (rc != MI_UNET_OK) throw std::runtime_error(std::string("Inference failed: ") + mi_unet_last_error());
+            raw.reset();
+            if (C > 1)
+                for (size_t p = 0; p < hw; ++p) tile.data[p] = tile_c[p * C];
+            const double device_ms = ms_since(infer_start);
+            float st[MI_UNET_N_STAGES] = {};
+            mi_unet_last_stage_ms(ctx, st);
+            lg << "Inference time: " << (long long)device_ms << " ms" << std::endl;
+            std::vector<medseg::Contour> contours;
+            if (cnt < 0) {                             // capacity overflow on the device: the host tracer takes over
+                contours = Mask2Polygon::extract_contours(vis);
+            } else {
+                for (int k = 0; k < cnt; ++k) {
+                    medseg::Contour cc;
+                    for (int q = start[k]; q < start[k + 1]; ++q) cc.emplace_back(xy[2 * q], xy[2 * q + 1]);
+                    contours.push_back(std::move(cc));
+                }
+            }
+            // artefacts: {normalized.png + sizes.json} || {mask.png} || {overlay.png + polygon json}
+            const auto t_art = clk::now();
+            double norm_ms = 0, mask_ms = 0, poly_ms = 0;
+            std::ostringstream con;
+            auto f_norm = std::async(std::launch::async, [&] {
+                const auto t0 = clk::now();
+                const bool ok = Preprocess::write_preprocess_outputs(tile, raw_path, output_dir + "/" + base_name + "_normalized.png",
+                                                                     output_dir + "/" + base_name + "_original_sizes.json", width, height);
+                norm_ms = ms_since(t0);
+                return ok;
+            });
+            auto f_mask = std::async(std::launch::async, [&] {
+                const auto t0 = clk::now();
+                const bool ok = medseg::write_png(output_dir + "/" + base_name + "_mask.png", vis, /*level0=*/true);
+                mask_ms = ms_since(t0);
+                return ok;
+            });
+            {
+                const auto t0 = clk::now();
+                Mask2Polygon::write_polygon_outputs(contours, tile, output_dir, base_name, width, height, con);
+                poly_ms = ms_since(t0);
+            }
+            const bool norm_ok = f_norm.get(), mask_ok = f_mask.get();
+            std::cout << con.str() << std::flush;
+            if (!norm_ok) throw std::runtime_error("Preprocessing failed");
+            if (!mask_ok) throw std::runtime_error("Failed to save mask");
+            char line[512];
+            std::snprintf(line, sizeof line,
+                          "  Stage times (ms): read %.2f | device call %.2f = upload+preprocess %.2f, network %.2f, postprocess %.2f, "
+                          "contours %.2f, download %.2f | artefacts %.2f = normalized.png+sizes.json %.2f || mask.png %.2f || "
+                          "overlay.png+polygon.json %.2f",
+                          read_ms, device_ms, st[MI_UNET_STAGE_UPLOAD_PRE], st[MI_UNET_STAGE_NETWORK], st[MI_UNET_STAGE_POSTPROCESS],
+                          st[MI_UNET_STAGE_CONTOURS], st[MI_UNET_STAGE_DOWNLOAD], ms_since(t_art), norm_ms, mask_ms, poly_ms);
+            lg << line << std::endl;
         } else {
-            // device-first: min/max + resample + quantise run on the GPU in front of the network; the tile
-            // comes back once, for the _normalized.png artefact
+            // device-first with a host tail (MEDSEG_HOST_POSTPROCESS / MEDSEG_HOST_CONTOURS = 1): min/max + resample + quantise
+            // run on the GPU in front of the network; the tile comes back once, for the _normalized.png artefact
             std::vector<uint16_t> raw;
             try {
                 raw = Preprocess::read_raw16(raw_path, width, height);

@@ -90,6 +90,14 @@ medseg::Image8 resample_normalize(const uint16_t *src, int w, int h, int outW, i
     return dst;
 }
 
+RawView::RawView(const std::string &raw_path, int w, int h)
+{
+    if (w <= 0 || h <= 0) throw std::runtime_error("width and height must be positive");
+    auto file = std::make_shared<MappedFile>(raw_path, (size_t)w * h * 2);
+    map_ = std::shared_ptr<void>(file, const_cast<uint16_t *>(file->data()));    // aliasing: the mapping lives as long as the view
+    samples_ = (size_t)w * h;
+}
+
 std::vector<uint16_t> read_raw16(const std::string &raw_path, int w, int h)
 {
     if (w <= 0 || h <= 0) throw std::runtime_error("width and height must be positive");

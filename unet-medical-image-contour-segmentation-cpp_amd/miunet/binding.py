@@ -19,7 +19,7 @@ EXPORTS = [
     "mi_unet_infer_u8", "mi_unet_infer_u8_device", "mi_unet_infer_raw16", "mi_unet_set_postprocess", "mi_unet_postprocess_masks", "mi_unet_extract_contours", "mi_unet_segment_raw16", "mi_unet_set_stream", "mi_unet_sync", "mi_unet_timer_begin",
     "mi_unet_timer_end", "mi_unet_set_profiling", "mi_unet_get_kernel_stats", "mi_unet_layer_debug", "mi_unet_destroy",
     "mi_unet_last_error", "mi_unet_device_count", "mi_unet_clone",
-    "mi_unet_debug_layer_count", "mi_unet_debug_layer_info", "mi_unet_debug_capture",
+    "mi_unet_debug_layer_count", "mi_unet_debug_layer_info", "mi_unet_debug_capture", "mi_unet_last_stage_ms",
     "mi_unet_group_create", "mi_unet_group_clone", "mi_unet_group_size", "mi_unet_group_handle", "mi_unet_group_load_weights",
     "mi_unet_group_load_weights_from_memory", "mi_unet_group_set_gather", "mi_unet_group_set_postprocess",
     "mi_unet_group_weight_transport", "mi_unet_group_gather", "mi_unet_group_infer_u8", "mi_unet_group_infer_raw16",
@@ -92,6 +92,7 @@ def lib():
         L.mi_unet_default_config.argtypes = [C.POINTER(Config)]
         L.mi_unet_default_config.restype = None
         L.mi_unet_clone.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_void_p)]
+        L.mi_unet_last_stage_ms.argtypes = [C.c_void_p, C.POINTER(C.c_float)]
         L.mi_unet_debug_layer_count.argtypes = [C.c_void_p]
         L.mi_unet_debug_layer_info.argtypes = [C.c_void_p, C.c_int, C.POINTER(LayerInfo)]
         L.mi_unet_debug_capture.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p,
@@ -285,6 +286,14 @@ class Engine:
         ms = C.c_float()
         _check(lib().mi_unet_timer_end(self._h, C.byref(ms)))
         return float(ms.value)
+
+    STAGES = ("upload_preprocess", "network", "postprocess", "contours", "download")
+
+    def last_stage_ms(self):
+        """device time per stage of the last infer_raw16 / segment_raw16 call (mi_unet_last_stage_ms)"""
+        ms = (C.c_float * len(self.STAGES))()
+        _check(lib().mi_unet_last_stage_ms(self._h, ms))
+        return dict(zip(self.STAGES, (float(v) for v in ms)))
 
     def layers(self):
         """the launch plan, step by step (mi_unet_debug_layer_info): list of dicts with name / kind / per-image shapes"""
