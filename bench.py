@@ -271,14 +271,35 @@ def run_pipeline(binding, synth, dev_index, nimg=16):
                        "masks so contours exist), 4-level base-64 fp32 UNet"}
     with binding.Engine(512, 512, max_batch=nimg, device=dev_index) as eng:
         eng.load_weights(blob)
-        tiles, masks, cont = eng.segment_raw16(raws, 1 << 15, 64)        # warm-up (staging buffers grow once)
-        t0 = time.perf_counter()
-        reps = 3
-        for _ in range(reps):
-            tiles, masks, cont = eng.segment_raw16(raws, 1 << 15, 64)
-        dt = (time.perf_counter() - t0) / reps
+
+        def timed(images):
+            """the C call alone -- argument block and output buffers prepared once, Python decoding outside the clock"""
+            prep = eng.segment_raw16_prepare(images, 1 << 15, 64)
+            for _ in range(2):
+                eng.segment_raw16_run(prep)                              # warm-up: staging buffers grow, graphs are captured
+            reps = 5
+            t0 = time.perf_counter()
+            for _ in range(reps):
+                eng.segment_raw16_run(prep)
+            dt = (time.perf_counter() - t0) / reps
+            return dt, eng.last_stage_ms(), eng.segment_raw16_decode(prep)
+
+        dt, stages, (tiles, masks, cont) = timed(raws)
+        # the same images in page-locked host memory (mi_unet_host_alloc): no staging copy on the calling thread
+        pins = [binding.PinnedArray(r.shape, np.uint16) for r in raws]
+        for pa, r in zip(pins, raws):
+            pa.a[...] = r
+        dt_p, stages_p, (tiles_p, masks_p, cont_p) = timed([pa.a for pa in pins])
+        pinned_same = bool(np.array_equal(tiles_p, tiles) and np.array_equal(masks_p, masks) and cont_p == cont)
+        tiles, masks = tiles.copy(), masks.copy()
+        for pa in pins:
+            pa.close()
     out["device_one_call"] = {"images_per_s": nimg / dt, "ms_per_image": dt / nimg * 1e3,
-                              "contours_first_image": len(cont[0]) if cont[0] is not None else -1}
+                              "contours_first_image": len(cont[0]) if cont[0] is not None else -1, "stages_ms": stages,
+                              "what": "mi_unet_segment_raw16, RAW images in ordinary (pageable) host memory"}
+    out["device_one_call_pinned"] = {"images_per_s": nimg / dt_p, "ms_per_image": dt_p / nimg * 1e3, "stages_ms": stages_p,
+                                     "same_results": pinned_same,
+                                     "what": "the same call with the RAW images in page-locked host memory (mi_unet_host_alloc)"}
     # parity of image 0 against the oracle chain, which is also the all-CPU timing sample
     t0 = time.perf_counter()
     tile0 = orc.preprocess_raw(raws[0])
@@ -290,6 +311,7 @@ def run_pipeline(binding, synth, dev_index, nimg=16):
                         "sample": "1 image: orc_preprocess_raw + orc_unet_forward + orc_postprocess_mask + orc_find_contours"}
     out["parity"] = {"tile_equal": bool(np.array_equal(tiles[0], tile0)), "mask_equal": bool(np.array_equal(masks[0], vis0)),
                      "contours_equal": cont[0] == cont0}
+    out["parity"]["pinned_route_equal"] = pinned_same
     out["parity"]["ok"] = all(out["parity"].values())
     with tempfile.TemporaryDirectory() as d:
         os.makedirs(os.path.join(d, "engine"))
@@ -324,6 +346,27 @@ def run_pipeline(binding, synth, dev_index, nimg=16):
                     t0 = time.perf_counter()
                     ok = hostlib.process_image_batch(paths, ws, hs, od)
                 dt = time.perf_counter() - t0
+                if route == "facade_device":
+                    # the reference's own call pattern: MedicalSeg::process_single_image in a loop, one image per call
+                    od1 = os.path.join(d, "out_single")
+                    os.makedirs(od1)
+                    for p in paths[:3]:
+                        hostlib.process_single_image(p, 2048, 1536, od1)                               # warm-up
+                    t1 = time.perf_counter()
+                    ok1 = sum(hostlib.process_single_image(p, 2048, 1536, od1) for p in paths)
+                    dt1 = time.perf_counter() - t1
+                    stage_lines = [l for l in open(hostlib.get_log_path()).read().splitlines() if "Stage times (ms):" in l]
+                    single = {"single_image_ms": dt1 / nimg * 1e3, "images_per_s": nimg / dt1, "succeeded": int(ok1),
+                              "what": "MedicalSeg::process_single_image per file (mapped RAW -> one device call -> five artefacts "
+                                      "written concurrently), 2048x1536 RAW16"}
+                    if stage_lines:
+                        import re
+                        vals = [[float(x) for x in re.findall(r"(?<![\w.])(\d+\.\d+)", l.split("Stage times (ms):")[1])] for l in stage_lines[-nimg:]]
+                        names = ["read", "device_call", "upload_preprocess", "network", "postprocess", "contours", "download", "artefacts",
+                                 "normalized_png_and_sizes_json", "mask_png", "overlay_png_and_polygon_json"]
+                        if all(len(v) == len(names) for v in vals):
+                            single["stages_ms_mean"] = {n: sum(v[i] for v in vals) / len(vals) for i, n in enumerate(names)}
+                    out["facade_single_image"] = single
                 hostlib.cleanup_resources()
             finally:
                 os.dup2(saved, 1)
@@ -405,16 +448,9 @@ def finish_group_child(child, run, deadline_s=240):
     if child is None:
         return None
     try:
-        child.stdin.write("go\n" if run else "no\n")
-        child.stdin.flush()
-        child.stdin.close()
-    except Exception:
-        pass
-    if not run:
-        child.wait(timeout=30)
-        return None
-    try:
-        out, _ = child.communicate(timeout=deadline_s)
+        out, _ = child.communicate(input="go\n" if run else "no\n", timeout=deadline_s if run else 30)
+        if not run:
+            return None
         lines = [l for l in out.splitlines() if l.startswith("{")]
         return json.loads(lines[-1]) if lines else {"error": f"group child exited {child.returncode} without a record"}
     except subprocess.TimeoutExpired:
@@ -693,7 +729,10 @@ def main():
                 out["pipeline"] = {"error": repr(e)}
         if group_child is not None:
             # ---- 6b. the C++ host's own multi-GPU path, one process over every visible device (a child process; see group_child_main)
-            out["group"] = finish_group_child(group_child, run=True)
+            try:
+                out["group"] = finish_group_child(group_child, run=True)
+            except Exception as e:                                            # an extra record never costs the headline
+                out["group"] = {"error": repr(e)}
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(blob, H, W, spec.in_ch, oracle_s)
         else:

@@ -120,6 +120,13 @@ int mi_unet_segment_raw16(mi_unet_t *h, const uint16_t *const *raws, const int *
                           uint8_t *tiles, uint8_t *masks, int32_t *xy, int cap_points, int32_t *start, int cap_contours,
                           int32_t *counts);
 
+/* Page-locked host memory.  RAW images handed to mi_unet_infer_raw16 / mi_unet_segment_raw16 (and their group forms) from such
+ * a buffer are read by the DMA engine directly -- no staging copy on the calling thread (100 MB for sixteen 2048 x 1536 images:
+ * 3 - 5 ms of memcpy that the pageable route pays).  Any hipHostMalloc'd / hipHostRegister'ed pointer is recognised, not only
+ * these; ordinary pointers keep working through the engine's own pinned ring. */
+int mi_unet_host_alloc(size_t bytes, void **p);
+void mi_unet_host_free(void *p);
+
 /* Device time of the stages of the LAST mi_unet_infer_raw16 / mi_unet_segment_raw16 call on this handle, in milliseconds, summed
  * over its micro-batches (hipEvent pairs on the streams the stages run on; the upload / preprocess stage of micro-batch k + 1
  * runs on a second stream under the network of micro-batch k, so the stages may add up to more than the call took).  The
@@ -164,6 +171,17 @@ int mi_unet_get_kernel_stats(mi_unet_t *h, mi_unet_kernel_stat *stats, int cap, 
  * Weights are given in PyTorch layout exactly as in the weight file. */
 int mi_unet_layer_debug(int device, const char *op, const float *in, int B, int H, int W, int Cin, const float *w,
                         const float *scale, const float *shift, int Cout, int relu, float *out);
+
+/* Numeric guard of the default fp32 plan (conv_algo auto / winograd).  Winograd F(4x4,3x3) is exact arithmetic re-associated:
+ * its rounding error relative to a layer's operand range is about five times that of F(2x2,3x3) (2e-5 against 4e-6 on logits
+ * of magnitude 4), and the path's bar is absolute (logits within 1e-3 of the fp32 reference, BASELINE north_star).  Whether
+ * F(4x4) holds that bar therefore depends on the dynamic range of the loaded weights.  Guarantee: when weights are loaded, one
+ * probe tile runs through the plan with every 3x3 layer on F(4x4) and again with every 3x3 layer on F(2x2); if the logits differ
+ * by more than 5e-4 (half the bar; the difference of the two plans overstates either one's own error), this handle -- and its clones -- runs F(2x2,3x3) on every layer.  The returned
+ * text says which (the facade logs it); *tripped / *diff (may be NULL) receive the decision and the measured difference.
+ * Beyond logits of magnitude ~1e2 no fp32 algorithm holds an ABSOLUTE 1e-3 (fp32 itself resolves 6e-8 of the range per
+ * operation); there the guard still picks the tighter algorithm and the meaningful bound is relative (~1e-6 of the range). */
+const char *mi_unet_numeric_guard(const mi_unet_t *h, int *tripped, float *diff);
 
 /* In-situ parity hook (tests): what the engine's OWN launch plan does to its OWN activations, layer by layer, at any size.
  * The opaque seam this opens is the reference's graph replay (src/process.cpp:143-155), whose intermediate tensors nobody

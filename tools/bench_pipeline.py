@@ -38,6 +38,11 @@ def main():
         print(f"  postprocess_masks (host labels in/out)      {t(lambda: eng.postprocess_masks(labels)):8.2f} ms")
         print(f"  extract_contours (host masks in)            {t(lambda: eng.extract_contours(vis, 1 << 15, 64)):8.2f} ms")
         print(f"  segment_raw16 (everything, one call)        {t(lambda: eng.segment_raw16(raws, 1 << 15, 64)):8.2f} ms")
+        print("    device time per stage (ms):", {k: round(v, 3) for k, v in eng.last_stage_ms().items()})
+        with binding.Engine(512, 512, max_batch=1) as e1:                       # the per-thread context of process_single_image
+            e1.load_weights(blob)
+            print(f"  segment_raw16, ONE image on a max_batch-1 engine   {t(lambda: e1.segment_raw16(raws[:1], 1 << 15, 64), 10):8.2f} ms")
+            print("    device time per stage (ms):", {k: round(v, 3) for k, v in e1.last_stage_ms().items()})
         nc = [len(c) for c in eng.extract_contours(vis, 1 << 15, 64)]
         print("  contours per image:", nc[:8], "points in the longest:", max((len(c) for cs in eng.extract_contours(vis, 1 << 15, 64) for c in cs), default=0))
     # host facade: directory mode, batch vs single
@@ -69,6 +74,11 @@ def main():
                 lines = [l.strip() for l in open(os.path.join(root, f), errors="replace") if l.startswith("Batch ")]
                 print("  facade log (last batch):", "; ".join(lines[-3:]))
         print(f"  facade process_image_batch: {tb / B * 1e3:.2f} ms/image ({n} ok); process_single_image loop: {ts / B * 1e3:.2f} ms/image")
+        for root, _, files in os.walk(os.path.join(d, "log")):
+            for f in files:
+                lines = [l.strip() for l in open(os.path.join(root, f), errors="replace") if "Stage times" in l]
+                for l in lines[-3:]:
+                    print("  ", l)
 
 
 if __name__ == "__main__":

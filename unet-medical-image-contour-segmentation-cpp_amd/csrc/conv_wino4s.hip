@@ -337,7 +337,13 @@ static hipError_t launch_wino4s_cfg(const ConvArgs &a, hipStream_t s)
     const int m_tiles = tiles_x * tiles_y * a.B;
     const int n_tiles = (a.Cout + 63) / 64;
     const int nwg = m_tiles * n_tiles;
-    const size_t lds_bytes = HEAD ? W4S::LDS_BYTES_HEAD : W4S::LDS_BYTES;
+    size_t lds_bytes = HEAD ? W4S::LDS_BYTES_HEAD : W4S::LDS_BYTES;
+    // experiment switch: MIUNET_WINO4S_ONE_WG=1 asks for more than half a CU's LDS, so only ONE workgroup is
+    // resident per CU -- the same kernel, same instructions, without its co-resident partner.  What that costs is what any
+    // one-workgroup-per-CU re-tiling of these layers (a 32-tile block on v_mfma_f32_32x32x2_f32 needs 56 % of the register
+    // file for its accumulators alone) would first have to win back.
+    static const bool one_wg = [] { const char *e = getenv("MIUNET_WINO4S_ONE_WG"); return e && e[0] == '1'; }();
+    if (one_wg) lds_bytes = 96 * 1024;
     auto kern = conv3x3_wino4s_f32<HEAD, 3>;
     if (hipError_t e = ensure_dynamic_lds(kern, lds_bytes); e != hipSuccess) return e;
     hipLaunchKernelGGL(kern, dim3(nwg), dim3(256), lds_bytes, s, a, tiles_x, tiles_y, m_tiles, nwg);

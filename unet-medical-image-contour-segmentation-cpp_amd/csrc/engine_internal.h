@@ -36,6 +36,8 @@ int engine_pack_weights(const mi_unet_config &cfg, int algo, const void *blob, s
 // allocate the device blob of `h` for `hw` (uploading hw.blob when `upload`, else leaving the bytes to the caller: a
 // broadcast or a peer copy fills engine_weight_ptr()), then build the launch plan
 int engine_adopt_weights(mi_unet_t *h, const HostWeights &hw, bool upload);
+// the numeric guard of the default fp32 plan, run once the weight bytes are on the device (engine.cpp)
+int engine_calibrate(mi_unet_t *h);
 float *engine_weight_ptr(mi_unet_t *h);
 size_t engine_weight_floats(const mi_unet_t *h);
 int engine_algo(const mi_unet_t *h);

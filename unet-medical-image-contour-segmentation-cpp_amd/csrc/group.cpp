@@ -249,7 +249,7 @@ int mi_unet_group_load_weights_from_memory(mi_unet_group_t *g, const void *blob,
     const int R = (int)g->eng.size();
     for (int r = 0; r < R; ++r)
         if (int rc = engine_adopt_weights(g->eng[r], hw, /*upload=*/r == 0)) return rc;
-    if (R == 1 && g->comms.empty()) return MI_UNET_OK;
+    if (R == 1 && g->comms.empty()) return engine_calibrate(g->eng[0]);
     const size_t bytes = sizeof(float) * hw.blob.size();
     // Transport ladder for ranks > 0: RCCL broadcast over xGMI -> device-to-device peer copies -> one upload per device from
     // the host blob.  A rung that fails is reported in the transport string and the next one is taken: the weights always
@@ -287,6 +287,8 @@ int mi_unet_group_load_weights_from_memory(mi_unet_group_t *g, const void *blob,
             HIP_TRY_G(hipMemcpy(engine_weight_ptr(g->eng[r]), hw.blob.data(), bytes, hipMemcpyHostToDevice));
         }
     }
+    for (int r = 0; r < R; ++r)                          // every rank probes its own copy: same weights, same decision
+        if (int rc = engine_calibrate(g->eng[r])) return rc;
     return MI_UNET_OK;
 }
 

@@ -153,6 +153,7 @@ bool initialize_engine(const std::string &trt_cache_path, const std::string &log
                    << " classes=" << g_cfg.classes << ", tile " << g_cfg.width << "x" << g_cfg.height << std::endl;
         g_log_file << "  Devices: " << mi_unet_group_size(g_group) << " (weights to ranks > 0 by "
                    << mi_unet_group_weight_transport(g_group) << "), micro-batch " << g_cfg.max_batch << " per device" << std::endl;
+        g_log_file << "  " << mi_unet_numeric_guard(mi_unet_group_handle(g_group, 0), nullptr, nullptr) << std::endl;
         g_log_file << "  Input size: " << (size_t)g_cfg.height * g_cfg.width * g_cfg.in_ch << " bytes (u8)" << std::endl;
         g_log_file << "  Output size: " << (size_t)g_cfg.height * g_cfg.width << " bytes (classes=" << g_cfg.classes << ")" << std::endl;
         return true;
@@ -311,9 +312,47 @@ bool device_postprocess_requested()
 // log text is collected per image and emitted in file order, chunk after chunk, by the calling thread.
 namespace {
 
+// Page-locked buffers for the RAW files of directory mode (mi_unet_host_alloc): the reader threads copy page cache -> pinned,
+// the engine's DMA reads them directly, and the device thread no longer pays a staging memcpy per image.  Pinning memory is
+// slow (a millisecond per 6 MB), so buffers are recycled across chunks and calls and released by cleanup_resources().
+class PinnedPool {
+public:
+    struct Buf { uint16_t *p = nullptr; size_t cap = 0; };
+    Buf acquire(size_t samples)
+    {
+        {
+            std::lock_guard<std::mutex> lk(m_);
+            for (size_t i = 0; i < free_.size(); ++i)
+                if (free_[i].cap >= samples) { Buf b = free_[i]; free_.erase(free_.begin() + i); return b; }
+        }
+        Buf b;
+        void *p = nullptr;
+        if (mi_unet_host_alloc(samples * sizeof(uint16_t), &p) != MI_UNET_OK) throw std::runtime_error(std::string("pinned allocation failed: ") + mi_unet_last_error());
+        b.p = static_cast<uint16_t *>(p); b.cap = samples;
+        return b;
+    }
+    void release(Buf b)
+    {
+        if (!b.p) return;
+        std::lock_guard<std::mutex> lk(m_);
+        free_.push_back(b);
+    }
+    void clear()
+    {
+        std::lock_guard<std::mutex> lk(m_);
+        for (Buf &b : free_) mi_unet_host_free(b.p);
+        free_.clear();
+    }
+
+private:
+    std::mutex m_;
+    std::vector<Buf> free_;
+};
+PinnedPool g_pinned;
+
 struct ChunkIn {
     size_t first = 0, count = 0;                       // range of the caller's lists
-    std::vector<std::vector<uint16_t>> raws;           // per file of the range (empty = unreadable)
+    std::vector<PinnedPool::Buf> raws;                 // per file of the range (p == nullptr: unreadable)
     std::vector<std::string> read_err;
     long long read_ms = 0;
 };
@@ -346,10 +385,13 @@ ChunkIn read_chunk(const std::vector<std::string> &paths, const std::vector<int>
 #pragma omp parallel for schedule(dynamic) num_threads(nt)
     for (long long k = 0; k < (long long)count; ++k) {
         try {
-            in.raws[k] = Preprocess::read_raw16(paths[first + k], widths[first + k], heights[first + k]);
+            const Preprocess::RawView view(paths[first + k], widths[first + k], heights[first + k]);
+            in.raws[k] = g_pinned.acquire(view.samples());
+            std::memcpy(in.raws[k].p, view.data(), view.samples() * sizeof(uint16_t));
         } catch (const std::exception &e) {
             in.read_err[k] = std::string("Processing error: ") + e.what() + " (" + paths[first + k] + ")";
-            in.raws[k].clear();
+            g_pinned.release(in.raws[k]);
+            in.raws[k] = PinnedPool::Buf{};
         }
     }
     in.read_ms = std::chrono::duration_cast<std::chrono::milliseconds>(std::chrono::high_resolution_clock::now() - t0).count();
@@ -366,7 +408,7 @@ ChunkOut device_chunk(const ChunkIn &in, const std::vector<int> &widths, const s
         if (in.read_err[k].empty()) {
             out.idx.push_back(k);
             for (int c = 0; c < C; ++c) {      // one plane per file: it feeds every input channel (include/mi_unet.h, mi_unet_infer_raw16)
-                ptrs.push_back(in.raws[k].data()); ws.push_back(widths[in.first + k]); hs.push_back(heights[in.first + k]);
+                ptrs.push_back(in.raws[k].p); ws.push_back(widths[in.first + k]); hs.push_back(heights[in.first + k]);
             }
         }
     if (out.idx.empty()) return out;
@@ -399,7 +441,7 @@ ChunkText artefact_chunk(const ChunkIn &in, const ChunkOut &out, const std::vect
     for (long long k = 0; k < (long long)m; ++k) {
         const size_t i = in.first + out.idx[k];
         std::ostringstream con, lg;
-        medseg::set_png_threads(m > 1 ? 1 : 8);    // the images of a chunk are already written in parallel: no band threads inside
+        medseg::set_png_threads(m > 1 ? 1 : 16);    // the images of a chunk are already written in parallel: no band threads inside
         try {
             const std::string base_name = fs::path(paths[i]).stem().string();
             lg << "\n=== Processing Image: " << fs::path(paths[i]).filename().string() << " ===" << std::endl;
@@ -520,10 +562,10 @@ int process_batch_pipelined(const std::vector<std::string> &paths, const std::ve
         dev_q.push_back({ st, std::async(std::launch::async, [st, lane, &widths, &heights] {
             try {
                 st->out = device_chunk(st->in, widths, heights, lane);
-                for (auto &r : st->in.raws) std::vector<uint16_t>().swap(r);      // the RAW images are on the device's side now
             } catch (const std::exception &e) {
                 st->dev_err = e.what();
             }
+            for (auto &r : st->in.raws) { g_pinned.release(r); r = PinnedPool::Buf{}; }     // the RAW images are on the device's side now
         }) });
     }
     while (!dev_q.empty()) retire_oldest();
@@ -799,6 +841,7 @@ void cleanup_resources()
             if (log_file.is_open()) log_file << "Execution context destroyed" << std::endl;
         }
         ++g_generation;
+        g_pinned.clear();
         if (g_lane2) { mi_unet_group_destroy(g_lane2); g_lane2 = nullptr; }
         if (g_group) {
             mi_unet_group_destroy(g_group);         // every device's buffers, streams, worker thread, weights

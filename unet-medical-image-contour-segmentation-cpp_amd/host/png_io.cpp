@@ -77,7 +77,7 @@ void deflate_band(const Image8 &img, Band &bd, int level, int strategy, bool las
 
 }  // namespace
 
-static thread_local int t_png_threads = 8;
+static thread_local int t_png_threads = 16;
 void set_png_threads(int n) { t_png_threads = n < 1 ? 1 : n; }
 
 bool write_png(const std::string &path, const Image8 &img, bool level0)
@@ -92,7 +92,7 @@ bool write_png(const std::string &path, const Image8 &img, bool level0)
     // level 1 with the run-length strategy -- fast, and the compressed bytes are not part of any contract (the pixels are)
     const int level = level0 ? 0 : 1, strategy = level0 ? Z_DEFAULT_STRATEGY : Z_RLE;
     const size_t total = ((size_t)img.cols * img.channels + 1) * img.rows;
-    int nb = level0 ? 1 : (int)std::min<size_t>((size_t)t_png_threads, std::max<size_t>(1, total / (64u << 10)));   // bands of >= 64 KB
+    int nb = level0 ? 1 : (int)std::min<size_t>((size_t)t_png_threads, std::max<size_t>(1, total / (48u << 10)));   // bands of >= 48 KB
     nb = std::max(1, std::min(nb, img.rows));
     std::vector<Band> bands(nb);
     for (int b = 0; b < nb; ++b) {

@@ -10,7 +10,7 @@
 namespace medseg {
 
 bool write_png(const std::string &path, const Image8 &img, bool level0);
-// A deflated PNG is compressed in up to n bands of rows on n threads (default 8).  Per calling thread: directory mode, which
+// A deflated PNG is compressed in up to n bands of rows on n threads (default 16).  Per calling thread: directory mode, which
 // already writes its images on several host threads, sets 1 on those.
 void set_png_threads(int n);
 // as_color = false: cv::IMREAD_GRAYSCALE (colour inputs are reduced with OpenCV's integer BT.601 weights);

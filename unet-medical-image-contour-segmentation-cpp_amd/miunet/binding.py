@@ -19,7 +19,7 @@ EXPORTS = [
     "mi_unet_infer_u8", "mi_unet_infer_u8_device", "mi_unet_infer_raw16", "mi_unet_set_postprocess", "mi_unet_postprocess_masks", "mi_unet_extract_contours", "mi_unet_segment_raw16", "mi_unet_set_stream", "mi_unet_sync", "mi_unet_timer_begin",
     "mi_unet_timer_end", "mi_unet_set_profiling", "mi_unet_get_kernel_stats", "mi_unet_layer_debug", "mi_unet_destroy",
     "mi_unet_last_error", "mi_unet_device_count", "mi_unet_clone",
-    "mi_unet_debug_layer_count", "mi_unet_debug_layer_info", "mi_unet_debug_capture", "mi_unet_last_stage_ms",
+    "mi_unet_debug_layer_count", "mi_unet_debug_layer_info", "mi_unet_debug_capture", "mi_unet_last_stage_ms", "mi_unet_numeric_guard", "mi_unet_host_alloc", "mi_unet_host_free",
     "mi_unet_group_create", "mi_unet_group_clone", "mi_unet_group_size", "mi_unet_group_handle", "mi_unet_group_load_weights",
     "mi_unet_group_load_weights_from_memory", "mi_unet_group_set_gather", "mi_unet_group_set_postprocess",
     "mi_unet_group_weight_transport", "mi_unet_group_gather", "mi_unet_group_infer_u8", "mi_unet_group_infer_raw16",
@@ -92,6 +92,11 @@ def lib():
         L.mi_unet_default_config.argtypes = [C.POINTER(Config)]
         L.mi_unet_default_config.restype = None
         L.mi_unet_clone.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_void_p)]
+        L.mi_unet_host_alloc.argtypes = [C.c_size_t, C.POINTER(C.c_void_p)]
+        L.mi_unet_host_free.argtypes = [C.c_void_p]
+        L.mi_unet_host_free.restype = None
+        L.mi_unet_numeric_guard.argtypes = [C.c_void_p, C.POINTER(C.c_int), C.POINTER(C.c_float)]
+        L.mi_unet_numeric_guard.restype = C.c_char_p
         L.mi_unet_last_stage_ms.argtypes = [C.c_void_p, C.POINTER(C.c_float)]
         L.mi_unet_debug_layer_count.argtypes = [C.c_void_p]
         L.mi_unet_debug_layer_info.argtypes = [C.c_void_p, C.c_int, C.POINTER(LayerInfo)]
@@ -124,6 +129,29 @@ def lib():
 def _check(rc):
     if rc != 0:
         raise MiUnetError(rc, lib().mi_unet_last_error().decode(errors="replace"))
+
+
+class PinnedArray:
+    """A numpy view of page-locked host memory (mi_unet_host_alloc): RAW images kept in one are uploaded without a staging copy.
+    Keep the object alive as long as the view `.a` is used; close() (or garbage collection) releases the memory."""
+
+    def __init__(self, shape, dtype):
+        self._p = C.c_void_p()
+        n = int(np.prod(shape)) * np.dtype(dtype).itemsize
+        _check(lib().mi_unet_host_alloc(n, C.byref(self._p)))
+        self.a = np.ctypeslib.as_array(C.cast(self._p, C.POINTER(C.c_uint8)), shape=(n,)).view(dtype).reshape(shape)
+
+    def close(self):
+        if self._p:
+            self.a = None
+            lib().mi_unet_host_free(self._p)
+            self._p = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
 
 
 def device_count() -> int:
@@ -246,22 +274,34 @@ class Engine:
             out.append([[tuple(p) for p in xy[i, start[i, c]:start[i, c + 1]].tolist()] for c in range(counts[i])])
         return out
 
-    def segment_raw16(self, raws, cap_points=8192, cap_contours=64):
-        """RAW16 images -> (tiles, mask images 0/255, contours per image) with every stage on the device"""
+    def segment_raw16_prepare(self, raws, cap_points=8192, cap_contours=64):
+        """argument block of mi_unet_segment_raw16 for these images: pointer arrays and caller-owned output buffers, built once"""
         c = self.cfg
         raws, ptrs, ws, hs, b = self._raw_args(raws)
-        tiles = self._tile_buf(b)
-        masks = np.empty((b, c.height, c.width), np.uint8)
-        xy = np.zeros((b, cap_points, 2), np.int32)
-        start = np.zeros((b, cap_contours + 1), np.int32)
-        counts = np.zeros(b, np.int32)
-        _check(lib().mi_unet_segment_raw16(self._h, ptrs, ws, hs, b, _ptr(tiles), _ptr(masks), _ptr(xy), cap_points, _ptr(start),
-                                           cap_contours, _ptr(counts)))
+        return dict(raws=raws, ptrs=ptrs, ws=ws, hs=hs, b=b, cap_points=cap_points, cap_contours=cap_contours,
+                    tiles=self._tile_buf(b), masks=np.empty((b, c.height, c.width), np.uint8),
+                    xy=np.zeros((b, cap_points, 2), np.int32), start=np.zeros((b, cap_contours + 1), np.int32),
+                    counts=np.zeros(b, np.int32))
+
+    def segment_raw16_run(self, p):
+        """the C call alone (what a C or C++ host pays)"""
+        _check(lib().mi_unet_segment_raw16(self._h, p["ptrs"], p["ws"], p["hs"], p["b"], _ptr(p["tiles"]), _ptr(p["masks"]), _ptr(p["xy"]),
+                                           p["cap_points"], _ptr(p["start"]), p["cap_contours"], _ptr(p["counts"])))
+
+    @staticmethod
+    def segment_raw16_decode(p):
+        xy, start, counts = p["xy"], p["start"], p["counts"]
         cont = []
-        for i in range(b):
+        for i in range(p["b"]):
             cont.append(None if counts[i] < 0 else
-                        [[tuple(p) for p in xy[i, start[i, k]:start[i, k + 1]].tolist()] for k in range(counts[i])])
-        return tiles, masks, cont
+                        [[tuple(q) for q in xy[i, start[i, k]:start[i, k + 1]].tolist()] for k in range(counts[i])])
+        return p["tiles"], p["masks"], cont
+
+    def segment_raw16(self, raws, cap_points=8192, cap_contours=64):
+        """RAW16 images -> (tiles, mask images 0/255, contours per image) with every stage on the device"""
+        p = self.segment_raw16_prepare(raws, cap_points, cap_contours)
+        self.segment_raw16_run(p)
+        return self.segment_raw16_decode(p)
 
     def infer_device(self, d_imgs_ptr: int, b: int, d_labels_ptr: int, d_logits_ptr: int = 0):
         _check(lib().mi_unet_infer_u8_device(self._h, C.c_void_p(d_imgs_ptr), b, C.c_void_p(d_labels_ptr),
@@ -286,6 +326,12 @@ class Engine:
         ms = C.c_float()
         _check(lib().mi_unet_timer_end(self._h, C.byref(ms)))
         return float(ms.value)
+
+    def numeric_guard(self):
+        """(text, tripped, diff) of mi_unet_numeric_guard: did this weight set keep F(4x4,3x3)?"""
+        t, d = C.c_int(), C.c_float()
+        text = lib().mi_unet_numeric_guard(self._h, C.byref(t), C.byref(d)).decode()
+        return text, bool(t.value), float(d.value)
 
     STAGES = ("upload_preprocess", "network", "postprocess", "contours", "download")
 
