@@ -355,7 +355,9 @@ def run_pipeline(binding, synth, dev_index, nimg=16):
                     t1 = time.perf_counter()
                     ok1 = sum(hostlib.process_single_image(p, 2048, 1536, od1) for p in paths)
                     dt1 = time.perf_counter() - t1
-                    stage_lines = [l for l in open(hostlib.get_log_path()).read().splitlines() if "Stage times (ms):" in l]
+                    log_text = open(hostlib.get_log_path()).read()
+                    stage_lines = [l for l in log_text.splitlines() if "Stage times (ms):" in l]
+                    out["facade_numeric_guard"] = next((l.strip() for l in log_text.splitlines() if "numeric guard" in l), None)
                     single = {"single_image_ms": dt1 / nimg * 1e3, "images_per_s": nimg / dt1, "succeeded": int(ok1),
                               "what": "MedicalSeg::process_single_image per file (mapped RAW -> one device call -> five artefacts "
                                       "written concurrently), 2048x1536 RAW16"}

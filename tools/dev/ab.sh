@@ -9,7 +9,7 @@ for round in 1 2; do
   for v in "$@"; do
     name=${v%%:*}; envs=${v#*:}
     env $envs python bench.py $extra --steps 10 --warmup 3 --no-cpu-baseline --no-extras --per-layer \
-        > "$out/${name}_r${round}.json" 2> "$out/${name}_r${round}.txt"
+        > "$out/${name}_r${round}.json" 2> "$out/${name}_r${round}.txt" || echo "  ($name: bench exit code $? -- expected for timing-only experiment builds whose results are wrong)"
     python - "$out/${name}_r${round}.json" "$name r$round" <<'PY'
 import json,sys
 d=json.loads(open(sys.argv[1]).read().strip().splitlines()[-1])

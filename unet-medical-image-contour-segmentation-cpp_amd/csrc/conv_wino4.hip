@@ -46,7 +46,11 @@ __device__ __forceinline__ void mfma16_vgpr(f32x4 &acc, const float a, const flo
 // SPLITK: the grid carries a.ksplit workgroups per tile, each walks one slice of the K chunks and writes its raw 4x4
 // outputs into slab [slice][B][H][W][Cout] of a.ksplit_ws; wino_splitk_reduce (conv_wino.hip) sums the slabs in slice order
 // (deterministic) and applies shift / ReLU / pooling.  For grids that cannot fill the chip (single images, deep levels).
-template <int NB, bool HEAD, bool SPLITK>
+// EXP != 0: timing-only experiment builds (MIUNET_W4_EXP, results are WRONG, never routed by default; DESIGN 4.3 "what the
+// transform's role split costs"): 1 = every wave runs the one-row transform role (no role branches, half the transform
+// VALU), 2 = every wave runs wave 0's two-row role (no role branches, same VALU as the heaviest wave), 3 = no forward
+// transform at all, 4 = the inverse transform and the stores replaced by a checksum of the accumulators.
+template <int NB, bool HEAD, bool SPLITK, int EXP = 0>
 __global__ __launch_bounds__(256, 1) void conv3x3_wino4_f32(const ConvArgs a, const int tiles_x, const int tiles_y,
                                                             const int m_tiles, const int nwg)
 {
@@ -116,12 +120,13 @@ __global__ __launch_bounds__(256, 1) void conv3x3_wino4_f32(const ConvArgs a, co
     // ---- stage 2: V = B^T d B for one 16-channel chunk; lane = (tile, channel quad), wave = row group of B^T:
     //   wave 0: xi 1, 2 = (d4 - 4 d2) +- (d3 - 4 d1)        wave 1: xi 3, 4 = (d4 - d2) +- (2 d3 - 2 d1)
     //   wave 2: xi 0    = 4 d0 - 5 d2 + d4                  wave 3: xi 5    = 4 d1 - 5 d3 + d5
-    const bool two = wave < 2;
+    const int wrole = EXP == 1 ? 2 : EXP == 2 ? 0 : wave;      // the transform role this wave plays
+    const bool two = wrole < 2;
     const int t_tile = lane >> 2, t_quad = lane & 3;
-    const int row0 = two ? 1 : wave - 2, rstep = two ? 1 : 2;
+    const int row0 = two ? 1 : wrole - 2, rstep = two ? 1 : 2;
     const float *const p_rd = Raw + (((4 * (t_tile >> 2) + row0) * W4::RAW_ROW + (t_tile & 3)) * 4 + t_quad) * 4;
     const int p_rstride = rstep * W4::RAW_ROW * WINO4_KC;
-    const int xi_a = two ? (wave == 0 ? 1 : 3) : (wave == 2 ? 0 : 5);
+    const int xi_a = two ? (wrole == 0 ? 1 : 3) : (wrole == 2 ? 0 : 5);
     float *const v_wr_a = Vs + xi_a * 6 * VPOS + t_tile * VROW + 4 * t_quad;      // + buf*VBUF + nu*VPOS; row b = + 6*VPOS
     f32x4 px_[4];                             // patch column k of this lane's rows
     f32x4 cR[2][6];                           // rows of B^T d (row b only on the two-row waves)
@@ -136,12 +141,12 @@ __global__ __launch_bounds__(256, 1) void conv3x3_wino4_f32(const ConvArgs a, co
     auto piece_col = [&](int k) {
         const f32x4 *d = px_;
         f32x4 ra, rb;
-        if (wave == 0) {
+        if (wrole == 0) {
             const f32x4 ta = d[3] - 4.f * d[1];
             const f32x4 tb = d[2] - 4.f * d[0];
             ra = ta + tb;
             rb = pk_sub(ta, tb);
-        } else if (wave == 1) {
+        } else if (wrole == 1) {
             const f32x4 ta = pk_sub(d[3], d[1]);
             const f32x4 tb = pk_sub(d[2], d[0]);
             ra = ta + 2.f * tb;
@@ -169,6 +174,7 @@ __global__ __launch_bounds__(256, 1) void conv3x3_wino4_f32(const ConvArgs a, co
     };
     // the transform of one chunk as 23 numbered pieces (0-5 load, 6-11 column pass, 12 prep a, 13-18 row a, 19 prep b ...)
     auto transform_all = [&](int rbuf, int buf) {
+        if constexpr (EXP == 3) return;
 #pragma unroll
         for (int k = 0; k < 6; ++k) { piece_load(k, rbuf); piece_col(k); }
         piece_prep(0);
@@ -275,7 +281,7 @@ __global__ __launch_bounds__(256, 1) void conv3x3_wino4_f32(const ConvArgs a, co
             // one load every fourth position, not a burst: 16 line misses at a time keep the VMEM queue moving, so the U loads
             // issued behind each of them are delayed by less than the U ring covers
             if (p % 4 == 0 && p / 4 < W4::RAW_ITERS) raw_dma_one(chunk + 2, par, p / 4);
-            if (p == 2) piece_load(0, rbuf);
+            if (EXP != 3 && p == 2) piece_load(0, rbuf);
             __builtin_amdgcn_sched_barrier(0);        // ... issued BEFORE this position's MFMAs (hipcc would sink them to their use)
             f32x4 bv[NB];
 #pragma unroll
@@ -287,7 +293,7 @@ __global__ __launch_bounds__(256, 1) void conv3x3_wino4_f32(const ConvArgs a, co
                     if (NB == 2 && p >= 32) mfma16_vgpr(acc[p][blk], av[s], bv[blk][s]);
                     else acc[p][blk] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[s], bv[blk][s], acc[p][blk], 0, 0, 0);
                 }
-                if (s == 1) {
+                if (EXP != 3 && s == 1) {
                     if (p >= 3 && p < 9) piece_col(p - 3);
                     if (p == 9) piece_prep(0);
                     if (p >= 10 && p < 16) piece_store(0, wr, p - 10);
@@ -297,7 +303,7 @@ __global__ __launch_bounds__(256, 1) void conv3x3_wino4_f32(const ConvArgs a, co
                     }
                     __builtin_amdgcn_sched_barrier(0);
                 }
-                if (s == 2 && p >= 3 && p < 8) {      // the next patch column, once the column pass above has consumed this one
+                if (EXP != 3 && s == 2 && p >= 3 && p < 8) {      // the next patch column, once the column pass above has consumed this one
                     piece_load(p - 2, rbuf);
                     __builtin_amdgcn_sched_barrier(0);
                 }
@@ -318,6 +324,15 @@ __global__ __launch_bounds__(256, 1) void conv3x3_wino4_f32(const ConvArgs a, co
     // initial value of position (1,1), whose inverse transform is the all-ones tile.  Stores are buffer stores on a
     // per-image descriptor: one per-lane byte offset for the whole tile row, the pixel displacement in the scalar offset;
     // pixels past the image edge and masked channels get voffset 0xFFFFFFFF, which the range check drops.
+    if constexpr (EXP == 4) {
+        f32x4 sum = f32x4{ 0.f, 0.f, 0.f, 0.f };
+#pragma unroll
+        for (int p = 0; p < 36; ++p)
+#pragma unroll
+            for (int blk = 0; blk < NB; ++blk) sum += acc[p][blk];
+        if (sum.x + sum.y + sum.z + sum.w == 12345.678f) a.out[tid] = sum.x;
+        return;
+    }
     const int e_b = b, e_by0 = by0, e_bx0 = bx0, e_ncol0 = ncol0;
     if constexpr (PERSIST) {
         if (tt + slots < t_count) {           // open the next tile: its loads fly during this tile's epilogue
@@ -480,6 +495,16 @@ static hipError_t launch_wino4_cfg(const ConvArgs &a0, hipStream_t s)
         const int grid = nwg * a.ksplit;
         hipLaunchKernelGGL(kern, dim3(grid), dim3(256), W4::LDS_BYTES, s, a, tiles_x, tiles_y, m_tiles, grid);
         return launch_wino_splitk_reduce(a, s);
+    }
+    if constexpr (NB == 2 && !HEAD) {                  // timing-only experiment builds of the two-block kernel (see the kernel's EXP)
+        static const int exp = [] { const char *e = getenv("MIUNET_W4_EXP"); return e ? atoi(e) : 0; }();
+        if (exp >= 1 && exp <= 4) {
+            auto ke = exp == 1 ? conv3x3_wino4_f32<2, false, false, 1> : exp == 2 ? conv3x3_wino4_f32<2, false, false, 2>
+                    : exp == 3 ? conv3x3_wino4_f32<2, false, false, 3> : conv3x3_wino4_f32<2, false, false, 4>;
+            if (hipError_t e = ensure_dynamic_lds(ke, W4::LDS_BYTES); e != hipSuccess) return e;
+            hipLaunchKernelGGL(ke, dim3(nwg), dim3(256), W4::LDS_BYTES, s, a, tiles_x, tiles_y, m_tiles, nwg);
+            return hipGetLastError();
+        }
     }
     auto kern = conv3x3_wino4_f32<NB, HEAD, false>;
     if (hipError_t e = ensure_dynamic_lds(kern, W4::LDS_BYTES); e != hipSuccess) return e;

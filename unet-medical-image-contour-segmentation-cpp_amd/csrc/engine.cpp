@@ -6,6 +6,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <chrono>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -104,8 +105,9 @@ struct mi_unet {
     hipEvent_t tile_ready[2] = {}, tile_free[2] = {};
     // stage timing of the last RAW-in call (mi_unet_last_stage_ms): event pairs per micro-batch, summed
     hipEvent_t stage_ev[2][5] = {}, out_done[2] = {};
-    hipEvent_t pre_ev[2][2] = {};
-    uint8_t *h_labels2 = nullptr;   // second pinned result buffer: micro-batch k + 1 downloads while the host still copies k out
+    hipEvent_t pre_ev[3][2] = {};   // three pairs: micro-batch k + 2 is staged before k's times are read
+    uint8_t *h_labels2 = nullptr;
+    uint8_t *h_tiles[2] = {};       // pinned mirrors of the tile buffers (a D2H into the caller's pageable memory would block the host)   // second pinned result buffer: micro-batch k + 1 downloads while the host still copies k out
     float stage_ms[MI_UNET_N_STAGES] = {};
     // pinned host staging (the reference used pageable std::vector, src/process.cpp:138,152)
     uint8_t *h_img = nullptr;
@@ -1279,12 +1281,16 @@ int ensure_raw_pipeline(mi_unet *h, bool two_buffers)
     for (int i = 0; i < 2; ++i) {
         for (hipEvent_t &e : h->stage_ev[i])
             if (!e) HIP_TRY(hipEventCreate(&e));
-        for (int j = 0; j < 2; ++j)
-            if (!h->pre_ev[i][j]) HIP_TRY(hipEventCreate(&h->pre_ev[i][j]));
         if (!h->out_done[i]) HIP_TRY(hipEventCreateWithFlags(&h->out_done[i], hipEventDisableTiming));
     }
+    for (int i = 0; i < 3; ++i)
+        for (int j = 0; j < 2; ++j)
+            if (!h->pre_ev[i][j]) HIP_TRY(hipEventCreate(&h->pre_ev[i][j]));
     if (two_buffers && !h->h_labels2)
         HIP_TRY(hipHostMalloc(&h->h_labels2, (size_t)h->cfg.max_batch * h->cfg.height * h->cfg.width, hipHostMallocDefault));
+    for (int i = 0; i < (two_buffers ? 2 : 1); ++i)
+        if (!h->h_tiles[i])
+            HIP_TRY(hipHostMalloc(&h->h_tiles[i], (size_t)h->cfg.max_batch * h->cfg.height * h->cfg.width * h->cfg.in_ch, hipHostMallocDefault));
     if (two_buffers && !h->d_img2)
         HIP_TRY(hipMalloc(&h->d_img2, (size_t)h->cfg.max_batch * h->cfg.height * h->cfg.width * h->cfg.in_ch));
     return 0;
@@ -1329,9 +1335,9 @@ int run_raw_call(mi_unet *h, const RawCall &c)
         const int bm = mbs[k].bm, par = k & 1;
         const size_t b0 = (size_t)mbs[k].b0;
         if (k >= 2) HIP_TRY(hipStreamWaitEvent(h->pre_stream, h->tile_free[par], 0));      // its last reader: micro-batch k - 2
-        HIP_TRY(hipEventRecord(h->pre_ev[par][0], h->pre_stream));
+        HIP_TRY(hipEventRecord(h->pre_ev[k % 3][0], h->pre_stream));
         if (int rc = stage_raw16(h, c.raws + b0 * C, c.widths + b0 * C, c.heights + b0 * C, bm, h->pre_stream, tile_buf(k))) return rc;
-        HIP_TRY(hipEventRecord(h->pre_ev[par][1], h->pre_stream));
+        HIP_TRY(hipEventRecord(h->pre_ev[k % 3][1], h->pre_stream));
         HIP_TRY(hipEventRecord(h->tile_ready[par], h->pre_stream));
         return 0;
     };
@@ -1361,7 +1367,7 @@ int run_raw_call(mi_unet *h, const RawCall &c)
             d_result = d_vis;
         }
         HIP_TRY(hipEventRecord(ev[3], s));
-        if (c.tiles) HIP_TRY(hipMemcpyAsync(c.tiles + b0 * hw * C, d_tiles, bm * hw * C, hipMemcpyDeviceToHost, s));
+        if (c.tiles) HIP_TRY(hipMemcpyAsync(h->h_tiles[par], d_tiles, bm * hw * C, hipMemcpyDeviceToHost, s));
         HIP_TRY(hipEventRecord(h->tile_free[par], s));
         HIP_TRY(hipMemcpyAsync(out_buf(k), d_result, bm * hw, hipMemcpyDeviceToHost, s));
         if (c.segment)
@@ -1378,10 +1384,11 @@ int run_raw_call(mi_unet *h, const RawCall &c)
         const size_t b0 = (size_t)mbs[k].b0;
         HIP_TRY(hipEventSynchronize(h->out_done[par]));
         memcpy(c.out_u8 + b0 * hw, out_buf(k), bm * hw);
+        if (c.tiles) memcpy(c.tiles + b0 * hw * C, h->h_tiles[par], bm * hw * C);
         if (c.segment)
             contours_to_caller(h, bm, c.cap_points, c.cap_contours, c.xy + b0 * c.cap_points * 2, c.start + b0 * (c.cap_contours + 1), c.counts + b0, par);
         float ms = 0.f;
-        HIP_TRY(hipEventElapsedTime(&ms, h->pre_ev[par][0], h->pre_ev[par][1]));
+        HIP_TRY(hipEventElapsedTime(&ms, h->pre_ev[k % 3][0], h->pre_ev[k % 3][1]));
         h->stage_ms[MI_UNET_STAGE_UPLOAD_PRE] += ms;
         for (int st = 0; st < 4; ++st) {
             HIP_TRY(hipEventElapsedTime(&ms, h->stage_ev[par][st], h->stage_ev[par][st + 1]));
@@ -1389,22 +1396,37 @@ int run_raw_call(mi_unet *h, const RawCall &c)
         }
         return 0;
     };
+    // MIUNET_RAW_TRACE=1: host-side timeline of the call on stderr (when did each enqueue / staging / copy-out start and end)
+    static const bool trace = [] { const char *e = getenv("MIUNET_RAW_TRACE"); return e && e[0] == '1'; }();
+    const auto t_call = std::chrono::steady_clock::now();
+    auto mark = [&](const char *what, int k) {
+        if (trace) fprintf(stderr, "[raw %8.3f ms] %s %d\n", std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_call).count(), what, k);
+    };
     if (c.segment) {
         int bmax = 0;
         for (const MB &m : mbs) bmax = std::max(bmax, m.bm);
         if (int rc = grow_contour_buffers(h, bmax, c.cap_points, c.cap_contours)) return rc;
     }
     HIP_TRY(hipStreamSynchronize(s));                  // an external stream may still be reading the tile buffers
+    mark("stage begin", 0);
     if (int rc = stage(0)) return rc;
+    mark("stage end", 0);
     for (int k = 0; k < n_mb; ++k) {
         if (int rc = enqueue(k)) return rc;
-        if (k + 1 < n_mb)                              // the host's staging copies of k + 1 run while the device works on k
+        mark("enqueued", k);
+        if (k + 1 < n_mb) {                            // the host's staging copies of k + 1 run while the device works on k
             if (int rc = stage(k + 1)) return rc;
-        if (k >= 1)
+            mark("stage end", k + 1);
+        }
+        if (k >= 1) {
             if (int rc = finalize(k - 1)) return rc;   // ... and so does the copy-out of k - 1
+            mark("finalized", k - 1);
+        }
     }
     if (int rc = finalize(n_mb - 1)) return rc;
-    HIP_TRY(hipStreamSynchronize(s));                  // D2H copies into the caller's own (pageable) tiles / logits included
+    mark("finalized", n_mb - 1);
+    HIP_TRY(hipStreamSynchronize(s));                  // D2H copies into the caller's own (pageable) logits included
+    mark("done", 0);
     return MI_UNET_OK;
 }
 
@@ -1775,10 +1797,14 @@ void mi_unet_destroy(mi_unet_t *h)
     if (h->h_labels) (void)hipHostFree(h->h_labels);
     if (h->h_cont) (void)hipHostFree(h->h_cont);
     if (h->h_labels2) (void)hipHostFree(h->h_labels2);
+    for (int i = 0; i < 3; ++i)
+        for (hipEvent_t e : h->pre_ev[i])
+            if (e) (void)hipEventDestroy(e);
     if (h->d_img2) (void)hipFree(h->d_img2);
     if (h->pre_stream) { (void)hipStreamSynchronize(h->pre_stream); (void)hipStreamDestroy(h->pre_stream); }
     for (int i = 0; i < 2; ++i) {
-        hipEvent_t evs2[] = { h->tile_ready[i], h->tile_free[i], h->pre_ev[i][0], h->pre_ev[i][1], h->out_done[i] };
+        if (h->h_tiles[i]) (void)hipHostFree(h->h_tiles[i]);
+        hipEvent_t evs2[] = { h->tile_ready[i], h->tile_free[i], h->out_done[i] };
         for (hipEvent_t e : evs2)
             if (e) (void)hipEventDestroy(e);
         for (hipEvent_t e : h->stage_ev[i])
