@@ -267,6 +267,65 @@ def test_conv3x3_resident_weights_fused_pooling(op, B, H, W, Cin, Cout):
     assert np.array_equal(pooled, binding.layer_debug(op + "_pool_lpout", x, w, None, shift, relu=True))
 
 
+# ---------------------------------------------------------------- 128 -> 64 with the reduction split over a wave pair (conv_lprk.hip)
+@pytest.mark.parametrize("op,B,H,W", [
+    ("conv3x3_bf16", 1, 4, 32),         # exactly one 4 x 32 tile
+    ("conv3x3_fp16", 2, 9, 40),         # ragged in x and y, border tiles only
+    ("conv3x3_bf16", 1, 12, 100),       # interior tiles (precomputed DMA offsets) next to border tiles
+    ("conv3x3_fp16", 1, 64, 512),       # 256 tiles: the patch ring wraps, steady-state waits and both barriers
+    ("conv3x3_bf16", 2, 256, 256),      # 1 024 tiles on 256 persistent workgroups
+])
+def test_conv3x3_resident_weights_k_split(op, B, H, W):
+    """up4.c1's shape (128 -> 64): each wave of a pair sums 64 input channels, the halves meet in LDS.  Same products as the
+    2 x 2 kernel, one fp32 add associated differently -- so the stored 16-bit tensor equals the 2 x 2 kernel's except where the
+    two fp32 sums straddle a rounding boundary (then by one unit in the last place, rarely), and it is within one 16-bit
+    rounding of the rounded-operand oracle."""
+    Cin, Cout = 128, 64
+    r = np.random.default_rng(13 * B + H + 3 * W)
+    x = r.standard_normal((B, H, W, Cin), dtype=np.float32)
+    w = (r.standard_normal((Cout, Cin, 3, 3), dtype=np.float32) * np.sqrt(2.0 / (9 * Cin))).astype(np.float32)
+    scale = (1.0 + 0.1 * r.standard_normal(Cout)).astype(np.float32)
+    shift = (0.1 * r.standard_normal(Cout)).astype(np.float32)
+    rnd = orc.bf16_round if op.endswith("bf16") else orc.fp16_round
+    ulp = 2.0 ** -7 if op.endswith("bf16") else 2.0 ** -10
+    got = binding.layer_debug(op + "k_lpout", x, w, scale, shift, relu=True)
+    assert not np.isnan(got).any(), "unwritten (NaN-poisoned) outputs"
+    assert np.array_equal(rnd(got), got)
+    for _ in range(2):                        # (a race between the waves of a pair would not show every time)
+        assert np.array_equal(got, binding.layer_debug(op + "k_lpout", x, w, scale, shift, relu=True))
+    two_by_two = binding.layer_debug(op + "_lpout", x, w, scale, shift, relu=True)
+    d = np.abs(got - two_by_two)
+    assert np.all(d <= ulp * np.maximum(np.abs(got), np.abs(two_by_two)) + 1e-6) and float(np.mean(d > 0)) < 5e-3
+    if H * W <= 64 * 512:
+        wf = (w.astype(np.float64) * scale.astype(np.float64)[:, None, None, None]).astype(np.float32)
+        ref = np.maximum(orc.conv3x3(rnd(x), rnd(wf)) + shift, 0.0)
+        assert np.max(np.abs(got - ref) / np.maximum(1.0, np.abs(ref))) < ulp
+
+
+@pytest.mark.parametrize("algo", ["bf16", "fp16"])
+def test_k_split_kernel_in_the_whole_network(algo, monkeypatch):
+    """base 64, two levels: the top up.c1 is 128 -> 64 reading the concat buffer (channel stride 128, skip first).  MIUNET_LPRK=2
+    sends it to the K-split kernel whatever the grid, =0 to the 2 x 2 kernel: same logits to fp32 re-association noise amplified
+    by one 16-bit rounding per layer behind it, same labels wherever the margin is not at that noise level."""
+    spec = UNetSpec(1, 64, 2, 3)
+    blob = pack_weights(spec, synth.make_weights(spec, 31))
+    imgs = synth.make_images(2, 96, 80, 1, 0x77, "blobs")
+    out, used = {}, {}
+    for mode in ("0", "2"):
+        monkeypatch.setenv("MIUNET_LPRK", mode)
+        with binding.Engine(96, 80, 1, 64, 2, 3, max_batch=2, conv_algo=algo) as eng:
+            eng.load_weights(blob)
+            eng.set_profiling(True)
+            out[mode] = eng.infer(imgs, want_logits=True)
+            used[mode] = [s["name"] for s in eng.kernel_stats() if s["kernel"].endswith("16k")]
+    assert used["0"] == [] and used["2"] == ["up2.c1"]
+    diff = float(np.max(np.abs(out["0"][1] - out["2"][1])))
+    assert diff < (2e-2 if algo == "bf16" else 3e-3), diff
+    srt = np.sort(out["0"][1], axis=1)
+    safe = (srt[:, -1] - srt[:, -2]) > 0.1
+    assert np.array_equal(out["0"][0][safe], out["2"][0][safe])
+
+
 # ---------------------------------------------------------------- the large transposed convolutions with resident weights (convt_lpr.hip)
 @pytest.mark.parametrize("op,B,H,W,Cin,Cout", [
     ("convT2x2_bf16", 1, 8, 32, 64, 32),        # exactly one 8 x 32 tile: wave = tap x half of the row blocks

@@ -129,7 +129,7 @@ def test_bf16_plan_every_layer_at_512_batch_16():
     rep = _check_layers("bf16", UNetSpec(), 512, 16, 4321, img=11)
     _show("bf16 512^2 x16", rep)
     kernels = {k for _, k, _, _ in rep}
-    assert {"conv3x3_bf16w", "conv3x3_bf16r", "convT2x2_bf16r"} <= kernels
+    assert {"conv3x3_bf16w", "conv3x3_bf16r", "conv3x3_bf16k", "convT2x2_bf16r"} <= kernels
 
 
 def test_fp16_plan_every_layer_at_1024x3_batch_8():
@@ -137,7 +137,7 @@ def test_fp16_plan_every_layer_at_1024x3_batch_8():
     rep = _check_layers("fp16", UNetSpec(in_ch=3, base=32, levels=5), 1024, 8, 99, img=3)
     _show("fp16 1024^2x3 x8", rep)
     kernels = {k for _, k, _, _ in rep}
-    assert {"conv3x3_fp16w", "conv3x3_fp16r", "convT2x2_fp16r"} <= kernels
+    assert {"conv3x3_fp16w", "conv3x3_fp16r", "conv3x3_fp16k", "convT2x2_fp16r"} <= kernels
 
 
 def test_capture_rejects_bad_arguments_and_small_batch_takes_small_grid_kernels():

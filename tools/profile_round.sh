@@ -1,6 +1,7 @@
 #!/bin/bash
 # Regenerates the judged profile artefacts of a round on the GPU box (run through gpurun from the repo root):
-#   tools/profile_round.sh r02 [fp32|bf16|fp16|all]
+#   tools/profile_round.sh r03 [fp32|bf16|fp16|all]
+# then, back in the build container, tools/collect_profiles.py r03 copies the judged files into profiles/ with the round tag.
 # bench line + per-layer table, rocprofv3 kernel-trace stats of the same bench command, and the PMC passes (FETCH_SIZE,
 # WRITE_SIZE, SQ MFMA-busy group: separate runs, kernel-trace only) summarised by profiles/summarize_pmc.py.
 # The program sits directly behind `--` (the profiler's preloaded library has initialised the GPU by then: no env/bash hop).
@@ -32,6 +33,14 @@ if [ "$what" = "fp32" ] || [ "$what" = "all" ]; then
     python bench.py --per-layer > $out/bench.json 2> $out/per_layer.txt
     echo "bench done"
     passes fp32
+    # every profile that carries this round's tag is MEASURED in this round: the one-GPU figure of BASELINE
+    # configs[3] (global batch 512 in micro-batches of 16) and the one-rank rehearsal of the RCCL path with the configs[3] strong loop
+    python bench.py --global-batch 512 --steps 3 --warmup 1 --no-cpu-baseline --no-extras > $out/global_batch512_bench.json 2> $out/global_batch512.err
+    BENCH_FORCE_DIST=1 python bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-extras > $out/dist_rehearsal_1rank.json 2> $out/dist_rehearsal.err
+    echo "global batch 512 + one-rank RCCL rehearsal done"
+    python -m pytest tests/test_gpu_insitu.py tests/test_gpu_numeric_range.py -q -s > $out/insitu_and_numeric_range.txt 2>&1 || echo "in-situ / numeric-range tests FAILED"
+    python tools/bench_pipeline.py 2>&1 | grep -v "^Processing\|^Original\|^Scaled\|^Extracted\|^Overlay\|^JSON\|^Total\|^Resources" > $out/pipeline_stages.txt
+    echo "parity logs + pipeline stages done"
 fi
 if [ "$what" = "bf16" ] || [ "$what" = "all" ]; then
     python bench.py --conv-algo bf16 --batch 128 --steps 5 --no-cpu-baseline --no-extras --per-layer > $out/bf16_bench.json 2> $out/bf16_per_layer.txt

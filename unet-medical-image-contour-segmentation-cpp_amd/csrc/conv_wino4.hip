@@ -127,6 +127,7 @@ __global__ __launch_bounds__(256, 1) void conv3x3_wino4_f32(const ConvArgs a, co
     const float *const p_rd = Raw + (((4 * (t_tile >> 2) + row0) * W4::RAW_ROW + (t_tile & 3)) * 4 + t_quad) * 4;
     const int p_rstride = rstep * W4::RAW_ROW * WINO4_KC;
     const int xi_a = two ? (wrole == 0 ? 1 : 3) : (wrole == 2 ? 0 : 5);
+    const float c_alpha = wrole == 0 ? -4.f : -1.f, c_beta = wrole == 0 ? 1.f : 2.f;
     float *const v_wr_a = Vs + xi_a * 6 * VPOS + t_tile * VROW + 4 * t_quad;      // + buf*VBUF + nu*VPOS; row b = + 6*VPOS
     f32x4 px_[4];                             // patch column k of this lane's rows
     f32x4 cR[2][6];                           // rows of B^T d (row b only on the two-row waves)
@@ -136,21 +137,20 @@ __global__ __launch_bounds__(256, 1) void conv3x3_wino4_f32(const ConvArgs a, co
         px_[0] = *reinterpret_cast<const f32x4 *>(src);
         px_[1] = *reinterpret_cast<const f32x4 *>(src + p_rstride);
         px_[2] = *reinterpret_cast<const f32x4 *>(src + 2 * p_rstride);
-        if (two) px_[3] = *reinterpret_cast<const f32x4 *>(src + 3 * p_rstride);
+        px_[3] = *reinterpret_cast<const f32x4 *>(src + 3 * p_rstride);      // (the one-row waves read a fourth row they never use: patch rows 6, 7 -- cheaper than a branch per column)
     };
     auto piece_col = [&](int k) {
         const f32x4 *d = px_;
         f32x4 ra, rb;
-        if (wrole == 0) {
-            const f32x4 ta = d[3] - 4.f * d[1];
-            const f32x4 tb = d[2] - 4.f * d[0];
-            ra = ta + tb;
-            rb = pk_sub(ta, tb);
-        } else if (wrole == 1) {
-            const f32x4 ta = pk_sub(d[3], d[1]);
-            const f32x4 tb = pk_sub(d[2], d[0]);
-            ra = ta + 2.f * tb;
-            rb = ta - 2.f * tb;
+        if (two) {
+            // waves 0 and 1 run ONE instruction sequence with wave-uniform coefficients (alpha, beta) = (-4, 1) and (-1, 2):
+            // ta = d3 + alpha d1, tb = d2 + alpha d0, rows ta +- beta tb.  The same values bit for bit as the literal forms (a
+            // product by 1 or -1 is exact), without the role branches in front of every column (same-card A/B of a build where
+            // every wave took one role: -0.28 ms of the 10.9 ms this kernel takes per step)
+            const f32x4 ta = d[3] + c_alpha * d[1];
+            const f32x4 tb = d[2] + c_alpha * d[0];
+            ra = ta + c_beta * tb;
+            rb = ta - c_beta * tb;
         } else {
             ra = 4.f * d[0] - 5.f * d[1] + d[2];
             rb = ra;

@@ -99,6 +99,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wino4s_f32(const ConvArgs a, c
     const float *const p_rd = Raw + (((4 * (t_tile >> 2) + row0) * W4::RAW_ROW + (t_tile & 3)) * 4 + t_quad) * 4;
     const int p_rstride = rstep * W4::RAW_ROW * WINO4_KC;
     const int xi_a = two ? (wave == 0 ? 1 : 3) : (wave == 2 ? 0 : 5);
+    const float c_alpha = wave == 0 ? -4.f : -1.f, c_beta = wave == 0 ? 1.f : 2.f;
     float *const v_wr_a = Vs + xi_a * 6 * VPOS + t_tile * VROW + 4 * t_quad;      // + nu*VPOS; row b = + 6*VPOS
     auto transform = [&]() {
         f32x4 cR[2][6];                       // rows of B^T d (row b only on the two-row waves)
@@ -109,18 +110,13 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wino4s_f32(const ConvArgs a, c
             d[0] = *reinterpret_cast<const f32x4 *>(src);
             d[1] = *reinterpret_cast<const f32x4 *>(src + p_rstride);
             d[2] = *reinterpret_cast<const f32x4 *>(src + 2 * p_rstride);
-            d[3] = two ? *reinterpret_cast<const f32x4 *>(src + 3 * p_rstride) : d[2];
+            d[3] = *reinterpret_cast<const f32x4 *>(src + 3 * p_rstride);       // (unused by the one-row waves: patch rows 6, 7)
             f32x4 ra, rb;
-            if (wave == 0) {
-                const f32x4 ta = d[3] - 4.f * d[1];
-                const f32x4 tb = d[2] - 4.f * d[0];
-                ra = ta + tb;
-                rb = pk_sub(ta, tb);
-            } else if (wave == 1) {
-                const f32x4 ta = pk_sub(d[3], d[1]);
-                const f32x4 tb = pk_sub(d[2], d[0]);
-                ra = ta + 2.f * tb;
-                rb = ta - 2.f * tb;
+            if (two) {                        // waves 0 and 1: one instruction sequence, wave-uniform coefficients (conv_wino4.hip)
+                const f32x4 ta = d[3] + c_alpha * d[1];
+                const f32x4 tb = d[2] + c_alpha * d[0];
+                ra = ta + c_beta * tb;
+                rb = ta - c_beta * tb;
             } else {
                 ra = 4.f * d[0] - 5.f * d[1] + d[2];
                 rb = ra;

@@ -7,6 +7,9 @@
 
 #include <algorithm>
 #include <chrono>
+#include <condition_variable>
+#include <mutex>
+#include <thread>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -52,6 +55,64 @@ struct Step {
     bool fused_away = false;      // POOL steps whose work is done by the preceding conv's epilogue
     int head_step = -1;           // CONV: index of the HEAD step this layer feeds (candidate for the fused head), else -1
     bool feeds_head = false;      // CONV: its output is the fp32 head's input (stays fp32 in the 16-bit pipelines)
+};
+
+// A few persistent helper threads for the staging copy of a RAW image (pageable source -> the engine's pinned ring): one
+// thread moves 6 MB at 10 - 20 GB/s, less when the source lies on the other socket, and sixteen such copies in a row are the
+// upload stage of a chunk.  Four threads keep that stage shorter than the first micro-batch's network, so it stays hidden.
+class CopyPool {
+public:
+    explicit CopyPool(int helpers) : n_(helpers)
+    {
+        for (int i = 0; i < n_; ++i) th_.emplace_back([this, i] { run(i); });
+    }
+    ~CopyPool()
+    {
+        { std::lock_guard<std::mutex> lk(m_); stop_ = true; ++gen_; }
+        cv_.notify_all();
+        for (std::thread &t : th_) t.join();
+    }
+    void copy(void *dst, const void *src, size_t bytes)
+    {
+        const int parts = n_ + 1;
+        const size_t piece = (bytes / parts + 4095) & ~(size_t)4095;
+        { std::lock_guard<std::mutex> lk(m_); dst_ = static_cast<char *>(dst); src_ = static_cast<const char *>(src); bytes_ = bytes; piece_ = piece; pending_ = n_; ++gen_; }
+        cv_.notify_all();
+        part(n_);                                      // the caller takes the last piece
+        std::unique_lock<std::mutex> lk(m_);
+        done_.wait(lk, [this] { return pending_ == 0; });
+    }
+
+private:
+    void part(int i)
+    {
+        const size_t lo = std::min(bytes_, piece_ * (size_t)i), hi = std::min(bytes_, lo + piece_);
+        if (hi > lo) memcpy(dst_ + lo, src_ + lo, hi - lo);
+    }
+    void run(int i)
+    {
+        unsigned long seen = 0;
+        for (;;) {
+            {
+                std::unique_lock<std::mutex> lk(m_);
+                cv_.wait(lk, [&] { return gen_ != seen; });
+                seen = gen_;
+                if (stop_) return;
+            }
+            part(i);
+            { std::lock_guard<std::mutex> lk(m_); if (--pending_ == 0) done_.notify_one(); }
+        }
+    }
+    int n_;
+    std::vector<std::thread> th_;
+    std::mutex m_;
+    std::condition_variable cv_, done_;
+    unsigned long gen_ = 0;
+    bool stop_ = false;
+    char *dst_ = nullptr;
+    const char *src_ = nullptr;
+    size_t bytes_ = 0, piece_ = 0;
+    int pending_ = 0;
 };
 
 }  // namespace
@@ -107,6 +168,15 @@ struct mi_unet {
     hipEvent_t stage_ev[2][5] = {}, out_done[2] = {};
     hipEvent_t pre_ev[3][2] = {};   // three pairs: micro-batch k + 2 is staged before k's times are read
     uint8_t *h_labels2 = nullptr;
+    // third stream of the RAW-in entry points: postprocess, mask_to_image, contours and the downloads of micro-batch k run
+    // here while the engine's stream already works on the network of k + 1; own workspace (the network's scratch buffers,
+    // which the single-stage entry points borrow, are in use by then), second label buffer
+    hipStream_t tail_stream = nullptr;
+    void *d_tail_ws = nullptr;
+    size_t tail_ws_bytes = 0;
+    uint8_t *d_tail_vis = nullptr, *d_labels2 = nullptr;
+    hipEvent_t net_done[2] = {}, tail_ev[2][4] = {};
+    std::unique_ptr<CopyPool> copy_pool;   // helpers of the pageable -> pinned staging copy (created on first use)
     uint8_t *h_tiles[2] = {};       // pinned mirrors of the tile buffers (a D2H into the caller's pageable memory would block the host)   // second pinned result buffer: micro-batch k + 1 downloads while the host still copies k out
     float stage_ms[MI_UNET_N_STAGES] = {};
     // pinned host staging (the reference used pageable std::vector, src/process.cpp:138,152)
@@ -655,6 +725,10 @@ int launch_plan(mi_unet *h, const uint8_t *d_imgs, int B, uint8_t *d_labels, flo
                 kname = lp_kind == 1 ? "conv3x3_bf16w" : "conv3x3_fp16w";
                 e = launch_conv3x3_lp2(a, lp_kind == 2, s);
             }
+            else if (lp_kind != 0 && conv3x3_lprk_takes(a)) {    // 128 -> 64: weights in registers, K split over a wave pair (conv_lprk.hip)
+                kname = lp_kind == 1 ? "conv3x3_bf16k" : "conv3x3_fp16k";
+                e = launch_conv3x3_lprk(a, lp_kind == 2, s);
+            }
             else if (lp_kind != 0 && conv3x3_lpr_takes(a)) {     // narrow layer: weights in registers, persistent (conv_lpr.hip)
                 kname = lp_kind == 1 ? (head_done ? "conv3x3_bf16r+head" : "conv3x3_bf16r") : (head_done ? "conv3x3_fp16r+head" : "conv3x3_fp16r");
                 e = launch_conv3x3_lpr(a, lp_kind == 2, s);
@@ -816,6 +890,7 @@ Routing Routing::from_env()
     r.lp2 = num("MIUNET_LP2", 1);
     r.lpr = num("MIUNET_LPR", 1);
     r.lpr_rb = num("MIUNET_LPR_RB", 2);
+    r.lprk = num("MIUNET_LPRK", 1);
     r.convt_lpr = num("MIUNET_CONVT_LPR", 1);
     r.wino4s = num("MIUNET_WINO4S", 1);
     r.convt_small = num("MIUNET_CONVT_SMALL", 1) != 0;
@@ -1252,7 +1327,13 @@ int stage_raw16(mi_unet *h, const uint16_t *const *raws, const int *widths, cons
             const bool pinned = hipPointerGetAttributes(&attr, raws[i]) == hipSuccess && attr.type == hipMemoryTypeHost;
             if (!pinned) {
                 (void)hipGetLastError();             // an ordinary host pointer is "invalid value" to the query: not an error of ours
-                memcpy(h->h_raw[slot], raws[i], n * sizeof(uint16_t));
+                static const int copy_threads = [] { const char *e = getenv("MIUNET_COPY_THREADS"); const int v = e ? atoi(e) : 4; return v < 1 ? 1 : v > 16 ? 16 : v; }();
+                if (copy_threads > 1 && n * sizeof(uint16_t) >= (1u << 20)) {
+                    if (!h->copy_pool) h->copy_pool.reset(new CopyPool(copy_threads - 1));
+                    h->copy_pool->copy(h->h_raw[slot], raws[i], n * sizeof(uint16_t));
+                } else {
+                    memcpy(h->h_raw[slot], raws[i], n * sizeof(uint16_t));
+                }
             }
             HIP_TRY(hipMemcpyAsync(h->d_raw[slot], pinned ? raws[i] : h->h_raw[slot], n * sizeof(uint16_t), hipMemcpyHostToDevice, s));
         }
@@ -1274,6 +1355,15 @@ namespace {
 int ensure_raw_pipeline(mi_unet *h, bool two_buffers)
 {
     if (!h->pre_stream) HIP_TRY(hipStreamCreateWithFlags(&h->pre_stream, hipStreamNonBlocking));
+    if (!h->tail_stream) HIP_TRY(hipStreamCreateWithFlags(&h->tail_stream, hipStreamNonBlocking));
+    const size_t npix = (size_t)h->cfg.max_batch * h->cfg.height * h->cfg.width;
+    if (!h->d_tail_vis) HIP_TRY(hipMalloc(&h->d_tail_vis, npix));
+    if (!h->d_labels2) HIP_TRY(hipMalloc(&h->d_labels2, npix));
+    for (int i = 0; i < 2; ++i) {
+        if (!h->net_done[i]) HIP_TRY(hipEventCreateWithFlags(&h->net_done[i], hipEventDisableTiming));
+        for (hipEvent_t &e : h->tail_ev[i])
+            if (!e) HIP_TRY(hipEventCreate(&e));
+    }
     for (int i = 0; i < 2; ++i) {
         if (!h->tile_ready[i]) HIP_TRY(hipEventCreateWithFlags(&h->tile_ready[i], hipEventDisableTiming));
         if (!h->tile_free[i]) HIP_TRY(hipEventCreateWithFlags(&h->tile_free[i], hipEventDisableTiming));
@@ -1310,21 +1400,41 @@ int run_raw_call(mi_unet *h, const RawCall &c)
     HIP_TRY(hipSetDevice(h->cfg.device));
     const int H = h->cfg.height, W = h->cfg.width, Bm = h->cfg.max_batch;
     const size_t hw = (size_t)H * W, C = (size_t)h->cfg.in_ch;
-    const size_t scratch = sizeof(float) * (size_t)Bm * hw * h->ch[0];
     hipStream_t s = h->stream;
     if (c.B <= 0) return MI_UNET_OK;
     // micro-batches: chunks of max_batch images -- and the FIRST chunk is cut once more when it is large (a quarter, at least
     // four images, then the rest), so that the network starts as soon as a few images have been uploaded and preprocessed
-    // and the upload of the rest hides under it.  MIUNET_RAW_SPLIT=0: whole chunks only.
+    // and the upload of the rest hides under it.
     struct MB { int b0, bm; };
     std::vector<MB> mbs;
     for (int b0 = 0; b0 < c.B; b0 += Bm) mbs.push_back({ b0, std::min(Bm, c.B - b0) });
-    static const bool split_first = [] { const char *e = getenv("MIUNET_RAW_SPLIT"); return !(e && e[0] == '0'); }();
-    if (split_first && mbs[0].bm >= 8) {
-        const int head = std::max(4, mbs[0].bm / 4);
-        const MB rest{ head, mbs[0].bm - head };
-        mbs[0].bm = head;
-        mbs.insert(mbs.begin() + 1, rest);
+    // MIUNET_RAW_SPLIT = 0: whole chunks only; "a" or "a,b,...": the first chunk is cut into a, b, ... images and the rest
+    // (default: a quarter of the chunk, at least four, then the rest -- same-card sweep at 16 images: 0 -> 749, 2 -> 780, 4 -> 787,
+    // 6 -> 737, 8 -> 779 images/s from pinned memory, tools/dev/split_sweep.py)
+    static const std::vector<int> split_env = [] {
+        std::vector<int> v;
+        const char *e = getenv("MIUNET_RAW_SPLIT");
+        if (!e) return std::vector<int>{ -1 };
+        for (const char *q = e; *q;) {
+            v.push_back(atoi(q));
+            while (*q && *q != ',') ++q;
+            if (*q == ',') ++q;
+        }
+        return v;
+    }();
+    if (!(split_env.size() == 1 && split_env[0] == 0) && mbs[0].bm >= 8) {
+        std::vector<int> cuts = split_env;
+        if (cuts.size() == 1 && cuts[0] < 0) cuts[0] = std::max(4, mbs[0].bm / 4);
+        int left = mbs[0].bm, b0 = 0;
+        std::vector<MB> parts;
+        for (int cnt : cuts) {
+            if (cnt <= 0 || cnt >= left) break;
+            parts.push_back({ b0, cnt });
+            b0 += cnt; left -= cnt;
+        }
+        parts.push_back({ b0, left });
+        mbs.erase(mbs.begin());
+        mbs.insert(mbs.begin(), parts.begin(), parts.end());
     }
     const int n_mb = (int)mbs.size();
     if (int rc = ensure_raw_pipeline(h, n_mb > 1)) return rc;
@@ -1341,42 +1451,53 @@ int run_raw_call(mi_unet *h, const RawCall &c)
         HIP_TRY(hipEventRecord(h->tile_ready[par], h->pre_stream));
         return 0;
     };
-    auto enqueue = [&](int k) -> int {                 // everything micro-batch k does on the engine's stream, results into pinned half k & 1
+    auto enqueue = [&](int k) -> int {                 // micro-batch k: network on the engine's stream, everything behind it on the tail stream
         const int bm = mbs[k].bm, par = k & 1;
         const size_t b0 = (size_t)mbs[k].b0;
         uint8_t *d_tiles = tile_buf(k);
-        hipEvent_t *ev = h->stage_ev[par];
-        if (c.segment && contour_workspace_bytes(bm, H, W, c.cap_contours) > scratch)
-            return fail(MI_UNET_EARG, "contour workspace does not fit the scratch buffer (cap_contours too large)");
+        uint8_t *d_lab = par ? h->d_labels2 : h->d_labels;
+        hipStream_t ts = h->tail_stream;
+        if (c.segment && contour_workspace_bytes(bm, H, W, c.cap_contours) > h->tail_ws_bytes)
+            return fail(MI_UNET_EARG, "contour workspace does not fit (cap_contours too large)");
         HIP_TRY(hipStreamWaitEvent(s, h->tile_ready[par], 0));
-        HIP_TRY(hipEventRecord(ev[0], s));
+        if (k >= 2) HIP_TRY(hipStreamWaitEvent(s, h->out_done[par], 0));                      // the tail of k - 2 has read this label buffer
+        HIP_TRY(hipEventRecord(h->stage_ev[par][0], s));
         float *d_lg = c.logits ? h->d_logits : nullptr;
-        if (int rc = run_microbatch(h, d_tiles, bm, h->d_labels, d_lg)) return rc;             // UNet + argmax
-        HIP_TRY(hipEventRecord(ev[1], s));
-        const uint8_t *d_result = h->d_labels;
-        int *d_xy = h->d_cont, *d_start = d_xy + (size_t)bm * c.cap_points * 2, *d_count = d_start + (size_t)bm * (c.cap_contours + 1);
-        if (c.segment || h->postprocess)
-            if (int rc = device_postprocess(h, h->d_labels, h->d_labels, bm)) return rc;       // {0, 2}
-        HIP_TRY(hipEventRecord(ev[2], s));
-        if (c.segment) {
-            uint8_t *d_vis = reinterpret_cast<uint8_t *>(h->d_s0);                             // s0 is free after the head
-            hipError_t e = launch_mask_to_image(h->d_labels, d_vis, bm * hw, s);
-            if (e == hipSuccess)
-                e = launch_extract_contours(d_vis, bm, H, W, d_xy, c.cap_points, d_start, c.cap_contours, d_count, h->d_s1, s);
-            if (e != hipSuccess) return fail(MI_UNET_EHIP, std::string("segment launch: ") + hipGetErrorString(e));
-            d_result = d_vis;
-        }
-        HIP_TRY(hipEventRecord(ev[3], s));
-        if (c.tiles) HIP_TRY(hipMemcpyAsync(h->h_tiles[par], d_tiles, bm * hw * C, hipMemcpyDeviceToHost, s));
-        HIP_TRY(hipEventRecord(h->tile_free[par], s));
-        HIP_TRY(hipMemcpyAsync(out_buf(k), d_result, bm * hw, hipMemcpyDeviceToHost, s));
-        if (c.segment)
-            if (int rc = contours_to_pinned(h, bm, c.cap_points, c.cap_contours, par)) return rc;
-        if (c.logits)
+        if (int rc = run_microbatch(h, d_tiles, bm, d_lab, d_lg)) return rc;                   // UNet + argmax
+        HIP_TRY(hipEventRecord(h->stage_ev[par][1], s));
+        if (c.logits)                                  // (a debugging output: into the caller's pageable memory, which blocks the host)
             HIP_TRY(hipMemcpyAsync(c.logits + b0 * hw * h->cfg.classes, h->d_logits, sizeof(float) * bm * hw * h->cfg.classes,
                                    hipMemcpyDeviceToHost, s));
-        HIP_TRY(hipEventRecord(ev[4], s));
-        HIP_TRY(hipEventRecord(h->out_done[par], s));
+        HIP_TRY(hipEventRecord(h->net_done[par], s));
+        // ---- tail: ordered behind the network of k, concurrent with the network of k + 1
+        HIP_TRY(hipStreamWaitEvent(ts, h->net_done[par], 0));
+        hipEvent_t *tv = h->tail_ev[par];
+        HIP_TRY(hipEventRecord(tv[0], ts));
+        const uint8_t *d_result = d_lab;
+        int *d_xy = h->d_cont, *d_start = d_xy + (size_t)bm * c.cap_points * 2, *d_count = d_start + (size_t)bm * (c.cap_contours + 1);
+        if (c.segment || h->postprocess) {
+            const int min_area = static_cast<int>(W * H * 0.06f);                              // src/postprocess.cpp:9, :30, :66
+            const hipError_t e = launch_postprocess_masks(d_lab, d_lab, bm, H, W, min_area, h->d_tail_ws, ts);      // {0, 2}
+            if (e != hipSuccess) return fail(MI_UNET_EHIP, std::string("postprocess launch: ") + hipGetErrorString(e));
+        }
+        HIP_TRY(hipEventRecord(tv[1], ts));
+        if (c.segment) {
+            hipError_t e = launch_mask_to_image(d_lab, h->d_tail_vis, bm * hw, ts);
+            if (e == hipSuccess)
+                e = launch_extract_contours(h->d_tail_vis, bm, H, W, d_xy, c.cap_points, d_start, c.cap_contours, d_count, h->d_tail_ws, ts);
+            if (e != hipSuccess) return fail(MI_UNET_EHIP, std::string("segment launch: ") + hipGetErrorString(e));
+            d_result = h->d_tail_vis;
+        }
+        HIP_TRY(hipEventRecord(tv[2], ts));
+        if (c.tiles) HIP_TRY(hipMemcpyAsync(h->h_tiles[par], d_tiles, bm * hw * C, hipMemcpyDeviceToHost, ts));
+        HIP_TRY(hipEventRecord(h->tile_free[par], ts));
+        HIP_TRY(hipMemcpyAsync(out_buf(k), d_result, bm * hw, hipMemcpyDeviceToHost, ts));
+        if (c.segment) {
+            const size_t n = (size_t)bm * ((size_t)c.cap_points * 2 + c.cap_contours + 1 + 1);
+            HIP_TRY(hipMemcpyAsync(h->h_cont + par * h->cont_cap, h->d_cont, n * sizeof(int), hipMemcpyDeviceToHost, ts));
+        }
+        HIP_TRY(hipEventRecord(tv[3], ts));
+        HIP_TRY(hipEventRecord(h->out_done[par], ts));
         return 0;
     };
     auto finalize = [&](int k) -> int {                // micro-batch k has left the device: pinned halves -> the caller's arrays
@@ -1390,9 +1511,11 @@ int run_raw_call(mi_unet *h, const RawCall &c)
         float ms = 0.f;
         HIP_TRY(hipEventElapsedTime(&ms, h->pre_ev[k % 3][0], h->pre_ev[k % 3][1]));
         h->stage_ms[MI_UNET_STAGE_UPLOAD_PRE] += ms;
-        for (int st = 0; st < 4; ++st) {
-            HIP_TRY(hipEventElapsedTime(&ms, h->stage_ev[par][st], h->stage_ev[par][st + 1]));
-            h->stage_ms[MI_UNET_STAGE_NETWORK + st] += ms;
+        HIP_TRY(hipEventElapsedTime(&ms, h->stage_ev[par][0], h->stage_ev[par][1]));
+        h->stage_ms[MI_UNET_STAGE_NETWORK] += ms;
+        for (int st = 0; st < 3; ++st) {
+            HIP_TRY(hipEventElapsedTime(&ms, h->tail_ev[par][st], h->tail_ev[par][st + 1]));
+            h->stage_ms[MI_UNET_STAGE_POSTPROCESS + st] += ms;
         }
         return 0;
     };
@@ -1402,10 +1525,20 @@ int run_raw_call(mi_unet *h, const RawCall &c)
     auto mark = [&](const char *what, int k) {
         if (trace) fprintf(stderr, "[raw %8.3f ms] %s %d\n", std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_call).count(), what, k);
     };
-    if (c.segment) {
+    {
         int bmax = 0;
         for (const MB &m : mbs) bmax = std::max(bmax, m.bm);
-        if (int rc = grow_contour_buffers(h, bmax, c.cap_points, c.cap_contours)) return rc;
+        if (c.segment)
+            if (int rc = grow_contour_buffers(h, bmax, c.cap_points, c.cap_contours)) return rc;
+        size_t need = postprocess_workspace_bytes(bmax, H, W);
+        if (c.segment) need = std::max(need, contour_workspace_bytes(bmax, H, W, c.cap_contours));
+        if (need > h->tail_ws_bytes) {
+            HIP_TRY(hipStreamSynchronize(h->tail_stream));
+            if (h->d_tail_ws) HIP_TRY(hipFree(h->d_tail_ws));
+            h->d_tail_ws = nullptr; h->tail_ws_bytes = 0;
+            HIP_TRY(hipMalloc(&h->d_tail_ws, need));
+            h->tail_ws_bytes = need;
+        }
     }
     HIP_TRY(hipStreamSynchronize(s));                  // an external stream may still be reading the tile buffers
     mark("stage begin", 0);
@@ -1618,10 +1751,10 @@ int mi_unet_layer_debug(int device, const char *op, const float *in, int B, int 
         out_n = (size_t)B * H * W * Cout;
         a.B = B; a.H = H; a.W = W; a.Cin = Cin; a.ldc = Cin; a.Cout = Cout; a.CoutPad = (int)npad; a.ldo = Cout; a.co_off = 0;
         a.relu = relu;
-    } else if (o == "conv3x3_bf16" || o == "convT2x2_bf16" || o == "conv3x3_fp16" || o == "convT2x2_fp16" || o == "conv3x3_bf16w" || o == "conv3x3_fp16w" || o == "conv3x3_bf16r" || o == "conv3x3_fp16r" || o == "convT2x2_bf16r" || o == "convT2x2_fp16r") {
+    } else if (o == "conv3x3_bf16" || o == "convT2x2_bf16" || o == "conv3x3_fp16" || o == "convT2x2_fp16" || o == "conv3x3_bf16w" || o == "conv3x3_fp16w" || o == "conv3x3_bf16r" || o == "conv3x3_fp16r" || o == "conv3x3_bf16k" || o == "conv3x3_fp16k" || o == "convT2x2_bf16r" || o == "convT2x2_fp16r") {
         if (!w || Cout <= 0 || Cin % 8) return fail(MI_UNET_EARG, "layer_debug: 16-bit conv needs weights and Cin % 8 == 0");
         const bool T = (o == "convT2x2_bf16" || o == "convT2x2_fp16" || o == "convT2x2_bf16r" || o == "convT2x2_fp16r");
-        const lp_cvt_fn cvt = (o == "conv3x3_fp16" || o == "convT2x2_fp16" || o == "conv3x3_fp16w" || o == "conv3x3_fp16r" || o == "convT2x2_fp16r") ? fp16_bits : bf16_bits;
+        const lp_cvt_fn cvt = (o == "conv3x3_fp16" || o == "convT2x2_fp16" || o == "conv3x3_fp16w" || o == "conv3x3_fp16r" || o == "conv3x3_fp16k" || o == "convT2x2_fp16r") ? fp16_bits : bf16_bits;
         const int nch = (Cin + KC_BF16 - 1) / KC_BF16;
         const size_t npad = round_up(T ? (size_t)4 * Cout : (size_t)Cout, NPAD);
         wpk.assign(((size_t)nch * (T ? 1 : 9) * npad * KC_BF16 + 1) / 2, 0.f);
@@ -1663,8 +1796,8 @@ int mi_unet_layer_debug(int device, const char *op, const float *in, int B, int 
     } else {
         return fail(MI_UNET_EARG, "layer_debug: unknown op " + o);
     }
-    const bool lp_in = (o == "conv3x3_bf16" || o == "convT2x2_bf16" || o == "conv3x3_fp16" || o == "convT2x2_fp16" || o == "conv3x3_bf16w" || o == "conv3x3_fp16w" || o == "conv3x3_bf16r" || o == "conv3x3_fp16r" || o == "convT2x2_bf16r" || o == "convT2x2_fp16r");
-    const bool lp_fp16 = (o == "conv3x3_fp16" || o == "convT2x2_fp16" || o == "conv3x3_fp16w" || o == "conv3x3_fp16r" || o == "convT2x2_fp16r");
+    const bool lp_in = (o == "conv3x3_bf16" || o == "convT2x2_bf16" || o == "conv3x3_fp16" || o == "convT2x2_fp16" || o == "conv3x3_bf16w" || o == "conv3x3_fp16w" || o == "conv3x3_bf16r" || o == "conv3x3_fp16r" || o == "conv3x3_bf16k" || o == "conv3x3_fp16k" || o == "convT2x2_bf16r" || o == "convT2x2_fp16r");
+    const bool lp_fp16 = (o == "conv3x3_fp16" || o == "convT2x2_fp16" || o == "conv3x3_fp16w" || o == "conv3x3_fp16r" || o == "conv3x3_fp16k" || o == "convT2x2_fp16r");
     if (lp_out && !lp_in) return fail(MI_UNET_EARG, "layer_debug: _lpout is for the 16-bit conv ops");
     a.out_lp = lp_out ? 1 : 0;
     int rc = MI_UNET_OK;
@@ -1702,6 +1835,8 @@ int mi_unet_layer_debug(int device, const char *op, const float *in, int B, int 
                 : o == "conv3x3_wino16" ? launch_conv3x3_wino16(a, nullptr)
                 : o == "conv3x3_bf16w" ? launch_conv3x3_lp2(a, false, nullptr)
                 : o == "conv3x3_fp16w" ? launch_conv3x3_lp2(a, true, nullptr)
+                : o == "conv3x3_bf16k" ? launch_conv3x3_lprk(a, false, nullptr)
+                : o == "conv3x3_fp16k" ? launch_conv3x3_lprk(a, true, nullptr)
                 : o == "conv3x3_bf16r" ? launch_conv3x3_lpr(a, false, nullptr)
                 : o == "conv3x3_fp16r" ? launch_conv3x3_lpr(a, true, nullptr)
                 : o == "convT2x2_bf16r" ? launch_convT2x2_lpr(a, false, nullptr)
@@ -1797,6 +1932,15 @@ void mi_unet_destroy(mi_unet_t *h)
     if (h->h_labels) (void)hipHostFree(h->h_labels);
     if (h->h_cont) (void)hipHostFree(h->h_cont);
     if (h->h_labels2) (void)hipHostFree(h->h_labels2);
+    if (h->tail_stream) { (void)hipStreamSynchronize(h->tail_stream); (void)hipStreamDestroy(h->tail_stream); }
+    void *tail_dev[] = { h->d_tail_ws, h->d_tail_vis, h->d_labels2 };
+    for (void *q : tail_dev)
+        if (q) (void)hipFree(q);
+    for (int i = 0; i < 2; ++i) {
+        if (h->net_done[i]) (void)hipEventDestroy(h->net_done[i]);
+        for (hipEvent_t e : h->tail_ev[i])
+            if (e) (void)hipEventDestroy(e);
+    }
     for (int i = 0; i < 3; ++i)
         for (hipEvent_t e : h->pre_ev[i])
             if (e) (void)hipEventDestroy(e);

@@ -20,6 +20,7 @@ struct Routing {
     int lp2 = 1;              // MIUNET_LP2: 0 never, 1 default thresholds, 2 every Cout % 128 == 0 layer
     int lpr = 1;              // MIUNET_LPR: 0 never, 1 when the tiles fill the chip four times over, 2 whatever the grid
     int lpr_rb = 2;           // MIUNET_LPR_RB: 1 = 8-row tiles for every shape
+    int lprk = 1;             // MIUNET_LPRK: the 128 -> 64 K-split resident-weight kernel (conv_lprk.hip), as lpr
     int convt_lpr = 1;        // MIUNET_CONVT_LPR: as lpr
     int wino4s = 1;           // MIUNET_WINO4S: 0 never, 1 grids that fill the chip twice over, 2 every one-block case
     bool convt_small = true;  // MIUNET_CONVT_SMALL=0: the per-tap transposed conv never shrinks its tile
@@ -115,6 +116,10 @@ hipError_t launch_conv3x3_lp2(const ConvArgs &a, bool fp16, hipStream_t s);
 // persistent workgroup per CU streaming input patches through an LDS ring (conv_lpr.hip).  Same packing, same arithmetic.
 bool conv3x3_lpr_takes(const ConvArgs &a);
 hipError_t launch_conv3x3_lpr(const ConvArgs &a, bool fp16, hipStream_t s);
+// 128 -> 64 channels (the first convolution behind the top-level concat): the same scheme with the reduction split over a wave
+// pair, partial sums through LDS (conv_lprk.hip).  Same packing; fp32 re-association differs from conv_mfma_bf16 by one add.
+bool conv3x3_lprk_takes(const ConvArgs &a);
+hipError_t launch_conv3x3_lprk(const ConvArgs &a, bool fp16, hipStream_t s);
 // ... and the three largest transposed convolutions (Cin -> Cout = 64 -> 32, 128 -> 64, 256 -> 128; convt_lpr.hip)
 bool convT2x2_lpr_takes(const ConvArgs &a);
 hipError_t launch_convT2x2_lpr(const ConvArgs &a, bool fp16, hipStream_t s);

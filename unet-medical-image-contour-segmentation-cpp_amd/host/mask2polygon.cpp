@@ -4,6 +4,7 @@
 // compression and newest-first contour order.
 #include "../../include/medseg/mask2polygon.h"
 
+#include <cstring>
 #include <cstdlib>
 #include <filesystem>
 #include <fstream>
@@ -178,9 +179,13 @@ void generate_json(const std::vector<Contour> &contours, const std::string &json
 Image8 draw_overlay(const Image8 &src, const std::vector<Contour> &contours)
 {
     Image8 img(src.rows, src.cols, 3);
-    for (int y = 0; y < src.rows; ++y)
-        for (int x = 0; x < src.cols; ++x)
-            for (int c = 0; c < 3; ++c) img.at(y, x, c) = src.at(y, x, src.channels == 3 ? c : 0);
+    for (int y = 0; y < src.rows; ++y) {                              // cv::imread(IMREAD_COLOR) of a gray PNG: B = G = R = gray
+        const uint8_t *s = src.ptr(y);
+        uint8_t *d = img.ptr(y);
+        if (src.channels == 3) std::memcpy(d, s, (size_t)src.cols * 3);
+        else
+            for (int x = 0; x < src.cols; ++x) { const uint8_t g = s[x]; d[3 * x] = g; d[3 * x + 1] = g; d[3 * x + 2] = g; }
+    }
     const uint8_t red_bgr[3] = { 0, 0, 255 };                         // cv::Scalar(0, 0, 255), src/mask2polygon.cpp:10
     for (const Contour &c : contours)                                 // drawContours(-1, thickness 1): closed polylines
         for (size_t k = 0; k < c.size(); ++k) draw_segment(img, c[k], c[(k + 1) % c.size()], red_bgr);
