@@ -50,6 +50,9 @@ __device__ __forceinline__ void mfma16_vgpr(f32x4 &acc, const float a, const flo
 // transform's role split costs"): 1 = every wave runs the one-row transform role (no role branches, half the transform
 // VALU), 2 = every wave runs wave 0's two-row role (no role branches, same VALU as the heaviest wave), 3 = no forward
 // transform at all, 4 = the inverse transform and the stores replaced by a checksum of the accumulators.
+// EXP = 5 (correct results): the two-block kernel PERSISTENT -- one workgroup per CU walks its XCD's tiles, the raw-patch DMA of
+// tile T+1 is issued before the epilogue of tile T, its U ring after it (hipcc spills 33 loop-invariant registers around the tile
+// loop; reloaded once per tile, outside the K loop).
 template <int NB, bool HEAD, bool SPLITK, int EXP = 0>
 __global__ __launch_bounds__(256, 1) void conv3x3_wino4_f32(const ConvArgs a, const int tiles_x, const int tiles_y,
                                                             const int m_tiles, const int nwg)
@@ -89,14 +92,19 @@ __global__ __launch_bounds__(256, 1) void conv3x3_wino4_f32(const ConvArgs a, co
         u_voff = (unsigned)(ncol0 * WINO4_KC + 4 * kq) * 4;
         in_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(a.in + (size_t)b * a.H * a.W * a.ldc), 0,
                                                     a.H * a.W * a.ldc * 4, 0x00020000);
+        // the two-block kernel's persistent build has no registers for loop-invariant per-lane values across the tile loop (hipcc
+        // hoists these divisions out of it and then spills them): the lane index is laundered through an empty asm, so they
+        // are recomputed per tile (a few dozen VALU against a 100 k-cycle tile)
+        int ln = lane;
+        if constexpr (NB == 2 && EXP == 5) asm volatile("" : "+v"(ln));
 #pragma unroll
         for (int s = 0; s < W4::RAW_ITERS; ++s) {
-            const int g = (wave + 4 * s) * 16 + (lane >> 2);                  // linear slot of this lane in load wave + 4s
+            const int g = (wave + 4 * s) * 16 + (ln >> 2);                    // linear slot of this lane in load wave + 4s
             const int py = g / W4::RAW_ROW, sl = g - py * W4::RAW_ROW;
             const int px = 4 * (sl % 5) + sl / 5;
             const int gy = by0 - 1 + py, gx = bx0 - 1 + px;
             const bool inb = g < W4::RAW_SLOTS && px < 18 && gy >= 0 && gy < a.H && gx >= 0 && gx < a.W;
-            raw_voff[s] = inb ? (unsigned)(((gy * a.W + gx) * a.ldc + 4 * (lane & 3)) * 4) : 0xFFFFFFFFu;
+            raw_voff[s] = inb ? (unsigned)(((gy * a.W + gx) * a.ldc + 4 * (ln & 3)) * 4) : 0xFFFFFFFFu;
         }
     };
     typedef __attribute__((address_space(3))) void *lds_ptr;
@@ -124,7 +132,7 @@ __global__ __launch_bounds__(256, 1) void conv3x3_wino4_f32(const ConvArgs a, co
     const bool two = wrole < 2;
     const int t_tile = lane >> 2, t_quad = lane & 3;
     const int row0 = two ? 1 : wrole - 2, rstep = two ? 1 : 2;
-    const float *const p_rd = Raw + (((4 * (t_tile >> 2) + row0) * W4::RAW_ROW + (t_tile & 3)) * 4 + t_quad) * 4;
+    int p_rd_off = (((4 * (t_tile >> 2) + row0) * W4::RAW_ROW + (t_tile & 3)) * 4 + t_quad) * 4;     // (laundered per tile in the persistent two-block build)
     const int p_rstride = rstep * W4::RAW_ROW * WINO4_KC;
     const int xi_a = two ? (wrole == 0 ? 1 : 3) : (wrole == 2 ? 0 : 5);
     const float c_alpha = wrole == 0 ? -4.f : -1.f, c_beta = wrole == 0 ? 1.f : 2.f;
@@ -133,7 +141,7 @@ __global__ __launch_bounds__(256, 1) void conv3x3_wino4_f32(const ConvArgs a, co
     f32x4 cR[2][6];                           // rows of B^T d (row b only on the two-row waves)
     f32x4 e_[4];
     auto piece_load = [&](int k, int rbuf) {
-        const float *src = p_rd + rbuf * W4::RAW_FLOATS + ((k & 3) * 5 + (k >> 2)) * WINO4_KC;      // pixel 4*tx + k -> slot 5*(k&3) + tx + (k>>2)
+        const float *src = Raw + p_rd_off + rbuf * W4::RAW_FLOATS + ((k & 3) * 5 + (k >> 2)) * WINO4_KC;      // pixel 4*tx + k -> slot 5*(k&3) + tx + (k>>2)
         px_[0] = *reinterpret_cast<const f32x4 *>(src);
         px_[1] = *reinterpret_cast<const f32x4 *>(src + p_rstride);
         px_[2] = *reinterpret_cast<const f32x4 *>(src + 2 * p_rstride);
@@ -216,6 +224,14 @@ __global__ __launch_bounds__(256, 1) void conv3x3_wino4_f32(const ConvArgs a, co
         }
         raw_dma(c_begin, 0);
         raw_dma(c_begin + 1, 1);
+        if constexpr (!((NB == 2 && EXP == 5) && !SPLITK)) {
+#pragma unroll
+            for (int p = 0; p < UD; ++p)
+#pragma unroll
+                for (int blk = 0; blk < NB; ++blk) u[p][blk] = u_load(c_begin, p, blk);
+        }
+    };
+    auto open_tile_u = [&]() {
 #pragma unroll
         for (int p = 0; p < UD; ++p)
 #pragma unroll
@@ -225,7 +241,8 @@ __global__ __launch_bounds__(256, 1) void conv3x3_wino4_f32(const ConvArgs a, co
     // PERSIST (one-block variant): this workgroup's share of its XCD's logical tile range (the bijective XCD remap of
     // kernel_common.h, walked with a stride).  The two-block variant has no registers left to hold a second tile's opening
     // loads across its epilogue: one tile per workgroup there (the loop below runs once and folds away).
-    constexpr bool PERSIST = NB == 1 && !SPLITK;
+    constexpr bool PERSIST = (NB == 1 || EXP == 5) && !SPLITK;
+    constexpr bool U_LATE = PERSIST && NB == 2;      // no registers for a second tile's U ring across the epilogue
     const int G = gridDim.x, xcd = blockIdx.x & 7;
     const int slot = PERSIST ? (int)(blockIdx.x >> 3) : 0;
     const int slots = PERSIST ? (G >> 3) + (xcd < (G & 7) ? 1 : 0) : 1;
@@ -235,8 +252,10 @@ __global__ __launch_bounds__(256, 1) void conv3x3_wino4_f32(const ConvArgs a, co
     if (slot < t_count) {
         setup_tile(t_start + slot);
         open_tile();
+        if constexpr (U_LATE) open_tile_u();
     }
     for (int tt = slot; tt < t_count; tt += slots) {
+    if constexpr (NB == 2 && EXP == 5) asm volatile("" : "+v"(p_rd_off));     // recompute the first transform's 24 LDS addresses per tile: no registers to keep them
     f32x4 acc[36][NB];
 #pragma unroll
     for (int p = 0; p < 36; ++p)
@@ -467,6 +486,7 @@ __global__ __launch_bounds__(256, 1) void conv3x3_wino4_f32(const ConvArgs a, co
             a.head_labels[(size_t)e_b * hw + pin] = (uint8_t)idx;
         }
     }
+    if constexpr (U_LATE) { if (tt + slots < t_count) open_tile_u(); }
     }   // persistent tile loop
 }
 
@@ -498,11 +518,14 @@ static hipError_t launch_wino4_cfg(const ConvArgs &a0, hipStream_t s)
     }
     if constexpr (NB == 2 && !HEAD) {                  // timing-only experiment builds of the two-block kernel (see the kernel's EXP)
         static const int exp = [] { const char *e = getenv("MIUNET_W4_EXP"); return e ? atoi(e) : 0; }();
-        if (exp >= 1 && exp <= 4) {
+        if (exp >= 1 && exp <= 5) {
             auto ke = exp == 1 ? conv3x3_wino4_f32<2, false, false, 1> : exp == 2 ? conv3x3_wino4_f32<2, false, false, 2>
-                    : exp == 3 ? conv3x3_wino4_f32<2, false, false, 3> : conv3x3_wino4_f32<2, false, false, 4>;
+                    : exp == 3 ? conv3x3_wino4_f32<2, false, false, 3> : exp == 4 ? conv3x3_wino4_f32<2, false, false, 4>
+                    : conv3x3_wino4_f32<2, false, false, 5>;
             if (hipError_t e = ensure_dynamic_lds(ke, W4::LDS_BYTES); e != hipSuccess) return e;
-            hipLaunchKernelGGL(ke, dim3(nwg), dim3(256), W4::LDS_BYTES, s, a, tiles_x, tiles_y, m_tiles, nwg);
+            const int cus = routing_of(a).cus;
+            const int ge = (exp == 5 && nwg > cus) ? cus : nwg;
+            hipLaunchKernelGGL(ke, dim3(ge), dim3(256), W4::LDS_BYTES, s, a, tiles_x, tiles_y, m_tiles, nwg);
             return hipGetLastError();
         }
     }
