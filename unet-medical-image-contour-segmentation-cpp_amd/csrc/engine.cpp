@@ -163,7 +163,7 @@ struct mi_unet {
     // network of micro-batch k runs (d_img / d_img2 alternate)
     hipStream_t pre_stream = nullptr;
     uint8_t *d_img2 = nullptr;
-    hipEvent_t tile_ready[2] = {}, tile_free[2] = {};
+    hipEvent_t tile_ready[2] = {};
     // stage timing of the last RAW-in call (mi_unet_last_stage_ms): event pairs per micro-batch, summed
     hipEvent_t stage_ev[2][5] = {}, out_done[2] = {};
     hipEvent_t pre_ev[3][2] = {};   // three pairs: micro-batch k + 2 is staged before k's times are read
@@ -172,6 +172,8 @@ struct mi_unet {
     // here while the engine's stream already works on the network of k + 1; own workspace (the network's scratch buffers,
     // which the single-stage entry points borrow, are in use by then), second label buffer
     hipStream_t tail_stream = nullptr;
+    hipStream_t dl_stream = nullptr;          // tile downloads: behind the network of k, beside its tail and the upload of k + 1
+    hipEvent_t tiles_done[2] = {};
     void *d_tail_ws = nullptr;
     size_t tail_ws_bytes = 0;
     uint8_t *d_tail_vis = nullptr, *d_labels2 = nullptr;
@@ -1290,6 +1292,18 @@ namespace {
 // (plane c of image i at index i*C + c, each with its own size and its own min/max, as if every plane went through
 // preprocess_raw on its own) and interleaves them into the HWC tile the first layer reads; a caller holding one plane per
 // image passes its pointer C times (the grey -> B,G,R replication cv::imread(IMREAD_COLOR) does at src/mask2polygon.cpp:117).
+// large host copies (RAW staging in, tiles / masks out) on the handle's helper threads (MIUNET_COPY_THREADS, default 4; 1 = plain memcpy)
+void host_copy(mi_unet *h, void *dst, const void *src, size_t bytes)
+{
+    static const int copy_threads = [] { const char *e = getenv("MIUNET_COPY_THREADS"); const int v = e ? atoi(e) : 4; return v < 1 ? 1 : v > 16 ? 16 : v; }();
+    if (copy_threads > 1 && bytes >= (1u << 20)) {
+        if (!h->copy_pool) h->copy_pool.reset(new CopyPool(copy_threads - 1));
+        h->copy_pool->copy(dst, src, bytes);
+    } else {
+        memcpy(dst, src, bytes);
+    }
+}
+
 int stage_raw16(mi_unet *h, const uint16_t *const *raws, const int *widths, const int *heights, int bm, hipStream_t s, uint8_t *d_tiles)
 {
     const int C = h->cfg.in_ch;
@@ -1327,13 +1341,7 @@ int stage_raw16(mi_unet *h, const uint16_t *const *raws, const int *widths, cons
             const bool pinned = hipPointerGetAttributes(&attr, raws[i]) == hipSuccess && attr.type == hipMemoryTypeHost;
             if (!pinned) {
                 (void)hipGetLastError();             // an ordinary host pointer is "invalid value" to the query: not an error of ours
-                static const int copy_threads = [] { const char *e = getenv("MIUNET_COPY_THREADS"); const int v = e ? atoi(e) : 4; return v < 1 ? 1 : v > 16 ? 16 : v; }();
-                if (copy_threads > 1 && n * sizeof(uint16_t) >= (1u << 20)) {
-                    if (!h->copy_pool) h->copy_pool.reset(new CopyPool(copy_threads - 1));
-                    h->copy_pool->copy(h->h_raw[slot], raws[i], n * sizeof(uint16_t));
-                } else {
-                    memcpy(h->h_raw[slot], raws[i], n * sizeof(uint16_t));
-                }
+                host_copy(h, h->h_raw[slot], raws[i], n * sizeof(uint16_t));
             }
             HIP_TRY(hipMemcpyAsync(h->d_raw[slot], pinned ? raws[i] : h->h_raw[slot], n * sizeof(uint16_t), hipMemcpyHostToDevice, s));
         }
@@ -1356,6 +1364,9 @@ int ensure_raw_pipeline(mi_unet *h, bool two_buffers)
 {
     if (!h->pre_stream) HIP_TRY(hipStreamCreateWithFlags(&h->pre_stream, hipStreamNonBlocking));
     if (!h->tail_stream) HIP_TRY(hipStreamCreateWithFlags(&h->tail_stream, hipStreamNonBlocking));
+    if (!h->dl_stream) HIP_TRY(hipStreamCreateWithFlags(&h->dl_stream, hipStreamNonBlocking));
+    for (hipEvent_t &e : h->tiles_done)
+        if (!e) HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming));
     const size_t npix = (size_t)h->cfg.max_batch * h->cfg.height * h->cfg.width;
     if (!h->d_tail_vis) HIP_TRY(hipMalloc(&h->d_tail_vis, npix));
     if (!h->d_labels2) HIP_TRY(hipMalloc(&h->d_labels2, npix));
@@ -1366,7 +1377,6 @@ int ensure_raw_pipeline(mi_unet *h, bool two_buffers)
     }
     for (int i = 0; i < 2; ++i) {
         if (!h->tile_ready[i]) HIP_TRY(hipEventCreateWithFlags(&h->tile_ready[i], hipEventDisableTiming));
-        if (!h->tile_free[i]) HIP_TRY(hipEventCreateWithFlags(&h->tile_free[i], hipEventDisableTiming));
     }
     for (int i = 0; i < 2; ++i) {
         for (hipEvent_t &e : h->stage_ev[i])
@@ -1444,7 +1454,7 @@ int run_raw_call(mi_unet *h, const RawCall &c)
     auto stage = [&](int k) -> int {                   // upload + preprocess micro-batch k on the second stream
         const int bm = mbs[k].bm, par = k & 1;
         const size_t b0 = (size_t)mbs[k].b0;
-        if (k >= 2) HIP_TRY(hipStreamWaitEvent(h->pre_stream, h->tile_free[par], 0));      // its last reader: micro-batch k - 2
+        if (k >= 2) HIP_TRY(hipStreamWaitEvent(h->pre_stream, c.tiles ? h->tiles_done[par] : h->net_done[par], 0));   // its last readers: network and tile download of k - 2
         HIP_TRY(hipEventRecord(h->pre_ev[k % 3][0], h->pre_stream));
         if (int rc = stage_raw16(h, c.raws + b0 * C, c.widths + b0 * C, c.heights + b0 * C, bm, h->pre_stream, tile_buf(k))) return rc;
         HIP_TRY(hipEventRecord(h->pre_ev[k % 3][1], h->pre_stream));
@@ -1469,6 +1479,11 @@ int run_raw_call(mi_unet *h, const RawCall &c)
             HIP_TRY(hipMemcpyAsync(c.logits + b0 * hw * h->cfg.classes, h->d_logits, sizeof(float) * bm * hw * h->cfg.classes,
                                    hipMemcpyDeviceToHost, s));
         HIP_TRY(hipEventRecord(h->net_done[par], s));
+        if (c.tiles) {                                 // the tiles leave on their own stream, beside the tail kernels
+            HIP_TRY(hipStreamWaitEvent(h->dl_stream, h->net_done[par], 0));
+            HIP_TRY(hipMemcpyAsync(h->h_tiles[par], d_tiles, bm * hw * C, hipMemcpyDeviceToHost, h->dl_stream));
+            HIP_TRY(hipEventRecord(h->tiles_done[par], h->dl_stream));
+        }
         // ---- tail: ordered behind the network of k, concurrent with the network of k + 1
         HIP_TRY(hipStreamWaitEvent(ts, h->net_done[par], 0));
         hipEvent_t *tv = h->tail_ev[par];
@@ -1489,8 +1504,6 @@ int run_raw_call(mi_unet *h, const RawCall &c)
             d_result = h->d_tail_vis;
         }
         HIP_TRY(hipEventRecord(tv[2], ts));
-        if (c.tiles) HIP_TRY(hipMemcpyAsync(h->h_tiles[par], d_tiles, bm * hw * C, hipMemcpyDeviceToHost, ts));
-        HIP_TRY(hipEventRecord(h->tile_free[par], ts));
         HIP_TRY(hipMemcpyAsync(out_buf(k), d_result, bm * hw, hipMemcpyDeviceToHost, ts));
         if (c.segment) {
             const size_t n = (size_t)bm * ((size_t)c.cap_points * 2 + c.cap_contours + 1 + 1);
@@ -1503,9 +1516,12 @@ int run_raw_call(mi_unet *h, const RawCall &c)
     auto finalize = [&](int k) -> int {                // micro-batch k has left the device: pinned halves -> the caller's arrays
         const int bm = mbs[k].bm, par = k & 1;
         const size_t b0 = (size_t)mbs[k].b0;
+        if (c.tiles) {                                 // (done long before the tail: copied out while the tail still runs)
+            HIP_TRY(hipEventSynchronize(h->tiles_done[par]));
+            host_copy(h, c.tiles + b0 * hw * C, h->h_tiles[par], bm * hw * C);
+        }
         HIP_TRY(hipEventSynchronize(h->out_done[par]));
-        memcpy(c.out_u8 + b0 * hw, out_buf(k), bm * hw);
-        if (c.tiles) memcpy(c.tiles + b0 * hw * C, h->h_tiles[par], bm * hw * C);
+        host_copy(h, c.out_u8 + b0 * hw, out_buf(k), bm * hw);
         if (c.segment)
             contours_to_caller(h, bm, c.cap_points, c.cap_contours, c.xy + b0 * c.cap_points * 2, c.start + b0 * (c.cap_contours + 1), c.counts + b0, par);
         float ms = 0.f;
@@ -1933,6 +1949,9 @@ void mi_unet_destroy(mi_unet_t *h)
     if (h->h_cont) (void)hipHostFree(h->h_cont);
     if (h->h_labels2) (void)hipHostFree(h->h_labels2);
     if (h->tail_stream) { (void)hipStreamSynchronize(h->tail_stream); (void)hipStreamDestroy(h->tail_stream); }
+    if (h->dl_stream) { (void)hipStreamSynchronize(h->dl_stream); (void)hipStreamDestroy(h->dl_stream); }
+    for (hipEvent_t e : h->tiles_done)
+        if (e) (void)hipEventDestroy(e);
     void *tail_dev[] = { h->d_tail_ws, h->d_tail_vis, h->d_labels2 };
     for (void *q : tail_dev)
         if (q) (void)hipFree(q);
@@ -1948,7 +1967,7 @@ void mi_unet_destroy(mi_unet_t *h)
     if (h->pre_stream) { (void)hipStreamSynchronize(h->pre_stream); (void)hipStreamDestroy(h->pre_stream); }
     for (int i = 0; i < 2; ++i) {
         if (h->h_tiles[i]) (void)hipHostFree(h->h_tiles[i]);
-        hipEvent_t evs2[] = { h->tile_ready[i], h->tile_free[i], h->out_done[i] };
+        hipEvent_t evs2[] = { h->tile_ready[i], h->out_done[i] };
         for (hipEvent_t e : evs2)
             if (e) (void)hipEventDestroy(e);
         for (hipEvent_t e : h->stage_ev[i])
