@@ -42,7 +42,11 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 PKG = os.path.join(ROOT, "unet-medical-image-contour-segmentation-cpp_amd")
 sys.path.insert(0, PKG)
 
-FP32_PEAK_TFLOPS = 157.3      # MI355X_MICROARCH.md: fp32 matrix peak (v_mfma_f32_32x32x2_f32 / 16x16x4_f32)
+# ONE set of peaks prices every roofline figure of this file and of profiles/summarize_pmc.py: the NOMINAL ones of
+# MI355X_MICROARCH.md (2.4 GHz).  The kernel headers (csrc/conv_lpr.hip, conv_lp2.hip) also quote what this card SUSTAINS -- 1.89
+# PFLOP/s for a register-only bf16 MFMA loop (the clock drops to 1.80 GHz under dense 16-bit matrix work), 6.29 TB/s for an HBM copy
+# -- as the practical ceilings their design notes argue against; those are never the denominator of a reported fraction.
+FP32_PEAK_TFLOPS = 157.3      # fp32 matrix peak (v_mfma_f32_32x32x2_f32 / 16x16x4_f32); the fp32 loop holds 2.38 GHz: 155.6 TF/s measured
 LP_PEAK_TFLOPS = 2500.0       # dense bf16 / fp16 MFMA peak (v_mfma_f32_32x32x16_{bf16,f16})
 HBM_PEAK_GBS = 8000.0
 
