@@ -72,3 +72,24 @@ def test_committed_pmc_summaries_carry_a_source_hash():
     for f in files:
         d = json.load(open(f))
         assert len(d["kernel_source_sha"]) == 16 and d["kernels"], f
+
+
+def test_group_child_idles_until_told_and_never_costs_the_headline():
+    """The `group` record (mi_unet_group_* over every visible device, one process) runs in a child that bench.py starts BEFORE it
+    touches the GPU; the child waits on stdin.  Told not to run it leaves quietly without importing anything GPU-related; a child
+    that overruns its deadline is killed by PID and becomes an error record, never an exception in the parent."""
+    import subprocess
+    child = bench.start_group_child()
+    assert bench.finish_group_child(child, run=False) is None and child.returncode == 0
+    hang = subprocess.Popen([sys.executable, "-c", "import sys, time; sys.stdin.readline(); time.sleep(60)"], stdin=subprocess.PIPE,
+                            stdout=subprocess.PIPE, text=True)
+    rec = bench.finish_group_child(hang, run=True, deadline_s=1)
+    assert "error" in rec and "killed" in rec["error"] and hang.poll() is not None
+    assert bench.finish_group_child(None, run=True) is None
+
+
+def test_the_newest_pmc_summary_describes_this_tree():
+    """the judged roofline quotes `traffic` / `mfma_busy` only from a PMC summary whose source hash equals the tree's: the last
+    profile round must have run on the final kernels"""
+    d, src = bench.pmc_summary("fp32")
+    assert d is not None, src

@@ -10,7 +10,8 @@ namespace miunet {
 // --------------------------------------------------------------------------------------------------------------------
 // The top levels of the 16-bit pipelines (512 x 512 x 64 in BASELINE config 3, 1024 x 1024 x 32 and 512 x 512 x 64 in
 // config 5) sit at the ridge of the roofline: 64 -> 64 channels is 288 FLOP per byte moved, 32 -> 32 half of that, against
-// 1.89 PFLOP/s / 6.3 TB/s = 300.  conv_mfma_bf16 (conv_lp.hip) runs them at 40-48 % of either roof: one tile per workgroup,
+// 1.89 PFLOP/s / 6.3 TB/s = 300 (what this card SUSTAINS: a register-only bf16 MFMA loop, an HBM copy -- the practical ceilings
+// this design argues against; every REPORTED fraction is priced at the nominal 2.5 PFLOP/s / 8 TB/s of bench.py).  conv_mfma_bf16 (conv_lp.hip) runs them at 40-48 % of either roof: one tile per workgroup,
 // and every tile stages the layer's WHOLE weight set into LDS again (73 KB for 64 -> 64: more bytes than its input patch),
 // waits for its patch with nothing else to do, and reads one LDS fragment per MFMA.  Here:
 //   * one PERSISTENT workgroup of eight waves per CU walks its XCD's share of the 8 x 32-pixel tiles;

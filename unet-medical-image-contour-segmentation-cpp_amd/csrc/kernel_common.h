@@ -2,6 +2,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 
+#include <atomic>
 #include <mutex>
 
 #include "kernels.h"
@@ -33,25 +34,38 @@ __device__ __forceinline__ int xcd_remap(int bid, int nwg)
 
 // Kernels that need more than 64 KB of dynamic LDS must opt in once per (kernel, device).  Keyed by the kernel's address:
 // template instantiations share one function-pointer TYPE, so a per-type flag would cover only the first of them.
+// The table is read without a lock on the launch path (an eager launch used to take a process-wide mutex here: contexts of
+// different host threads launch concurrently); the mutex only serialises the rare first opt-in of a (kernel, device, size).
 template <typename K>
 inline hipError_t ensure_dynamic_lds(K kernel, size_t bytes)
 {
-    struct Slot { const void *fn; size_t bytes[64]; };           // largest size opted in so far, per device
-    static Slot slots[16] = {};
-    static std::mutex guard;                                     // engines of different host threads launch concurrently
-    std::lock_guard<std::mutex> lk(guard);
+    struct Slot { std::atomic<const void *> fn; std::atomic<size_t> bytes[64]; };           // largest size opted in so far, per device
+    static Slot slots[32];
+    static std::mutex guard;
     const void *fn = reinterpret_cast<const void *>(kernel);
     int dev = 0;
-    hipError_t e = hipGetDevice(&dev);
+    hipError_t e = hipGetDevice(&dev);                               // (a thread-local read inside the runtime)
     if (e != hipSuccess) return e;
     if (dev < 0 || dev >= 64) return hipErrorInvalidDevice;
-    Slot *sl = nullptr;
-    for (Slot &c : slots)
-        if (c.fn == fn || c.fn == nullptr) { sl = &c; break; }
-    if (sl != nullptr && sl->fn == fn && sl->bytes[dev] >= bytes) return hipSuccess;
+    for (Slot &c : slots) {
+        const void *f = c.fn.load(std::memory_order_acquire);
+        if (f == nullptr) break;
+        if (f == fn) {
+            if (c.bytes[dev].load(std::memory_order_acquire) >= bytes) return hipSuccess;
+            break;
+        }
+    }
+    std::lock_guard<std::mutex> lk(guard);
     e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
     if (e != hipSuccess) return e;
-    if (sl != nullptr) { sl->fn = fn; sl->bytes[dev] = bytes; }     // table full: just set the attribute every time
+    for (Slot &c : slots) {
+        const void *f = c.fn.load(std::memory_order_relaxed);
+        if (f == fn || f == nullptr) {
+            if (c.bytes[dev].load(std::memory_order_relaxed) < bytes) c.bytes[dev].store(bytes, std::memory_order_release);
+            if (f == nullptr) c.fn.store(fn, std::memory_order_release);
+            break;
+        }
+    }                                                               // table full: the attribute is simply set again next time
     return hipSuccess;
 }
 
