@@ -372,7 +372,13 @@ struct ChunkText {
 
 constexpr int kCapPoints = 1 << 15, kCapContours = 64;     // postprocess keeps components >= 6 % of the tile: <= 16
 
-int io_threads_for(size_t n) { return (int)std::max<size_t>(1, std::min<size_t>(n, 8)); }   // a few I/O threads, never the whole machine
+// I/O and artefact threads of directory mode: one per image of the chunk up to MEDSEG_IO_THREADS (default 16 -- a GPU's share of a
+// host, never the whole machine: an 8-GPU node runs eight of these pools)
+int io_threads_for(size_t n)
+{
+    static const int cap = std::max(1, env_int("MEDSEG_IO_THREADS", 16));
+    return (int)std::max<size_t>(1, std::min<size_t>(n, (size_t)cap));
+}
 
 ChunkIn read_chunk(const std::vector<std::string> &paths, const std::vector<int> &widths, const std::vector<int> &heights,
                    size_t first, size_t count)
@@ -599,7 +605,7 @@ int process_image_batch(const std::vector<std::string> &raw_paths, const std::ve
         std::vector<size_t> idx;                           // images that could be read
         std::vector<std::string> read_err(n);
         const auto t_read = std::chrono::high_resolution_clock::now();
-        const int io_threads = (int)std::max<size_t>(1, std::min<size_t>(n, 8));   // a few I/O threads, never the whole machine
+        const int io_threads = io_threads_for(n);
 #pragma omp parallel for schedule(dynamic) num_threads(io_threads)   // independent file reads; messages in file order below
         for (long long i = 0; i < (long long)n; ++i) {
             try {
