@@ -65,6 +65,46 @@ def _small():
 
 
 @pytest.mark.gpu
+def test_group_rccl_code_path_executes_on_a_stand_in_library(tmp_path, monkeypatch):
+    """The group's RCCL calls -- ncclCommInitAll, the grouped ncclBroadcast of the weight blob, the grouped ncclSend / ncclRecv
+    gather of label maps into the first rank -- have never met a second GPU (gpurun offers one).  tests/cpu/fake_rccl.cpp is a
+    stand-in library with the same entry points whose transfers are device-to-device copies, so that this code path EXECUTES here
+    with two and three ranks sharing the card: a wrong peer, offset or count in csrc/group.cpp gives wrong label maps, an
+    unmatched send / recv an error.  (It says nothing about RCCL itself.)"""
+    import shutil
+    import subprocess
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    so = tmp_path / "libfake_rccl.so"
+    subprocess.check_call([hipcc, "-O1", "-std=c++17", "-fPIC", "-shared", "-x", "hip", "--offload-arch=gfx950",
+                           os.path.join(root, "tests", "cpu", "fake_rccl.cpp"), "-o", str(so)], stderr=subprocess.DEVNULL)
+    monkeypatch.setenv("MIUNET_RCCL_LIB", str(so))
+    monkeypatch.setenv("MIUNET_GROUP_RCCL", "2")
+    spec, blob = _small()
+    imgs = synth.make_images(7, 64, 96, 1, 0xC4, "blobs")
+    with binding.Engine(64, 96, 1, 16, 2, 3, max_batch=2) as eng:
+        eng.load_weights(blob)
+        want, _ = eng.infer(imgs)
+    for devices in ([0, 0], [0, 0, 0]):
+        with binding.Group(64, 96, 1, 16, 2, 3, max_batch=2, devices=devices) as g:
+            assert g.size == len(devices) and g.weight_transport == "rccl"
+            g.load_weights(blob)                       # ranks > 0 receive the packed blob through the grouped broadcast
+            assert g.weight_transport == "rccl"
+            for b in (7, 5, 1, 2):                     # ragged shards; with one image the later ranks own nothing
+                g.set_gather("host")
+                lab_h, _ = g.infer(imgs[:b])
+                g.set_gather("xgmi")
+                lab_x, _ = g.infer(imgs[:b])
+                assert np.array_equal(lab_h, want[:b]) and np.array_equal(lab_x, want[:b]), (devices, b)
+            g.set_postprocess(True)
+            g.set_gather("xgmi")
+            post, _ = g.infer(imgs)
+            g.set_postprocess(False)
+        assert post.shape == want.shape and set(np.unique(post)) <= {0, 2}
+
+
+@pytest.mark.gpu
 def test_group_of_one_equals_the_engine():
     spec, blob = _small()
     imgs = synth.make_images(5, 64, 96, 1, 0xA1, "blobs")

@@ -44,9 +44,11 @@ struct Rccl {
     bool load(std::string &why)
     {
         if (so) return true;
-        const char *names[] = { "librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1" };
+        // MIUNET_RCCL_LIB: another library with the same eight entry points (tests/cpu/fake_rccl.cpp: the group's RCCL calls executed
+        // on a one-GPU box, every transfer a device-to-device copy)
+        const char *names[] = { getenv("MIUNET_RCCL_LIB"), "librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1" };
         for (const char *n : names)
-            if ((so = dlopen(n, RTLD_NOW | RTLD_LOCAL)) != nullptr) break;
+            if (n && *n && (so = dlopen(n, RTLD_NOW | RTLD_LOCAL)) != nullptr) break;
         if (!so) { why = std::string("dlopen librccl: ") + dlerror(); return false; }
         auto sym = [&](const char *n) { void *p = dlsym(so, n); if (!p) why = std::string("librccl lacks ") + n; return p; };
         CommInitAll = reinterpret_cast<decltype(CommInitAll)>(sym("ncclCommInitAll"));
@@ -165,8 +167,9 @@ int mi_unet_group_create(const mi_unet_config *cfg, const int *devices, int n_de
     // RCCL communicators: only for > 1 rank on pairwise distinct devices (MIUNET_GROUP_RCCL=0 forces the peer-copy path,
     // =1 also builds a one-rank communicator so that the RCCL calls can be rehearsed on a single GPU)
     const char *env = getenv("MIUNET_GROUP_RCCL");
-    const bool distinct = std::set<int>(devs.begin(), devs.end()).size() == R;
-    const bool want = distinct && !(env && env[0] == '0') && (R > 1 || (env && env[0] == '1'));
+    // (=2, tests only: communicators even when ranks share a device -- real RCCL refuses that, the stand-in of MIUNET_RCCL_LIB does not)
+    const bool distinct = std::set<int>(devs.begin(), devs.end()).size() == R || (env && env[0] == '2');
+    const bool want = distinct && !(env && env[0] == '0') && (R > 1 || (env && (env[0] == '1' || env[0] == '2')));
     if (want) {
         std::string why;
         if (g->rccl.load(why)) {
@@ -174,11 +177,11 @@ int mi_unet_group_create(const mi_unet_config *cfg, const int *devices, int n_de
             const int rc = g->rccl.CommInitAll(g->comms.data(), (int)R, devs.data());
             if (rc != 0) {
                 g->comms.clear();
-                if (env && env[0] == '1') { const int e = nccl_fail(g, rc, "ncclCommInitAll"); mi_unet_group_destroy(g); return e; }
+                if (env && (env[0] == '1' || env[0] == '2')) { const int e = nccl_fail(g, rc, "ncclCommInitAll"); mi_unet_group_destroy(g); return e; }
             } else {
                 g->transport = "rccl";
             }
-        } else if (env && env[0] == '1') {
+        } else if (env && (env[0] == '1' || env[0] == '2')) {
             mi_unet_group_destroy(g);
             return engine_fail(MI_UNET_EHIP, why);
         }
