@@ -233,7 +233,9 @@ void mi_unet_destroy(mi_unet_t *h);
  *             first device (7 concurrent point-to-point transfers on an 8-GPU node), then one D2H.
  * `devices` lists HIP ordinals, one rank each (a repeated ordinal puts two ranks on one GPU: a test configuration, peer-copy
  * weights, HOST gather only); devices == NULL means ordinals cfg->device .. cfg->device + n_devices - 1, and n_devices <= 0
- * means every visible device.  cfg->max_batch is per rank.  N > 1 distinct devices has never run on hardware here. */
+ * means every visible device.  cfg->max_batch is per rank.  N > 1 distinct devices has never run on hardware here; the RCCL code path
+ * itself (communicators, broadcast, send / recv gather) runs in the tests on one card against a stand-in library (MIUNET_RCCL_LIB,
+ * MIUNET_GROUP_RCCL=2: tests/cpu/fake_rccl.cpp). */
 typedef struct mi_unet_group mi_unet_group_t;
 #define MI_UNET_GATHER_HOST 0
 #define MI_UNET_GATHER_XGMI 1

@@ -326,6 +326,30 @@ def test_k_split_kernel_in_the_whole_network(algo, monkeypatch):
     assert np.array_equal(out["0"][0][safe], out["2"][0][safe])
 
 
+@pytest.mark.parametrize("algo", ["bf16", "fp16"])
+def test_tail_micro_batch_takes_other_kernels_and_gives_the_same_bits(algo, monkeypatch):
+    """Kernel routing depends on the grid, hence on the micro-batch size: with max_batch = 2 a batch of three runs its third image
+    alone, and at 512 x 512 several layers then fall under a routing threshold (e.g. the 128-channel level: 256 tiles fill the
+    wide kernel's grid at two images, 128 do not).  The kernel families are bit-identical by construction, so the image must come
+    out the same bit for bit whether it ran alone or as the first of a pair.  (The K-split 128 -> 64 kernel differs from the 2 x 2
+    kernel by one fp32 add: switched off here; at the bench sizes its routing does not depend on the batch.)"""
+    monkeypatch.setenv("MIUNET_LPRK", "0")
+    spec = UNetSpec(1, 64, 3, 3)
+    blob = pack_weights(spec, synth.make_weights(spec, 8))
+    imgs = synth.make_images(3, 512, 512, 1, 0x7A11, "blobs")
+    with binding.Engine(512, 512, 1, 64, 3, 3, max_batch=2, conv_algo=algo) as eng:
+        eng.load_weights(blob)
+        eng.set_profiling(True)
+        lab3, lg3 = eng.infer(imgs, want_logits=True)                  # micro-batches of 2 and 1
+        used3 = [(s["name"], s["kernel"]) for s in eng.kernel_stats()]
+        eng.set_profiling(False)
+        lab2, lg2 = eng.infer(imgs[[2, 0]], want_logits=True)          # the same image as the first of a pair
+    n = len(used3) // 2
+    pair, alone = dict(used3[:n]), dict(used3[n:])
+    assert set(pair) == set(alone) and any(pair[k] != alone[k] for k in pair), "the tail micro-batch was expected to route differently"
+    assert np.array_equal(lg3[2], lg2[0]) and np.array_equal(lab3[2], lab2[0])
+
+
 # ---------------------------------------------------------------- the large transposed convolutions with resident weights (convt_lpr.hip)
 @pytest.mark.parametrize("op,B,H,W,Cin,Cout", [
     ("convT2x2_bf16", 1, 8, 32, 64, 32),        # exactly one 8 x 32 tile: wave = tap x half of the row blocks
