@@ -2,8 +2,9 @@
 // bf16 or fp16 operands, fp32 accumulation on v_mfma_f32_32x32x16_{bf16,f16}; gfx950 only.
 //
 // Why a second kernel.  conv_mfma_bf16 (conv_lp.hip) gives a wave 2 x 2 blocks of 32 x 32: every MFMA needs one fresh 1 KB
-// fragment from LDS (2 A + 2 B reads per 4 MFMAs).  At 32 cycles per MFMA and four SIMDs that is 256 B/clk per CU against the
-// LDS's 128 B/clk: the matrix pipe cannot be more than 50 % busy, and the counters say exactly that on the deep layers
+// fragment from LDS (2 A + 2 B reads per 4 MFMAs).  At 32 cycles per MFMA and four SIMDs that is 256 B/clk per CU = ALL of the
+// LDS's read rate (round 2 took the rate for 128 B/clk; it is 256 conflict-free, MI355X_MICROARCH.md): with the stores of the
+// staging beside them the matrix pipe cannot be much more than 50 % busy, and the counters say exactly that on the deep layers
 // (SQ_VALU_MFMA_BUSY_CYCLES: 0.44 of the cycles at 2.4 GHz = about half of the cycles at the clock this instruction stream
 // actually holds; a register-only loop of the same MFMA sustains 1.89 PFLOP/s at 1.80 GHz on this card,
 // tools/dev/mfma_clock_probe.hip).  Here a wave owns 4 image rows x 128 output channels = 4 x 4 blocks: 4 A + 4 B reads per
@@ -19,8 +20,9 @@
 // Workgroup = 4 waves = 16 rows x 32 columns of pixels x 128 output channels.  K is walked in chunks of 32 input channels:
 //   LDS: the 18 x 34 input patch of the chunk, 64 bytes per pixel, double-buffered (2 x 39,936 B); the next chunk's patch
 //        arrives by LDS-DMA (buffer_load ... lds, 16 bytes per lane: no staging registers, no ds_write), one load per group of
-//        16 MFMAs; rows cannot be padded that way, so the four 16-byte pieces of pixel p sit in slots piece ^ ((p >> 1) & 3)
-//        (conflict-free ds_read_b128; conv_lpr.hip).  ONE barrier per chunk = per 288 MFMAs of a wave.  (Register-staged
+//        16 MFMAs; rows cannot be padded that way, so the four 16-byte pieces of a pixel are permuted inside its 64 bytes
+//        for the 16-lane service groups of ds_read_b128 (lpr_common.h: lds_swz_row1 -- a fragment is one patch row x 32
+//        columns).  ONE barrier per chunk = per 288 MFMAs of a wave.  (Register-staged
 //        patches in 80-byte padded rows, the first form of this kernel, measured 0.6-0.75 % slower on config 3, same card.)
 //   per chunk and wave: 18 groups (9 taps x 2 halves) of 4 ds_read_b128 + 4 buffer_load_b128 + 16 MFMAs; the patch fragments
 //        are read one group ahead, the weight fragments three.
@@ -31,6 +33,7 @@
 #include <type_traits>
 
 #include "kernel_common.h"
+#include "lpr_common.h"
 
 namespace miunet {
 
@@ -58,7 +61,7 @@ struct LP2 {
 // measured on the layers this kernel does not take: within 3 % of the 2 x 2 kernel either way, so it does not exist.)
 template <typename T, bool OUT_LP, int WD, int NT>
 __global__ __launch_bounds__(256, 1) void conv3x3_lp2(const ConvArgs a, const int tiles_x, const int tiles_y,
-                                                                    const int m_tiles, const int nwg)
+                                                                    const int m_tiles, const int nwg, const int swz)
 {
     typedef typename Lp2Vec<T>::x8 x8;
     constexpr int ROW = LP2::ROW, PW = LP2::PW, MT = LP2::MT, BN = 32 * NT, TH = LP2::TH;
@@ -82,23 +85,28 @@ __global__ __launch_bounds__(256, 1) void conv3x3_lp2(const ConvArgs a, const in
     const T *in_img = reinterpret_cast<const T *>(a.in) + (size_t)b * a.H * a.W * a.ldc;
 
     // ---- patch loads: LDS-DMA (buffer_load ... lds, 16 bytes per lane: no staging registers, no ds_write); load i = wave + 4 k
-    // covers pixels 16 i .. + 16, lane l = (pixel l >> 2, slot l & 3), the piece in slot s of pixel p is piece s ^ ((p >> 1) & 3)
+    // covers pixels 16 i .. + 16, lane l = (pixel l >> 2, slot l & 3), the piece in slot s of the pixel in patch column c is
+    // piece s ^ lds_swz_row1(c).  Offsets are multiples of 16 bytes (ldc % 8 == 0): the two low bits carry the piece index
+    // for the partial-last-chunk test of dma_a
     typedef __attribute__((address_space(3))) void *lds_ptr;
     constexpr int DMA_ITERS = (LP2::A_LOADS + 3) / 4;
     unsigned dvoff[DMA_ITERS];
 #pragma unroll
     for (int k = 0; k < DMA_ITERS; ++k) {
         const int i = wave + 4 * k;
-        const int p = 16 * i + (lane >> 2), q = (lane & 3) ^ ((p >> 1) & 3);
+        const int p = 16 * i + (lane >> 2);
         const int py = p / PW, px = p - py * PW;
+        const int q = (lane & 3) ^ lds_swz_row1(swz, px, p);
         const int gy = y0 - 1 + py, gx = x0 - 1 + px;
         const bool inb = i < LP2::A_LOADS && p < LP2::NPIX && gy >= 0 && gy < a.H && gx >= 0 && gx < a.W;
-        dvoff[k] = inb ? (unsigned)(((gy * a.W + gx) * a.ldc + 8 * q) * 2) : 0xFFFFFFFFu;
+        dvoff[k] = inb ? ((unsigned)(((gy * a.W + gx) * a.ldc + 8 * q) * 2) | (unsigned)q) : 0xFFFFFFFFu;
     }
     const __amdgpu_buffer_rsrc_t in_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<T *>(in_img), 0, a.H * a.W * a.ldc * 2, 0x00020000);
     auto dma_a = [&](int chunk, int buf, int k) {             // this wave's k-th load of a chunk's patch
         if (wave + 4 * k < LP2::A_LOADS) {
-            const unsigned voff = (chunk * KC_BF16 + 8 * ((lane & 3) ^ ((lane >> 3) & 3)) < a.Cin) ? dvoff[k] : 0xFFFFFFFFu;      // (a partial last chunk)
+            const unsigned dv = dvoff[k];
+            // (a partial last chunk reads zeros; a dead lane stays out of range: 0xFFFFFFF0 is past every tensor)
+            const unsigned voff = (chunk * KC_BF16 + 8 * (int)(dv & 3u) < a.Cin) ? (dv & ~15u) : 0xFFFFFFFFu;
             __builtin_amdgcn_raw_ptr_buffer_load_lds(in_rsrc, (lds_ptr)(As + buf * LP2::A_ELEMS + (wave + 4 * k) * 16 * ROW), 16, voff, chunk * KC_BF16 * 2, 0, 0);
         }
     };
@@ -129,7 +137,7 @@ __global__ __launch_bounds__(256, 1) void conv3x3_lp2(const ConvArgs a, const in
 #pragma unroll
         for (int dx = 0; dx < 3; ++dx) {
             const int p = (wave * MT + r) * PW + li + dx;
-            aoff[r][dx] = (unsigned)(p * 64 + ((lh ^ ((p >> 1) & 3)) << 4));
+            aoff[r][dx] = (unsigned)(p * 64 + ((lh ^ lds_swz_row1(swz, li + dx, p)) << 4));
         }
 #pragma unroll
     for (int k = 0; k < DMA_ITERS; ++k) dma_a(0, 0, k);
@@ -293,7 +301,7 @@ static hipError_t launch_lp2_cfg(const ConvArgs &a, hipStream_t s)
     // ring depth 3: a ring of 6 groups measured the same within 1 % and spills a register
     auto kern = conv3x3_lp2<T, OUT_LP, 3, NT>;
     if (hipError_t e = ensure_dynamic_lds(kern, lds_bytes); e != hipSuccess) return e;
-    hipLaunchKernelGGL(kern, dim3(nwg), dim3(256), lds_bytes, s, a, tiles_x, tiles_y, m_tiles, nwg);
+    hipLaunchKernelGGL(kern, dim3(nwg), dim3(256), lds_bytes, s, a, tiles_x, tiles_y, m_tiles, nwg, routing_of(a).lds_swz);
     return hipGetLastError();
 }
 
@@ -304,7 +312,7 @@ bool conv3x3_lp2_takes(const ConvArgs &a)
 {
     const int mode = routing_of(a).lp2;
     if (mode == 0) return false;
-    if (a.head_w != nullptr || a.Cout % 128 != 0 || a.Cin % 8 || a.CoutPad % NPAD) return false;
+    if (a.head_w != nullptr || a.Cout % 128 != 0 || a.Cin % 8 || a.ldc % 8 || a.CoutPad % NPAD) return false;
     if (mode == 2) return true;
     const long long nwg = (long long)((a.W + 31) / 32) * ((a.H + LP2::TH - 1) / LP2::TH) * a.B * (a.Cout / 128);
     // from Cin = 128 since the 16-byte-store epilogue (same card, config 3: down1.c2 0.333 -> 0.322 ms, up3.c2 0.313 -> 0.298, down2.c1
@@ -315,7 +323,7 @@ bool conv3x3_lp2_takes(const ConvArgs &a)
 
 hipError_t launch_conv3x3_lp2(const ConvArgs &a, bool fp16, hipStream_t s)
 {
-    if (a.Cout % 128 != 0 || a.head_w != nullptr) return hipErrorInvalidValue;
+    if (a.Cout % 128 != 0 || a.head_w != nullptr || a.ldc % 8) return hipErrorInvalidValue;
     if (fp16) return a.out_lp ? launch_lp2_cfg<_Float16, true, 4>(a, s) : launch_lp2_cfg<_Float16, false, 4>(a, s);
     return a.out_lp ? launch_lp2_cfg<__bf16, true, 4>(a, s) : launch_lp2_cfg<__bf16, false, 4>(a, s);
 }

@@ -22,9 +22,9 @@ namespace miunet {
 //     filled by LDS-DMA loads (buffer_load ... lds, 16 bytes per lane, no staging registers) LEAD = NBUF - 1 tiles ahead of
 //     the MFMAs -- one to two patches (22-87 KB) in flight per CU at any time, which is what 1/256 of the HBM bandwidth
 //     needs at its latency.  An LDS-DMA load places lane l's 16 bytes at base + 16 l, so rows cannot be padded; instead
-//     the four 16-byte pieces of pixel p sit in slots piece ^ ((p >> 1) & 3): eight consecutive pixels then cover all eight
-//     16-byte bank groups whatever piece they read (conflict-free ds_read_b128), and the permutation costs nothing -- it is
-//     the per-lane global offset of the load;
+//     the four 16-byte pieces of a pixel are permuted inside its 64 bytes so that every 16-lane service group of a
+//     ds_read_b128 covers all sixteen 16-byte bank groups (lpr_common.h: lds_swz_rows2), and the permutation costs nothing --
+//     it is the per-lane global offset of the load;
 //   * an MFMA row block is 2 image rows x 16 columns (not 1 x 32): the 32x32 accumulator then holds every 2 x 2 output
 //     block in ONE lane (registers r, r+1, r+8, r+9), so the fused max pooling stays in-lane;
 //   * one barrier per tile.  A wave waits for ITS loads of tile n+1 after the MFMAs of tile n and before its stores
@@ -61,7 +61,7 @@ struct LPR {
 // run in the order of conv_mfma_bf16's fused head (four interleaved partial sums per class, folded at the end): the same
 // logits bit for bit.  `out` is never written.
 template <typename T, int CIN, int NBT, int NBUF, int RB, bool HEAD = false>
-__global__ __launch_bounds__(512, 1) void conv3x3_lpr(const ConvArgs a, const int tiles_x, const int tiles_y, const int ntiles)
+__global__ __launch_bounds__(512, 1) void conv3x3_lpr(const ConvArgs a, const int tiles_x, const int tiles_y, const int ntiles, const int swz)
 {
     typedef typename LprVec<T>::x8 x8;
     typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
@@ -107,14 +107,16 @@ __global__ __launch_bounds__(512, 1) void conv3x3_lpr(const ConvArgs a, const in
     }
 
     // ---- per-lane LDS byte offsets of the A fragments inside a plane: pixel p = row block's (row li >> 4, column li & 15)
-    // displaced by the tap; 16-byte piece q = 2 g + lh sits in slot q ^ ((p >> 1) & 3)
+    // displaced by the tap; 16-byte piece q = 2 g + lh sits in slot q ^ lds_swz_rows2(row, col) (lpr_common.h; the second
+    // row block of a wave is 8 rows down and the second column half 16 columns right: the same slots)
     unsigned aoff[9][2];
 #pragma unroll
     for (int tap = 0; tap < 9; ++tap) {
         const int dy = tap / 3, dx = tap - 3 * dy;
-        const int p = (2 * rp + (li >> 4) + dy) * GEO::PW + 16 * ch0 + (li & 15) + dx;
+        const int prow = 2 * rp + (li >> 4) + dy, pcol = 16 * ch0 + (li & 15) + dx;
+        const int p = prow * GEO::PW + pcol;
 #pragma unroll
-        for (int g = 0; g < 2; ++g) aoff[tap][g] = (unsigned)(p * 64 + (((2 * g + lh) ^ ((p >> 1) & 3)) << 4));
+        for (int g = 0; g < 2; ++g) aoff[tap][g] = (unsigned)(p * 64 + (((2 * g + lh) ^ lds_swz_rows2(swz, prow, pcol, p)) << 4));
     }
 
     // ---- per-lane global byte offsets of this wave's patch loads, relative to the patch origin (y0 - 1, x0 - 1): load i =
@@ -123,8 +125,9 @@ __global__ __launch_bounds__(512, 1) void conv3x3_lpr(const ConvArgs a, const in
 #pragma unroll
     for (int k = 0; k < DMA_ITERS; ++k) {
         const int i = wave + 8 * k, c = i / GEO::PLANE_LOADS, j = i - c * GEO::PLANE_LOADS;
-        const int p = 16 * j + (lane >> 2), q = (lane & 3) ^ ((p >> 1) & 3);
+        const int p = 16 * j + (lane >> 2);
         const int py = p / GEO::PW, px = p - py * GEO::PW;
+        const int q = (lane & 3) ^ lds_swz_rows2(swz, py, px, p);
         dvoff[k] = (i < TILE_LOADS && p < GEO::NPIX) ? (unsigned)(((py * a.W + px) * a.ldc + 32 * c + 8 * q) * 2) : 0xFFFFFFFFu;
     }
     const int my_loads = (TILE_LOADS - wave + 7) / 8;        // loads this wave issues per tile
@@ -197,8 +200,9 @@ __global__ __launch_bounds__(512, 1) void conv3x3_lpr(const ConvArgs a, const in
 #pragma unroll
             for (int k = 0; k < DMA_ITERS; ++k) {
                 const int i = wave + 8 * k, c = i / GEO::PLANE_LOADS, j = i - c * GEO::PLANE_LOADS;
-                const int p = 16 * j + (lane >> 2), q = (lane & 3) ^ ((p >> 1) & 3);
+                const int p = 16 * j + (lane >> 2);
                 const int py = p / GEO::PW, px = p - py * GEO::PW;
+                const int q = (lane & 3) ^ lds_swz_rows2(swz, py, px, p);
                 const int gy = y0 - 1 + py, gx = x0 - 1 + px;
                 const bool inb = p < GEO::NPIX && gy >= 0 && gy < a.H && gx >= 0 && gx < a.W;
                 const unsigned voff = inb ? (unsigned)(((gy * a.W + gx) * a.ldc + 32 * c + 8 * q) * 2) : 0xFFFFFFFFu;
@@ -364,7 +368,7 @@ static hipError_t launch_lpr_cfg(const ConvArgs &a, hipStream_t s)
     static_assert(lds <= 160 * 1024, "LDS of one CU");
     auto kern = conv3x3_lpr<T, CIN, NBT, NBUF, RB, HEAD>;
     if (hipError_t e = ensure_dynamic_lds(kern, lds); e != hipSuccess) return e;
-    hipLaunchKernelGGL(kern, dim3(grid), dim3(512), lds, s, a, tiles_x, tiles_y, ntiles);
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(512), lds, s, a, tiles_x, tiles_y, ntiles, routing_of(a).lds_swz);
     return hipGetLastError();
 }
 

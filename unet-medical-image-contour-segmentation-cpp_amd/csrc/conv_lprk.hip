@@ -18,7 +18,7 @@ namespace miunet {
 //   * persistent workgroup of eight waves per CU = 2 row pairs x 2 channel blocks x 2 K halves; a tile is 4 rows x 32 columns
 //     (a 128-channel patch of 6 x 34 pixels is 52 KB: a ring of two fits the CU next to the exchange buffer; 8-row tiles
 //     would need 174 KB);
-//   * LDS: 2 x 52 KB patch ring (LDS-DMA loads, pieces swizzled as in conv_lpr.hip) + 32 KB exchange + 20 KB output scratch;
+//   * LDS: 2 x 52 KB patch ring (LDS-DMA loads, pieces permuted as in conv_lpr.hip: lpr_common.h) + 32 KB exchange + 20 KB output scratch;
 //   * two barriers per tile (patch complete / partial sums published).
 // Arithmetic: the same products as conv_mfma_bf16, fp32 accumulation inside each K half in its order, then ONE extra fp32
 // add of the two halves -- (c0 + c1) + (c2 + c3) instead of ((c0 + c1) + c2) + c3: not bit-identical to the 2 x 2 kernel
@@ -40,7 +40,7 @@ struct LPRK {
 };
 
 template <typename T>
-__global__ __launch_bounds__(512, 1) void conv3x3_lprk(const ConvArgs a, const int tiles_x, const int tiles_y, const int ntiles)
+__global__ __launch_bounds__(512, 1) void conv3x3_lprk(const ConvArgs a, const int tiles_x, const int tiles_y, const int ntiles, const int swz)
 {
     typedef typename LprVec<T>::x8 x8;
     typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
@@ -75,9 +75,10 @@ __global__ __launch_bounds__(512, 1) void conv3x3_lprk(const ConvArgs a, const i
 #pragma unroll
     for (int tap = 0; tap < 9; ++tap) {
         const int dy = tap / 3, dx = tap - 3 * dy;
-        const int p = (2 * rp + (li >> 4) + dy) * LPRK::PW + (li & 15) + dx;
+        const int prow = 2 * rp + (li >> 4) + dy, pcol = (li & 15) + dx;
+        const int p = prow * LPRK::PW + pcol;
 #pragma unroll
-        for (int g = 0; g < 2; ++g) aoff[tap][g] = (unsigned)(p * 64 + (((2 * g + lh) ^ ((p >> 1) & 3)) << 4));
+        for (int g = 0; g < 2; ++g) aoff[tap][g] = (unsigned)(p * 64 + (((2 * g + lh) ^ lds_swz_rows2(swz, prow, pcol, p)) << 4));
     }
 
     // ---- per-lane global byte offsets of this wave's patch loads, relative to the patch origin (y0 - 1, x0 - 1)
@@ -85,8 +86,9 @@ __global__ __launch_bounds__(512, 1) void conv3x3_lprk(const ConvArgs a, const i
 #pragma unroll
     for (int k = 0; k < LPRK::DMA_ITERS; ++k) {
         const int i = wave + 8 * k, c = i / LPRK::PLANE_LOADS, j = i - c * LPRK::PLANE_LOADS;
-        const int p = 16 * j + (lane >> 2), q = (lane & 3) ^ ((p >> 1) & 3);
+        const int p = 16 * j + (lane >> 2);
         const int py = p / LPRK::PW, px = p - py * LPRK::PW;
+        const int q = (lane & 3) ^ lds_swz_rows2(swz, py, px, p);
         dvoff[k] = (i < LPRK::TILE_LOADS && p < LPRK::NPIX) ? (unsigned)(((py * a.W + px) * a.ldc + 32 * c + 8 * q) * 2) : 0xFFFFFFFFu;
     }
 
@@ -129,8 +131,9 @@ __global__ __launch_bounds__(512, 1) void conv3x3_lprk(const ConvArgs a, const i
 #pragma unroll
             for (int k = 0; k < LPRK::DMA_ITERS; ++k) {
                 const int i = wave + 8 * k, c = i / LPRK::PLANE_LOADS, j = i - c * LPRK::PLANE_LOADS;
-                const int p = 16 * j + (lane >> 2), q = (lane & 3) ^ ((p >> 1) & 3);
+                const int p = 16 * j + (lane >> 2);
                 const int py = p / LPRK::PW, px = p - py * LPRK::PW;
+                const int q = (lane & 3) ^ lds_swz_rows2(swz, py, px, p);
                 const int gy = y0 - 1 + py, gx = x0 - 1 + px;
                 const bool inb = p < LPRK::NPIX && gy >= 0 && gy < a.H && gx >= 0 && gx < a.W;
                 const unsigned voff = inb ? (unsigned)(((gy * a.W + gx) * a.ldc + 32 * c + 8 * q) * 2) : 0xFFFFFFFFu;
@@ -246,7 +249,7 @@ static hipError_t launch_lprk(const ConvArgs &a, hipStream_t s)
     static_assert(LPRK::LDS_BYTES <= 160 * 1024, "LDS of one CU");
     auto kern = conv3x3_lprk<T>;
     if (hipError_t e = ensure_dynamic_lds(kern, LPRK::LDS_BYTES); e != hipSuccess) return e;
-    hipLaunchKernelGGL(kern, dim3(grid), dim3(512), LPRK::LDS_BYTES, s, a, tiles_x, tiles_y, ntiles);
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(512), LPRK::LDS_BYTES, s, a, tiles_x, tiles_y, ntiles, routing_of(a).lds_swz);
     return hipGetLastError();
 }
 

@@ -17,7 +17,7 @@ namespace miunet {
 //     32-pixel row blocks (Cin <= 128: all Cout / 32 channel blocks of the tap) or half of the tap's channels (Cin = 256):
 //     Cin / 16 x NBW B-fragments = 16, 64 or 128 weight registers, loaded once;
 //   * LDS holds only input tiles: 32 KB each (256, 128 or 64 pixels x Cin), a ring of three filled by LDS-DMA loads two
-//     tiles ahead, pieces swizzled as in conv_lpr.hip (slot = piece ^ ((pixel >> 1) & 3): conflict-free ds_read_b128);
+//     tiles ahead, pieces permuted inside a pixel's 64 bytes for the 16-lane service groups of ds_read_b128 (lpr_common.h: lds_swz_row1);
 //   * a row block's accumulators (NBW x 16 registers) are rounded once and leave through a wave-private LDS tile as 16-byte
 //     stores: every output pixel of the tap gets its 64 or 128 contiguous bytes in one piece;
 //   * one barrier per tile, waits counted as in conv_lpr.hip (a wave waits for ITS loads of tile n + 1 after the MFMAs of
@@ -27,7 +27,7 @@ namespace miunet {
 //
 // CIN = 64 / 128 / 256, NBW = 32-channel blocks per wave, COSPLIT = waves w >> 2 split the tap's channels (else its row blocks)
 template <typename T, int CIN, int NBW, bool COSPLIT>
-__global__ __launch_bounds__(512, 1) void convT2x2_lpr(const ConvArgs a, const int tiles_x, const int tiles_y, const int ntiles)
+__global__ __launch_bounds__(512, 1) void convT2x2_lpr(const ConvArgs a, const int tiles_x, const int tiles_y, const int ntiles, const int swz)
 {
     typedef typename LprVec<T>::x8 x8;
     typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
@@ -67,17 +67,18 @@ __global__ __launch_bounds__(512, 1) void convT2x2_lpr(const ConvArgs a, const i
             wreg[ks][j] = *reinterpret_cast<const x8 *>(wpk + ((size_t)(ks >> 1) * a.CoutPad + (size_t)kidx * a.Cout + co) * KC_BF16 + 16 * (ks & 1) + 8 * lh);
     }
 
-    // ---- A fragments: pixel p = 32 mb + li of the tile, piece q = 2 g + lh in slot q ^ ((p >> 1) & 3) (the same for every mb)
+    // ---- A fragments: pixel p = 32 mb + li of the tile (one image row x 32 columns), piece q = 2 g + lh in slot
+    // q ^ lds_swz_row1(column li) (lpr_common.h; the same for every mb)
     unsigned aoff[2];
 #pragma unroll
-    for (int g = 0; g < 2; ++g) aoff[g] = (unsigned)(li * 64 + (((2 * g + lh) ^ ((li >> 1) & 3)) << 4));
+    for (int g = 0; g < 2; ++g) aoff[g] = (unsigned)(li * 64 + (((2 * g + lh) ^ lds_swz_row1(swz, li, li)) << 4));
 
     // ---- this wave's four patch loads: load i = wave + 8 k = pixels 16 (i % PLANE_LOADS) .. + 16 of plane i / PLANE_LOADS
     unsigned dvoff[4];
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
         const int i = wave + 8 * k, c = i / PLANE_LOADS, j = i - c * PLANE_LOADS;
-        const int p = 16 * j + (lane >> 2), q = (lane & 3) ^ ((p >> 1) & 3);
+        const int p = 16 * j + (lane >> 2), q = (lane & 3) ^ lds_swz_row1(swz, p & 31, p);
         dvoff[k] = (unsigned)((((p >> 5) * a.W + (p & 31)) * a.ldc + 32 * c + 8 * q) * 2);
     }
 
@@ -189,7 +190,7 @@ static hipError_t launch_convt_lpr_cfg(const ConvArgs &a, hipStream_t s)
     static_assert(lds <= 160 * 1024, "LDS of one CU");
     auto kern = convT2x2_lpr<T, CIN, NBW, COSPLIT>;
     if (hipError_t e = ensure_dynamic_lds(kern, lds); e != hipSuccess) return e;
-    hipLaunchKernelGGL(kern, dim3(grid), dim3(512), lds, s, a, tiles_x, tiles_y, ntiles);
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(512), lds, s, a, tiles_x, tiles_y, ntiles, routing_of(a).lds_swz);
     return hipGetLastError();
 }
 
