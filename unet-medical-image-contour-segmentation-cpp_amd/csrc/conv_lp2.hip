@@ -289,6 +289,285 @@ __global__ __launch_bounds__(256, 1) void conv3x3_lp2(const ConvArgs a, const in
     }
 }
 
+// --------------------------------------------------------------------------------------------------------------------
+// The same tile on v_mfma_f32_16x16x32_{bf16,f16} (conv3x3_lp2s).  Under dense 16-bit MFMA work the chip holds its clock
+// down (1.7-1.9 GHz on these layers against 2.4 nominal: `clock_ghz_from_sq_busy` of the bench), so cycles saved by a
+// tighter issue stream come back only partly as wall time, while the MFMA SHAPE is a lever of its own: at equal cycles per
+// FLOP the 16x16x32 form holds a higher clock (MI355X_MICROARCH.md, 'DVFS give-back' item 7: 1.12-1.15 x the FLOP/s of the
+// 32x32x16 form on random data).  Same workgroup, same LDS patch ring, same weight ring; what changes:
+//   * a wave's 4 rows x 32 columns x 128 channels are 8 x 8 blocks of 16 pixels x 16 channels (4 accumulator registers
+//     each: the same 256); block m = (row r = m >> 1, column half h = m & 1);
+//   * one MFMA contracts a tap's whole 32-channel chunk: lane (i = lane & 15, kq = lane >> 4) supplies the pixel's / the
+//     output channel's 8 input channels 8 kq .. + 8 -- piece kq of the pixel's 64 bytes, one ds_read_b128 / buffer load;
+//   * a group is (tap, channel half): 4 weight fragments x the tap's 8 patch fragments = 32 MFMAs of 16 cycles (the same 512
+//     cycles as a group of the 32x32x16 form); the patch fragments are refilled one by one right after their last use in
+//     the tap's second group (28 MFMAs ahead of their next use), the weight ring is the same three groups deep;
+//   * LDS piece slots: q ^ 2 ((col >> 2) & 1) -- a 16-lane service group of this read holds columns {0-3, 12-15} with one
+//     piece index and {4-11} with the next (tools/dev/lds_bank_model.py).
+// Arithmetic: the same products; the fp32 sum of a tap's 32 channels is formed inside ONE instruction instead of two
+// chained ones, so results differ from the 32x32x16 kernels by fp32 re-association (not bit-identical to conv_mfma_bf16;
+// pinned to the rounded-operand oracle at 1e-4 and, in situ, to one 16-bit ulp).
+// In-place accumulation through inline asm: the builtin's 4-register destination is not tied to its accumulator operand
+// (only the wider MFMAs get the tied form), and with all 256 accumulator registers live hipcc then rotates the accumulators
+// through other registers -- copies through VGPRs at the loop head and spills inside the K loop.  "+a" pins each block to
+// its own AGPR quad.  Hazards: no accumulator is touched again for 32 MFMAs inside the loop, and a barrier separates the
+// last MFMA from the epilogue's first accumulator read.
+__device__ __forceinline__ void mfma_lp2s(f32x4 &c, Lp2Vec<__bf16>::x8 a, Lp2Vec<__bf16>::x8 b)
+{
+    asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+a"(c) : "v"(a), "v"(b));
+}
+__device__ __forceinline__ void mfma_lp2s(f32x4 &c, Lp2Vec<_Float16>::x8 a, Lp2Vec<_Float16>::x8 b)
+{
+    asm volatile("v_mfma_f32_16x16x32_f16 %0, %1, %2, %0" : "+a"(c) : "v"(a), "v"(b));
+}
+__device__ __forceinline__ int lds_swz_row16(int col) { return 2 * ((col >> 2) & 1); }
+
+template <typename T, bool OUT_LP>
+__global__ __launch_bounds__(256, 1) void conv3x3_lp2s(const ConvArgs a, const int tiles_x, const int tiles_y,
+                                                       const int m_tiles, const int nwg)
+{
+    typedef typename Lp2Vec<T>::x8 x8;
+    constexpr int ROW = LP2::ROW, PW = LP2::PW, MT = LP2::MT, BN = 128, TH = LP2::TH;
+    constexpr int MB = 2 * MT, NB = BN / 16, WD = 3;         // 8 pixel blocks x 8 channel blocks per wave; weight ring depth in groups
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    T *const As = reinterpret_cast<T *>(lds);                // [2][NPIX][ROW]
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int i16 = lane & 15, kq = lane >> 4;
+
+    const int L = xcd_remap(blockIdx.x, nwg);
+    const int n_tile = L / m_tiles;
+    int m = L - n_tile * m_tiles;
+    const int tx = m % tiles_x; m /= tiles_x;
+    const int ty = m % tiles_y;
+    const int b = m / tiles_y;
+    const int x0 = tx * 32, y0 = ty * TH, n0 = n_tile * BN;
+    const T *in_img = reinterpret_cast<const T *>(a.in) + (size_t)b * a.H * a.W * a.ldc;
+
+    // ---- patch loads by LDS-DMA, as in conv3x3_lp2 (the two low bits of an offset carry the piece index)
+    typedef __attribute__((address_space(3))) void *lds_ptr;
+    constexpr int DMA_ITERS = (LP2::A_LOADS + 3) / 4;
+    unsigned dvoff[DMA_ITERS];
+#pragma unroll
+    for (int k = 0; k < DMA_ITERS; ++k) {
+        const int i = wave + 4 * k;
+        const int p = 16 * i + (lane >> 2);
+        const int py = p / PW, px = p - py * PW;
+        const int q = (lane & 3) ^ lds_swz_row16(px);
+        const int gy = y0 - 1 + py, gx = x0 - 1 + px;
+        const bool inb = i < LP2::A_LOADS && p < LP2::NPIX && gy >= 0 && gy < a.H && gx >= 0 && gx < a.W;
+        dvoff[k] = inb ? ((unsigned)(((gy * a.W + gx) * a.ldc + 8 * q) * 2) | (unsigned)q) : 0xFFFFFFFFu;
+    }
+    const __amdgpu_buffer_rsrc_t in_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<T *>(in_img), 0, a.H * a.W * a.ldc * 2, 0x00020000);
+    auto dma_a = [&](int chunk, int buf, int k) {
+        if (wave + 4 * k < LP2::A_LOADS) {
+            const unsigned dv = dvoff[k];
+            const unsigned voff = (chunk * KC_BF16 + 8 * (int)(dv & 3u) < a.Cin) ? (dv & ~15u) : 0xFFFFFFFFu;
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(in_rsrc, (lds_ptr)(As + buf * LP2::A_ELEMS + (wave + 4 * k) * 16 * ROW), 16, voff, chunk * KC_BF16 * 2, 0, 0);
+        }
+    };
+
+    // ---- weight fragments straight from global memory: packed [chunk][tap][CoutPad][32]; lane (i16, kq) of channel block j
+    // wants input channels 8 kq .. + 8 of output channel n0 + 16 j + i16
+    const int nchunks = (a.Cin + KC_BF16 - 1) / KC_BF16;
+    const unsigned tap_bytes = (unsigned)a.CoutPad * KC_BF16 * 2;
+    const __amdgpu_buffer_rsrc_t w_rsrc =
+        __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(a.wpk), 0, (int)((size_t)nchunks * 9 * tap_bytes), 0x00020000);
+    const unsigned w_voff = (unsigned)(((n0 + i16) * KC_BF16 + 8 * kq) * 2);
+    auto w_load = [&](int chunk, int grp, int jj) {          // grp = 2 tap + channel half; jj = block inside the half
+        return __builtin_bit_cast(x8, __builtin_amdgcn_raw_buffer_load_b128(w_rsrc, w_voff + (unsigned)((4 * (grp & 1) + jj) * 16 * KC_BF16 * 2),
+                                                                             (unsigned)(chunk * 9 + (grp >> 1)) * tap_bytes, 0));
+    };
+
+    f32x4 acc[MB][NB];
+#pragma unroll
+    for (int i = 0; i < MB; ++i)
+#pragma unroll
+        for (int j = 0; j < NB; ++j) acc[i][j] = f32x4{ 0.f, 0.f, 0.f, 0.f };
+
+    unsigned aoff[6][3];                          // byte offset of piece kq of pixel (4 wave + r) * 34 + i16 + dx (column half 1: + 1024)
+#pragma unroll
+    for (int r = 0; r < 6; ++r)
+#pragma unroll
+        for (int dx = 0; dx < 3; ++dx) {
+            const int p = (wave * MT + r) * PW + i16 + dx;
+            aoff[r][dx] = (unsigned)(p * 64 + ((kq ^ lds_swz_row16(i16 + dx)) << 4));
+        }
+#pragma unroll
+    for (int k = 0; k < DMA_ITERS; ++k) dma_a(0, 0, k);
+    x8 wf[WD][4];
+#pragma unroll
+    for (int k = 0; k < WD; ++k)
+#pragma unroll
+        for (int jj = 0; jj < 4; ++jj) wf[k][jj] = w_load(0, k, jj);
+    __builtin_amdgcn_s_waitcnt(0x0F70 | ((WD * 4) & 15) | (((WD * 4) >> 4) << 14));        // the patch is older than the ring
+    __syncthreads();
+    for (int chunk = 0; chunk < nchunks; ++chunk) {
+        const int abuf = chunk & 1;
+        const bool more = chunk + 1 < nchunks;
+        const int nxt = more ? chunk + 1 : chunk;                          // the last chunk prefetches itself: straight-line code
+        const unsigned abase = (unsigned)(abuf * LP2::A_ELEMS * 2);
+        auto read_a = [&](int tap, int mb) {      // patch fragment of block mb = (row mb >> 1, column half mb & 1) for a tap
+            const int dy = tap / 3, dx = tap - 3 * dy;
+            return *reinterpret_cast<const x8 *>(reinterpret_cast<const char *>(As) + (abase + aoff[(mb >> 1) + dy][dx]) + (mb & 1) * 1024);
+        };
+        x8 af[MB];
+#pragma unroll
+        for (int mb = 0; mb < MB; ++mb) af[mb] = read_a(0, mb);
+#pragma unroll
+        for (int g = 0; g < 18; ++g) {
+            const int tap = g >> 1, jh = g & 1;
+            if (more && g < DMA_ITERS) dma_a(chunk + 1, abuf ^ 1, g);      // the next patch, one load per group
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int mb = 0; mb < MB; ++mb) {
+#pragma unroll
+                for (int jj = 0; jj < 4; ++jj) mfma_lp2s(acc[mb][4 * jh + jj], af[mb], wf[g % WD][jj]);
+                if (jh == 1 && tap + 1 < 9) {     // last use of this fragment in the tap: refill it for the next one
+                    af[mb] = read_a(tap + 1, mb);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            }
+            const int gn = g + WD;                // refill the ring slot three groups ahead (into the next chunk at the end)
+#pragma unroll
+            for (int jj = 0; jj < 4; ++jj) wf[g % WD][jj] = w_load(gn < 18 ? chunk : nxt, gn % 18, jj);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        __builtin_amdgcn_s_waitcnt(0x0F70 | ((WD * 4) & 15) | (((WD * 4) >> 4) << 14));    // this wave's patch loads have landed
+        __syncthreads();
+    }
+
+    // ---- epilogue: + shift, ReLU, (16-bit rounding), stores.  Lane = channel i16 of block j; register r of block (row, h) =
+    // pixel column 16 h + 4 kq + r of image row y0 + 4 wave + row.
+    typedef typename std::conditional<OUT_LP, T, float>::type OutT;
+    constexpr unsigned ES = sizeof(OutT);
+    const __amdgpu_buffer_rsrc_t out_rsrc = __builtin_amdgcn_make_buffer_rsrc(
+        reinterpret_cast<OutT *>(a.out) + (size_t)b * a.H * a.W * a.ldo, 0, (int)((size_t)a.H * a.W * a.ldo * ES), 0x00020000);
+    const bool do_pool = a.pool_out != nullptr;
+    const int Hp = a.H >> 1, Wp = a.W >> 1;
+    const __amdgpu_buffer_rsrc_t pool_rsrc = __builtin_amdgcn_make_buffer_rsrc(
+        do_pool ? reinterpret_cast<OutT *>(a.pool_out) + (size_t)b * Hp * Wp * a.pool_ld : reinterpret_cast<OutT *>(a.out), 0,
+        do_pool ? (int)((size_t)Hp * Wp * a.pool_ld * ES) : 0, 0x00020000);
+    const float relu_lo = a.relu ? 0.f : -3.402823466e+38f;
+    const int yw = y0 + wave * MT;
+    const bool interior = x0 + 32 <= a.W && y0 + TH <= a.H;
+    float shj[NB];                                // loaded BEFORE the first store (conv3x3_lp2)
+#pragma unroll
+    for (int j = 0; j < NB; ++j) shj[j] = n0 + 16 * j + i16 < a.Cout ? a.bias[n0 + 16 * j + i16] : 0.f;
+    if constexpr (OUT_LP) {
+        if (a.Cout % 8 == 0 && a.ldo % 8 == 0 && a.co_off % 8 == 0 && (!do_pool || a.pool_ld % 8 == 0)) {
+            // 16-bit outputs leave through a wave-private LDS tile of 32 pixels x 32 channels as 16-byte pieces (conv3x3_lp2)
+            typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+            constexpr int TROW = 40;
+            T *const Ts = As + wave * (48 * TROW);       // [32 pixels][TROW] + pooled [16][TROW], wave-private
+            T *const Ps = Ts + 32 * TROW;
+            auto lds_epilogue = [&](auto interior_tag) {
+            constexpr bool INTERIOR = decltype(interior_tag)::value;
+#pragma unroll
+            for (int jp = 0; jp < NB / 2; ++jp) {         // 32 channels = blocks 2 jp, 2 jp + 1
+#pragma unroll
+                for (int i = 0; i < MT; ++i) {
+#pragma unroll
+                    for (int h = 0; h < 2; ++h)
+#pragma unroll
+                        for (int jl = 0; jl < 2; ++jl)
+#pragma unroll
+                            for (int r = 0; r < 4; ++r)
+                                Ts[(16 * h + 4 * kq + r) * TROW + 16 * jl + i16] = (T)fmaxf(acc[2 * i + h][2 * jp + jl][r] + shj[2 * jp + jl], relu_lo);
+                    if (do_pool && (i & 1)) {     // rows i - 1 and i, column pairs (r, r + 1): pooled column 8 h + 2 kq + (r >> 1)
+#pragma unroll
+                        for (int h = 0; h < 2; ++h)
+#pragma unroll
+                            for (int jl = 0; jl < 2; ++jl)
+#pragma unroll
+                                for (int r = 0; r < 4; r += 2) {
+                                    const f32x4 &u = acc[2 * (i - 1) + h][2 * jp + jl], &v = acc[2 * i + h][2 * jp + jl];
+                                    const float mx = fmaxf(fmaxf(u[r], u[r + 1]), fmaxf(v[r], v[r + 1]));
+                                    Ps[(8 * h + 2 * kq + (r >> 1)) * TROW + 16 * jl + i16] = (T)fmaxf(mx + shj[2 * jp + jl], relu_lo);
+                                }
+                    }
+#pragma unroll
+                    for (int it = 0; it < 2; ++it) {
+                        const int e = lane + 64 * it, m = e >> 2, q = e & 3;
+                        const u32x4 v = *reinterpret_cast<const u32x4 *>(Ts + m * TROW + 8 * q);
+                        const bool ok = INTERIOR || (yw + i < a.H && x0 + m < a.W);
+                        __builtin_amdgcn_raw_buffer_store_b128(v, out_rsrc,
+                            ok ? (unsigned)((((yw + i) * a.W + x0 + m) * a.ldo + a.co_off + n0 + 32 * jp + 8 * q) * 2) : 0xFFFFFFFFu, 0, 0);
+                        wide_store_guard();
+                    }
+                    if (do_pool && (i & 1)) {
+                        const int m = lane >> 2, q = lane & 3;              // 16 pooled pixels x 4 pieces = 64 lanes
+                        const u32x4 v = *reinterpret_cast<const u32x4 *>(Ps + m * TROW + 8 * q);
+                        const bool ok = INTERIOR || (yw + i < a.H && x0 + 2 * m + 1 < a.W);
+                        __builtin_amdgcn_raw_buffer_store_b128(v, pool_rsrc,
+                            ok ? (unsigned)(((((yw + i) >> 1) * Wp + (x0 >> 1) + m) * a.pool_ld + n0 + 32 * jp + 8 * q) * 2) : 0xFFFFFFFFu, 0, 0);
+                        wide_store_guard();
+                    }
+                }
+            }
+            };
+            if (interior) lds_epilogue(std::true_type{});
+            else lds_epilogue(std::false_type{});
+            return;
+        }
+    }
+    // fp32 outputs (the layer in front of an unfused head) and unaligned channel offsets: element stores
+    auto store_out = [&](const __amdgpu_buffer_rsrc_t &rs, float v, unsigned voff, unsigned soff) {
+        if constexpr (OUT_LP) {
+            const T t = (T)v;
+            __builtin_amdgcn_raw_buffer_store_b16(__builtin_bit_cast(unsigned short, t), rs, voff, soff, 0);
+        } else {
+            __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), rs, voff, soff, 0);
+        }
+    };
+    const unsigned pix_bytes = (unsigned)a.ldo * ES, ppix_bytes = (unsigned)a.pool_ld * ES;
+#pragma unroll
+    for (int j = 0; j < NB; ++j) {
+        const int co = n0 + 16 * j + i16;
+        const bool n_ok = co < a.Cout;
+        const float sh = shj[j];
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const int xc = x0 + 16 * h + 4 * kq;  // first of this lane's four columns
+            const unsigned vbase = n_ok ? (unsigned)(((yw * a.W + xc) * a.ldo + a.co_off + co) * ES) : 0xFFFFFFFFu;
+            if (do_pool) {
+                const unsigned pbase = n_ok ? (unsigned)((((yw >> 1) * Wp + (xc >> 1)) * a.pool_ld + co) * ES) : 0xFFFFFFFFu;
+#pragma unroll
+                for (int ip = 0; ip < MT / 2; ++ip)
+#pragma unroll
+                    for (int r = 0; r < 4; r += 2) {
+                        const f32x4 &u = acc[4 * ip + h][j], &v = acc[4 * ip + 2 + h][j];
+                        const float mx = fmaxf(fmaxf(fmaxf(u[r], u[r + 1]), fmaxf(v[r], v[r + 1])) + sh, relu_lo);
+                        const bool ok = interior || (yw + 2 * ip + 1 < a.H && xc + r + 1 < a.W);
+                        store_out(pool_rsrc, mx, ok ? pbase : 0xFFFFFFFFu, (unsigned)(ip * Wp + (r >> 1)) * ppix_bytes);
+                    }
+            }
+#pragma unroll
+            for (int i = 0; i < MT; ++i)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const float v = fmaxf(acc[2 * i + h][j][r] + sh, relu_lo);
+                    const bool ok = interior || (yw + i < a.H && xc + r < a.W);
+                    store_out(out_rsrc, v, ok ? vbase : 0xFFFFFFFFu, (unsigned)(i * a.W + r) * pix_bytes);
+                }
+        }
+    }
+}
+
+template <typename T, bool OUT_LP>
+static hipError_t launch_lp2s_cfg(const ConvArgs &a, hipStream_t s)
+{
+    const int tiles_x = (a.W + 31) / 32, tiles_y = (a.H + LP2::TH - 1) / LP2::TH;
+    const int m_tiles = tiles_x * tiles_y * a.B;
+    const int nwg = m_tiles * ((a.Cout + 127) / 128);
+    auto kern = conv3x3_lp2s<T, OUT_LP>;
+    if (hipError_t e = ensure_dynamic_lds(kern, LP2::LDS_BYTES); e != hipSuccess) return e;
+    hipLaunchKernelGGL(kern, dim3(nwg), dim3(256), LP2::LDS_BYTES, s, a, tiles_x, tiles_y, m_tiles, nwg);
+    return hipGetLastError();
+}
+
 template <typename T, bool OUT_LP, int NT>
 static hipError_t launch_lp2_cfg(const ConvArgs &a, hipStream_t s)
 {
@@ -324,6 +603,10 @@ bool conv3x3_lp2_takes(const ConvArgs &a)
 hipError_t launch_conv3x3_lp2(const ConvArgs &a, bool fp16, hipStream_t s)
 {
     if (a.Cout % 128 != 0 || a.head_w != nullptr || a.ldc % 8) return hipErrorInvalidValue;
+    if (routing_of(a).lp2_shape == 16) {          // the 16x16x32 form (conv3x3_lp2s)
+        if (fp16) return a.out_lp ? launch_lp2s_cfg<_Float16, true>(a, s) : launch_lp2s_cfg<_Float16, false>(a, s);
+        return a.out_lp ? launch_lp2s_cfg<__bf16, true>(a, s) : launch_lp2s_cfg<__bf16, false>(a, s);
+    }
     if (fp16) return a.out_lp ? launch_lp2_cfg<_Float16, true, 4>(a, s) : launch_lp2_cfg<_Float16, false, 4>(a, s);
     return a.out_lp ? launch_lp2_cfg<__bf16, true, 4>(a, s) : launch_lp2_cfg<__bf16, false, 4>(a, s);
 }
