@@ -51,3 +51,37 @@ def test_resident_weight_kernels_do_not_spill(tmp_path):
         text = asm.read_text()
         assert text.count(".amdhsa_kernel ") >= kernels
         assert "scratch_" not in text, [l for l in text.splitlines() if "scratch_" in l][:5]
+
+
+LP_SOURCES = ("conv_lp.hip", "conv_lp2.hip", "conv_lpr.hip", "conv_lprk.hip", "convt_lpr.hip")
+
+
+@pytest.mark.skipif(not os.path.exists(HIPCC), reason="hipcc not installed")
+@pytest.mark.parametrize("src", LP_SOURCES)
+def test_inline_asm_mfmas_have_their_wait_states(src, tmp_path):
+    """The 16-bit kernels issue v_mfma_f32_16x16x32 through inline asm (in-place accumulation: csrc/lpr_common.h), and hipcc pads
+    nothing around an asm: between such an MFMA and any other access to its destination there must be 12 wait states in the
+    instruction stream itself (mfma16_drain), and no VALU may write one of its operands within two states in front of it
+    (the chains start from the literal 0, not from a v_mov).  tools/dev/scan_mfma_hazard.py walks the assembly of every
+    instantiation; the accumulate chain (the next MFMA taking the destination whole as its C) is exempt."""
+    import scan_mfma_hazard
+    asm = tmp_path / (src + ".s")
+    subprocess.run([HIPCC, "-O3", "-std=c++17", "--offload-arch=gfx950", "-S", "--cuda-device-only", "-o", str(asm),
+                    os.path.join(CSRC, src)], check=True, capture_output=True, timeout=600)
+    text = asm.read_text()
+    assert text.count("v_mfma_f32_16x16x32") > 100 and "v_mfma_f32_32x32x16" not in text       # one MFMA shape in the 16-bit kernels
+    hits = scan_mfma_hazard.scan(str(asm))
+    assert hits == [], "\n".join(hits[:10])
+
+
+def test_mfma_scanner_sees_both_hazards(tmp_path):
+    import scan_mfma_hazard
+    s = tmp_path / "h.s"
+    s.write_text("\tv_mov_b32_e32 v4, 0\n\tv_mfma_f32_16x16x32_bf16 v[4:7], v[8:11], v[12:15], v[4:7]\n"
+                 "\tv_mfma_f32_16x16x32_bf16 v[4:7], v[8:11], v[12:15], v[4:7]\n\ts_nop 3\n\tv_add_f32_e32 v0, v5, v1\n\ts_endpgm\n")
+    hits = scan_mfma_hazard.scan(str(s))
+    assert any("v_add_f32" in h for h in hits) and any("v_mov_b32" in h for h in hits)
+    ok = tmp_path / "ok.s"
+    ok.write_text("\tv_mfma_f32_16x16x32_bf16 v[4:7], v[8:11], v[12:15], 0\n\tv_mfma_f32_16x16x32_bf16 v[4:7], v[8:11], v[12:15], v[4:7]\n"
+                  "\ts_nop 7\n\ts_nop 7\n\tv_add_f32_e32 v0, v5, v1\n\ts_endpgm\n")
+    assert scan_mfma_hazard.scan(str(ok)) == []

@@ -147,10 +147,12 @@ def test_config5_fp16_1024_three_channels_five_levels():
     ("conv3x3_bf16", 1, 8, 8, 256, 256),        # a deep-layer shape: two n-tiles, eight chunks, a tile mostly past the image
     ("conv3x3_fp16", 1, 32, 64, 32, 128),       # several tiles, a single chunk
     ("conv3x3_fp16", 1, 5, 7, 96, 384),         # three n-tiles
+    ("conv3x3_bf16", 1, 40, 70, 128, 128),      # interior and edge tiles, four chunks, fused pooling
 ])
 def test_conv3x3_wide_kernel(op, B, H, W, Cin, Cout):
-    """Same products, same fp32 accumulation order (taps in raster order, 16 channels per MFMA, chunks in order) as the 2 x 2
-    kernel: pinned to the rounded-operand oracle at 1e-4 AND bit-identical to that kernel, 16-bit outputs included."""
+    """Same products, same fp32 accumulation chain (chunks of 32 channels in order, taps in raster order, one v_mfma_f32_16x16x32 per
+    tap and chunk) as the 2 x 2 kernel: pinned to the rounded-operand oracle at 1e-4 AND bit-identical to that kernel, 16-bit
+    outputs and the fused 2 x 2 pooling included."""
     r = np.random.default_rng(B + 3 * H + 5 * W + Cin + Cout)
     x = r.standard_normal((B, H, W, Cin), dtype=np.float32)
     w = (r.standard_normal((Cout, Cin, 3, 3), dtype=np.float32) * np.sqrt(2.0 / (9 * Cin))).astype(np.float32)
@@ -166,39 +168,7 @@ def test_conv3x3_wide_kernel(op, B, H, W, Cin, Cout):
     got16 = binding.layer_debug(op + "w_lpout", x, w, scale, shift, relu=True)
     assert np.array_equal(got16, binding.layer_debug(op + "_lpout", x, w, scale, shift, relu=True))
     assert np.array_equal(got16, rnd(got))                    # the stored 16-bit tensor = one rounding of the fp32 result
-
-
-@pytest.mark.parametrize("op,B,H,W,Cin,Cout", [
-    ("conv3x3_bf16", 2, 16, 32, 64, 128),       # exactly one tile per image, two chunks
-    ("conv3x3_bf16", 1, 21, 45, 40, 128),       # ragged in x and y, Cin % 32 != 0 (masked last chunk)
-    ("conv3x3_bf16", 1, 8, 8, 256, 256),        # two n-tiles, eight chunks, a tile mostly past the image
-    ("conv3x3_fp16", 1, 32, 64, 32, 128),       # several tiles, a single chunk
-    ("conv3x3_fp16", 1, 5, 7, 96, 384),         # three n-tiles
-    ("conv3x3_bf16", 1, 40, 70, 128, 128),      # interior and edge tiles, four chunks
-])
-def test_conv3x3_wide_kernel_16x16x32(op, B, H, W, Cin, Cout, monkeypatch):
-    """The wide kernel on v_mfma_f32_16x16x32 (conv3x3_lp2s, MIUNET_LP2_SHAPE=16): the same products, a tap's 32 channels summed
-    inside one instruction -- pinned to the rounded-operand oracle at 1e-4, equal to the 32x32x16 form up to fp32 re-association,
-    and its 16-bit output = one rounding of its own fp32 result."""
-    r = np.random.default_rng(B + 3 * H + 5 * W + Cin + Cout)
-    x = r.standard_normal((B, H, W, Cin), dtype=np.float32)
-    w = (r.standard_normal((Cout, Cin, 3, 3), dtype=np.float32) * np.sqrt(2.0 / (9 * Cin))).astype(np.float32)
-    scale = (1.0 + 0.1 * r.standard_normal(Cout)).astype(np.float32)
-    shift = (0.1 * r.standard_normal(Cout)).astype(np.float32)
-    rnd = orc.bf16_round if op.endswith("bf16") else orc.fp16_round
-    monkeypatch.setenv("MIUNET_LP2_SHAPE", "32")
-    got32 = binding.layer_debug(op + "w", x, w, scale, shift, relu=True)
-    monkeypatch.setenv("MIUNET_LP2_SHAPE", "16")
-    got = binding.layer_debug(op + "w", x, w, scale, shift, relu=True)
-    wf = (w.astype(np.float64) * scale.astype(np.float64)[:, None, None, None]).astype(np.float32)
-    ref = np.maximum(orc.conv3x3(rnd(x), rnd(wf)) + shift, 0.0)
-    bar = 1e-4 * max(1.0, float(np.abs(ref).max()))
-    assert not np.isnan(got).any(), "unwritten (NaN-poisoned) outputs"
-    assert np.max(np.abs(got - ref)) < bar
-    assert np.max(np.abs(got - got32)) < bar
-    got16 = binding.layer_debug(op + "w_lpout", x, w, scale, shift, relu=True)
-    assert np.array_equal(got16, rnd(got))                    # the stored 16-bit tensor = one rounding of the fp32 result
-    if H % 2 == 0 and W % 2 == 0:                             # the fused 2 x 2 max pooling of the same tile
+    if H % 2 == 0 and W % 2 == 0:
         pooled = binding.layer_debug(op + "w_pool_lpout", x, w, scale, shift, relu=True)
         assert np.array_equal(pooled, orc.maxpool2x2(got16))
 

@@ -77,3 +77,20 @@ def test_cli_command_handling_without_an_engine(tmp_path):
     # log dir derived as <dir of engine>/../log (src/main.cpp:87) and the banner + error lines are in the log
     log = (tmp_path / "engine" / ".." / "log" / "segmentation_log.txt").read_text()
     assert "=== Initializing Medical Image Segmentation Engine ===" in log and "not found" in log
+
+
+def test_lds_layouts_of_the_16bit_kernels_are_conflict_free():
+    """tools/dev/lds_bank_model.py: gfx950 services a ds_read_b128 in four groups of 16 lanes over 64 banks; the piece permutation of
+    csrc/lpr_common.h (lds_swz_row16) must put every fragment read of the 16-bit kernels at 4 LDS cycles, for every patch row,
+    column half and tap displacement -- and the model must still see the 2-way conflict of the round-2 layout it replaced (the
+    counters of profiles/r03_ab_lds_swizzle.txt agree with both)."""
+    sys.path.insert(0, os.path.join(ROOT, "tools", "dev"))
+    import lds_bank_model as m
+    for name, fn in m.SHIPPED_16BIT.items():
+        mean, worst = fn()
+        assert mean == 4.0 and worst == 4, (name, mean, worst)
+    assert m.round2_frag32_rows2() == (8.0, 8) and m.round2_frag32_row1() == (8.0, 8)
+    # the kernels' permutation is the model's: one source line each
+    src = open(os.path.join(ROOT, "unet-medical-image-contour-segmentation-cpp_amd", "csrc", "lpr_common.h")).read()
+    assert "lds_swz_row16(int col) { return 2 * ((col >> 2) & 1); }" in src
+    assert all(m.swz_row16(c) == 2 * ((c >> 2) & 1) for c in range(64))

@@ -7,8 +7,11 @@ addresses broadcast; every extra distinct address on a busy bank adds a cycle.  
 banks, so a group is conflict-free iff its pieces fall into distinct 16-byte bank groups: (byte address / 16) mod 16.
 
 `cycles(addr_of_lane)` returns the LDS cycles of one wave-instruction (4 = conflict-free).  The functions below restate the
-address arithmetic of each kernel's fragment reads (file:line given) and enumerate every (wave role, tap, k half).
-Run as a script for the table; tests/test_tools_cpu.py asserts that the shipped layouts are conflict-free."""
+address arithmetic of each kernel's fragment reads and enumerate every (row, column half, tap displacement).  Round 3
+checked the model against the hardware: with the round-2 layout rocprofv3 counted SQ_LDS_BANK_CONFLICT = 0.45-0.47 of
+SQ_LDS_IDX_ACTIVE on these kernels (the model: every read 8 cycles instead of 4), with a conflict-free layout 0.04-0.11
+(profiles/r03_ab_lds_swizzle.txt).  Run as a script for the table; tests/test_tools_cpu.py asserts that the shipped 16-bit
+layouts are conflict-free."""
 
 _G0 = list(range(0, 4)) + list(range(12, 16)) + list(range(20, 28))
 _G1 = list(range(4, 12)) + list(range(16, 20)) + list(range(28, 32))
@@ -28,13 +31,13 @@ def cycles(addr_of_lane):
     return total
 
 
-# ---- the two piece permutations of csrc/lpr_common.h (mode 1) and the round-2 form (mode 0)
-def swz_rows2(mode, row, col, pixel):
-    return 2 * (row & 1) + ((col >> 2) & 1) if mode else (pixel >> 1) & 3
+# ---- the piece permutation of csrc/lpr_common.h, and the round-2 form it replaced
+def swz_row16(col):
+    return 2 * ((col >> 2) & 1)
 
 
-def swz_row1(mode, col, pixel):
-    return (col >> 2) & 3 if mode else (pixel >> 1) & 3
+def swz_round2(pixel):
+    return (pixel >> 1) & 3
 
 
 def _mean(values):
@@ -42,25 +45,50 @@ def _mean(values):
     return sum(values) / len(values), max(values)
 
 
-def conv_lpr(mode, pw=34):
-    """csrc/conv_lpr.hip `aoff` (and conv_lprk.hip): lane = (row li >> 4, column li & 15, k half lh), patch rows of 34 pixels."""
+def frag16_patch(pw=34, rows=18):
+    """The 16x16x32 patch fragment of conv_lpr.hip / conv_lprk.hip / conv_lp2.hip (`aoff`): lane = (column i16 = lane & 15 of
+    ONE patch row, piece kq = lane >> 4), unpadded 64-byte pixels, patch rows of `pw` pixels; both column halves."""
     out = []
-    for rp in range(4):
-        for ch0 in range(2):
-            for tap in range(9):
-                dy, dx = divmod(tap, 3)
-                for g in range(2):
-                    def addr(lane):
-                        li, lh = lane & 31, lane >> 5
-                        row, col = 2 * rp + (li >> 4) + dy, 16 * ch0 + (li & 15) + dx
-                        p = row * pw + col
-                        return p * 64 + (((2 * g + lh) ^ swz_rows2(mode, row, col, p)) << 4)
-                    out.append(cycles(addr))
+    for row in range(rows):
+        for h in range(2):
+            for dx in range(3):
+                def addr(lane):
+                    i16, kq = lane & 15, lane >> 4
+                    col = 16 * h + i16 + dx
+                    return (row * pw + col) * 64 + ((kq ^ swz_row16(col)) << 4)
+                out.append(cycles(addr))
     return _mean(out)
 
 
-def conv_lp2(mode, pw=34):
-    """csrc/conv_lp2.hip `aoff`: lane = (column li of one patch row, k half lh)."""
+def frag16_rows64():
+    """conv_lp.hip `a_frag` / `b_frag` and convt_lpr.hip `aoff`: 64-byte rows (pixels / weight rows), lane = (row i16, piece kq)."""
+    out = []
+    for dx in range(3):
+        def addr(lane):
+            i16, kq = lane & 15, lane >> 4
+            return (i16 + dx) * 64 + ((kq ^ swz_row16(i16 + dx)) << 4)
+        out.append(cycles(addr))
+    return _mean(out)
+
+
+def round2_frag32_rows2(pw=34):
+    """Round 2: 32x32x16 fragments of two patch rows x 16 columns (lane = (row li >> 4, column li & 15, k half lh)), slot =
+    piece ^ ((pixel >> 1) & 3) -- conv_lpr / conv_lprk until round 3."""
+    out = []
+    for rp in range(4):
+        for tap in range(9):
+            dy, dx = divmod(tap, 3)
+            for g in range(2):
+                def addr(lane):
+                    li, lh = lane & 31, lane >> 5
+                    p = (2 * rp + (li >> 4) + dy) * pw + (li & 15) + dx
+                    return p * 64 + (((2 * g + lh) ^ swz_round2(p)) << 4)
+                out.append(cycles(addr))
+    return _mean(out)
+
+
+def round2_frag32_row1(pw=34):
+    """Round 2: 32x32x16 fragments of one patch row x 32 columns (conv_lp2, convT_lpr until round 3)."""
     out = []
     for row in range(18):
         for dx in range(3):
@@ -68,52 +96,36 @@ def conv_lp2(mode, pw=34):
                 def addr(lane):
                     li, lh = lane & 31, lane >> 5
                     p = row * pw + li + dx
-                    return (p * 64 + ((lh ^ swz_row1(mode, li + dx, p)) << 4)) ^ (32 if g else 0)
+                    return p * 64 + (((2 * g + lh) ^ swz_round2(p)) << 4)
                 out.append(cycles(addr))
     return _mean(out)
 
 
-def convt_lpr(mode):
-    """csrc/convt_lpr.hip `aoff`: lane = (pixel li of a 32-pixel row block, k half lh); no halo."""
-    out = []
-    for g in range(2):
-        def addr(lane):
-            li, lh = lane & 31, lane >> 5
-            return li * 64 + (((2 * g + lh) ^ swz_row1(mode, li, li)) << 4)
-        out.append(cycles(addr))
-    return _mean(out)
-
-
-def conv_lp_rows80():
-    """csrc/conv_lp.hip `a_frag` / `b_frag`: 80-byte padded rows, lane = (pixel li, k half lh)."""
-    out = []
-    for dx in range(3):
-        for g in range(2):
-            def addr(lane):
-                li, lh = lane & 31, lane >> 5
-                return (li + dx) * 80 + 16 * lh + 32 * g
-            out.append(cycles(addr))
-    return _mean(out)
-
-
 def wino4_v(vrow_floats=20):
-    """csrc/conv_wino4.hip / conv_wino4s.hip `v_rd`: lane = (tile j16 = lane & 15, channel quad kq = lane >> 4), rows of VROW floats."""
+    """csrc/conv_wino4.hip / conv_wino4s.hip `v_rd` (fp32, v_mfma_f32_16x16x4_f32): lane = (tile j16 = lane & 15, channel quad
+    kq = lane >> 4), rows of VROW floats.  2-way conflicted under the real grouping; these kernels spend 12-25 % of their time
+    with the LDS array busy, so the layout was left alone."""
     def addr(lane):
         return (lane & 15) * vrow_floats * 4 + 16 * (lane >> 4)
     return _mean([cycles(addr)])
 
 
+SHIPPED_16BIT = {
+    "conv3x3_lpr / lprk / lp2 patch fragments (16x16x32: one row x 16 columns, piece in the lane)": frag16_patch,
+    "conv_mfma_bf16 patch and weight fragments, convT2x2_lpr fragments (64-byte rows)": frag16_rows64,
+}
+
+
 def report():
-    rows = [
-        ("conv3x3_lpr / lprk A fragments (2 rows x 16 columns)", conv_lpr(0), conv_lpr(1)),
-        ("conv3x3_lp2 A fragments (1 row x 32 columns)", conv_lp2(0), conv_lp2(1)),
-        ("convT2x2_lpr A fragments", convt_lpr(0), convt_lpr(1)),
-        ("conv_mfma_bf16 fragments (80-byte rows)", conv_lp_rows80(), conv_lp_rows80()),
-        ("F(4x4) V fragments (80-byte rows)", wino4_v(), wino4_v()),
-    ]
-    print(f"{'read pattern':58s} {'round-2 layout':>16s} {'shipped layout':>16s}   (LDS cycles per ds_read_b128: mean / worst; 4 = conflict-free)")
-    for name, old, new in rows:
-        print(f"{name:58s} {old[0]:9.2f} / {old[1]:<4d} {new[0]:9.2f} / {new[1]:<4d}")
+    print("LDS cycles per ds_read_b128, mean / worst (4 = conflict-free)")
+    for name, fn in SHIPPED_16BIT.items():
+        m, w = fn()
+        print(f"  shipped   {name:96s} {m:5.2f} / {w}")
+    for name, fn in (("round 2: 32x32x16 fragments of two rows x 16 columns, slot = piece ^ ((pixel >> 1) & 3)", round2_frag32_rows2),
+                     ("round 2: 32x32x16 fragments of one row x 32 columns, same slots", round2_frag32_row1),
+                     ("fp32 F(4x4) V fragments (80-byte rows; unchanged)", wino4_v)):
+        m, w = fn()
+        print(f"  reference {name:96s} {m:5.2f} / {w}")
 
 
 if __name__ == "__main__":

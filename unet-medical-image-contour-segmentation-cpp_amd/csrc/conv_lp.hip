@@ -3,33 +3,29 @@
 #include <type_traits>
 
 #include "kernel_common.h"
+#include "lpr_common.h"
 
 namespace miunet {
 
 // --------------------------------------------------------------------------------------------------------------------
 // conv_mfma_bf16 -- the same implicit GEMM with bf16 operands and fp32 accumulation (BASELINE config 3).
 // Layout and schedule are those of conv_mfma_f32; what changes:
-//   * a K-chunk is 32 channels; LDS rows hold 32 bf16 + 8 pad = 80 bytes (the same conflict-free stride);
+//   * a K-chunk is 32 channels = ONE v_mfma_f32_16x16x32 per tap (lpr_common.h: the shape the chip clocks highest under dense
+//     16-bit MFMA work); LDS rows are 64 bytes, unpadded, the four 16-byte pieces of a row permuted for the 16-lane service
+//     groups of ds_read_b128 (lds_swz_row16: a group reads rows {0-3, 12-15} with one piece index and {4-11} with the next);
 //   * activations are 16-bit in HBM as well (every tensor but the network's last conv output, which feeds the fp32 head):
 //     the producing kernel rounds its fp32 result once (round-to-nearest-even) instead of every consumer rounding it while
 //     staging -- the same values (rounding commutes with max pooling and is idempotent across the skip connections), half the
 //     HBM and L2 traffic, no conversion VALU in the loader: one 16-byte load and one 16-byte ds_write per 8 channels;
 //   * epilogue: buffer stores on a per-image descriptor (one per-lane byte offset per output-row group, pixel displacement
 //     in the scalar offset) -- 64-bit address arithmetic per store was most of the kernel's instructions at small K;
-//   * v_mfma_f32_32x32x16_bf16 takes A[i][8h + j], j = 0..7 from lane (i, h): exactly one ds_read_b128 per operand per
-//     MFMA, natural k order, 32 cycles per instruction (16x the fp32 rate) -- the kernel is bound by its staging and LDS
-//     traffic and by HBM, not by the matrix pipe.
+//   * lane (i16 = lane & 15, kq = lane >> 4) supplies A[i16][8 kq .. + 8] and B[8 kq .. + 8][i16]: one ds_read_b128 per
+//     fragment, 8 fragment reads per 16 MFMAs of 16 cycles; the fragments of tap t + 1 are requested before the MFMAs of tap t
+//     (the MFMAs are volatile asms: the software pipeline is written out) -- the kernel is bound by its staging and LDS traffic
+//     and by HBM, not by the matrix pipe.
 // The same kernel serves fp16 operands (BASELINE config 5's arithmetic): T = __bf16 or _Float16, 16 bits either way.
 template <typename T> struct LpVec { typedef T x8 __attribute__((ext_vector_type(8))); };
 
-__device__ __forceinline__ f32x16 mfma_lp(LpVec<__bf16>::x8 a, LpVec<__bf16>::x8 b, f32x16 c)
-{
-    return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
-}
-__device__ __forceinline__ f32x16 mfma_lp(LpVec<_Float16>::x8 a, LpVec<_Float16>::x8 b, f32x16 c)
-{
-    return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0);
-}
 
 // OUT_LP: the output tensor (and the pooled one) is 16-bit like the input; false = fp32 output (the layer in front of the head)
 // HEAD: the layer feeds the network's fp32 1x1 head + argmax (ConvArgs::head_w): the post-ReLU fp32 tile crosses LDS instead
@@ -40,13 +36,14 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_bf16(const ConvArgs a, const
 {
     typedef typename LpVec<T>::x8 bf16x8;
     static_assert(BN == 32 || BN % 64 == 0, "n-tile of 32 (narrow layers: base 32) or a multiple of 64 output channels");
-    constexpr int ROW = KC_BF16 + 8;                     // bf16 elements per LDS row (80 bytes)
+    constexpr int ROW = KC_BF16;                         // 16-bit elements per LDS row (64 bytes, pieces permuted)
     constexpr int HEAD_ROW = BN + 4;                     // floats per pixel of the fused head's LDS tile
     constexpr int HALO = (TAPS == 9) ? 1 : 0;
     constexpr int PW = 32 + 2 * HALO, PH = TH + 2 * HALO, NPIX = PW * PH;
     constexpr int NA8 = NPIX * (KC_BF16 / 8);            // 8-channel pieces of the A patch
     constexpr int A_ITERS = (NA8 + 255) / 256;
-    constexpr int MT = TH / 4, NT = BN / 32;
+    constexpr int MT = TH / 4;
+    constexpr int MB16 = 2 * MT, NB16 = BN / 16;         // a wave's blocks of 16 pixels (row i = m >> 1, column half h = m & 1) x 16 channels
     constexpr int B_PARTS = BN >= 64 ? BN / 64 : 1;      // 64 rows x 64 bytes = 4 KB = 256 threads x 16 bytes (BN = 32: half of them)
     constexpr int B_ITERS = TAPS * B_PARTS;
     extern __shared__ __attribute__((aligned(16))) float lds[];
@@ -56,7 +53,7 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_bf16(const ConvArgs a, const
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int li = lane & 31, lh = lane >> 5;
+    const int i16 = lane & 15, kq = lane >> 4;
 
     const int L = xcd_remap(blockIdx.x, nwg);
     const int n_tiles = nwg / m_tiles;
@@ -79,12 +76,12 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_bf16(const ConvArgs a, const
         const bool live = e < NA8;
         const bool inb = live && gy >= 0 && gy < a.H && gx >= 0 && gx < a.W;
         a_goff[s] = inb ? (gy * a.W + gx) * a.ldc + 8 * q : -1;
-        a_loff[s] = live ? pix * ROW + 8 * q : -1;
+        a_loff[s] = live ? pix * ROW + 8 * (q ^ lds_swz_row16(px)) : -1;
     }
     const int bq = tid & 3, bn = tid >> 2;               // 16-byte piece (8 bf16) / cout row inside a 64-cout slab
     const bool b_live = BN >= 64 || bn < BN;             // BN = 32: rows 32..63 of the slab belong to nobody
     const T *w_base = wpk + ((size_t)n0 + bn) * KC_BF16 + 8 * bq;
-    const int b_loff = bn * ROW + 8 * bq;
+    const int b_loff = bn * ROW + 8 * (bq ^ lds_swz_row16(bn));
 
     bf16x8 a_reg[A_ITERS];
     bf16x8 b_reg[B_ITERS];
@@ -116,16 +113,27 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_bf16(const ConvArgs a, const
         }
     };
 
-    f32x16 acc[MT][NT];
+    f32x4 acc[MB16][NB16];
 #pragma unroll
-    for (int i = 0; i < MT; ++i)
+    for (int m = 0; m < MB16; ++m)
 #pragma unroll
-        for (int j = 0; j < NT; ++j)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+        for (int j = 0; j < NB16; ++j) acc[m][j] = f32x4{ 0.f, 0.f, 0.f, 0.f };      // (a staging round and a barrier ahead of the first MFMA)
 
-    const T *a_frag = As + ((wave * MT) * PW + li) * ROW + 8 * lh;
-    const T *b_frag = Bs + li * ROW + 8 * lh;
+    // fragment addresses: patch pixel (row wave MT + i + dy, column 16 h + i16 + dx), piece kq; weight row tap BN + 16 j + i16
+    int a_off[3];
+#pragma unroll
+    for (int dx = 0; dx < 3; ++dx) a_off[dx] = (i16 + dx) * ROW + 8 * (kq ^ lds_swz_row16(i16 + dx));
+    const T *const a_frag = As + (wave * MT) * PW * ROW;
+    const T *const b_frag = Bs + i16 * ROW + 8 * (kq ^ lds_swz_row16(i16));
+    auto read_tap = [&](const int tap, bf16x8 (&af)[MB16], bf16x8 (&bf)[NB16]) {
+        const int dy = (TAPS == 9) ? tap / 3 : 0, dx = (TAPS == 9) ? tap % 3 : 0;
+#pragma unroll
+        for (int m = 0; m < MB16; ++m)
+            af[m] = *reinterpret_cast<const bf16x8 *>(a_frag + (((m >> 1) + dy) * PW + 16 * (m & 1)) * ROW + a_off[dx]);
+#pragma unroll
+        for (int j = 0; j < NB16; ++j)
+            bf[j] = *reinterpret_cast<const bf16x8 *>(b_frag + (tap * BN + 16 * j) * ROW);
+    };
     const int nchunks = (a.Cin + KC_BF16 - 1) / KC_BF16;
     load_chunk(0);
     store_chunk();
@@ -133,24 +141,15 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_bf16(const ConvArgs a, const
     for (int chunk = 0; chunk < nchunks; ++chunk) {
         const bool more = chunk + 1 < nchunks;
         if (more) load_chunk(chunk + 1);
+        bf16x8 af[2][MB16], bf[2][NB16];
+        read_tap(0, af[0], bf[0]);
 #pragma unroll
         for (int tap = 0; tap < TAPS; ++tap) {
-            const int dy = (TAPS == 9) ? tap / 3 : 0, dx = (TAPS == 9) ? tap % 3 : 0;
+            if (tap + 1 < TAPS) read_tap(tap + 1, af[(tap + 1) & 1], bf[(tap + 1) & 1]);
 #pragma unroll
-            for (int g = 0; g < KC_BF16 / 16; ++g) {
-                bf16x8 af[MT], bf[NT];
+            for (int m = 0; m < MB16; ++m)
 #pragma unroll
-                for (int i = 0; i < MT; ++i)
-                    af[i] = *reinterpret_cast<const bf16x8 *>(a_frag + ((i + dy) * PW + dx) * ROW + 16 * g);
-#pragma unroll
-                for (int j = 0; j < NT; ++j)
-                    bf[j] = *reinterpret_cast<const bf16x8 *>(b_frag + (tap * BN + 32 * j) * ROW + 16 * g);
-#pragma unroll
-                for (int i = 0; i < MT; ++i)
-#pragma unroll
-                    for (int j = 0; j < NT; ++j)
-                        acc[i][j] = mfma_lp(af[i], bf[j], acc[i][j]);
-            }
+                for (int j = 0; j < NB16; ++j) mfma16_lpr(acc[m][j], af[tap & 1][m], bf[tap & 1][j]);
         }
         __syncthreads();
         if (more) {
@@ -158,9 +157,14 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_bf16(const ConvArgs a, const
             __syncthreads();
         }
     }
+    mfma16_drain();                               // (lpr_common.h: a barrier alone does not cover the last MFMA's latency)
+#pragma unroll
+    for (int m = 0; m < MB16; ++m)
+#pragma unroll
+        for (int j = 0; j < NB16; ++j) mfma16_settled(acc[m][j]);
 
-    // ---- epilogue: + shift, ReLU, (16-bit rounding), buffer stores.  Lane = channel li of block j, register r = pixel
-    // column (r & 3) + 8 (r >> 2) + 4 lh of image row y0 + wave*MT + i.
+    // ---- epilogue: + shift, ReLU, (16-bit rounding), buffer stores.  Lane = channel i16 of the 16-channel block j; register r
+    // of pixel block (i, h) = pixel column 16 h + 4 kq + r of image row y0 + wave*MT + i.
     typedef typename std::conditional<OUT_LP, T, float>::type OutT;
     constexpr unsigned ES = sizeof(OutT);
     const int OH = (TAPS == 9) ? a.H : 2 * a.H, OW = (TAPS == 9) ? a.W : 2 * a.W;
@@ -195,18 +199,18 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_bf16(const ConvArgs a, const
     T *const Ps = Ts + TH * 32 * TROW;
     // the shifts of this lane's channels, loaded BEFORE the first store (a load issued behind stores makes hipcc wait for
     // vmcnt(0): for every store in flight)
-    float shj[NT];
+    float shj[NB16];
 #pragma unroll
-    for (int j = 0; j < NT; ++j) {
-        const int n = n0 + 32 * j + li;
+    for (int j = 0; j < NB16; ++j) {
+        const int n = n0 + 16 * j + i16;
         const bool n_ok = (TAPS == 9) ? (n < a.Cout) : (n < 4 * a.Cout);
         shj[j] = n_ok ? a.bias[(TAPS == 9) ? n : n % a.Cout] : 0.f;
     }
     auto epilogue = [&](auto lds_tag) {           // one straight-line copy per route: no per-store branches
     constexpr bool TO_LDS = decltype(lds_tag)::value;
 #pragma unroll
-    for (int j = 0; j < NT; ++j) {
-        const int n = n0 + 32 * j + li;
+    for (int j = 0; j < NB16; ++j) {
+        const int n = n0 + 16 * j + i16;
         int co, oy_off = 0, ox_off = 0;
         if (TAPS == 9) {
             co = n;
@@ -217,35 +221,39 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_bf16(const ConvArgs a, const
         }
         const bool n_ok = (TAPS == 9) ? (n < a.Cout) : (n < 4 * a.Cout);
         const float sh = shj[j];
-        // per-lane byte offset of (row yw, column x0 + 4 lh) [conv] or of its 2x2 output block's (oy_off, ox_off) pixel [convT]
-        const unsigned vbase = !n_ok ? 0xFFFFFFFFu
-            : (TAPS == 9) ? (unsigned)(((yw * a.W + x0 + 4 * lh) * a.ldo + a.co_off + co) * ES)
-                          : (unsigned)((((2 * yw + oy_off) * OW + 2 * (x0 + 4 * lh) + ox_off) * a.ldo + a.co_off + co) * ES);
-        if (do_pool) {
-            const unsigned pbase = n_ok ? (unsigned)((((yw >> 1) * Wp + ((x0 + 4 * lh) >> 1)) * a.pool_ld + co) * ES) : 0xFFFFFFFFu;
 #pragma unroll
-            for (int r = 0; r < 16; r += 2) {
-                const int xr = (r & 3) + 8 * (r >> 2);
-                const float mx = fmaxf(fmaxf(fmaxf(acc[0][j][r], acc[0][j][r + 1]), fmaxf(acc[MT - 1][j][r], acc[MT - 1][j][r + 1])) + sh, relu_lo);
-                if constexpr (TO_LDS) { Ps[(wave * 16 + ((xr + 4 * lh) >> 1)) * TROW + 32 * j + li] = (T)mx; continue; }
-                const bool ok = interior || (yw + 1 < a.H && x0 + xr + 4 * lh + 1 < a.W);
-                store_out(pool_rsrc, mx, ok ? pbase : 0xFFFFFFFFu, (xr >> 1) * ppix_bytes);
-            }
-        }
+        for (int h = 0; h < 2; ++h) {
+            const int xc = x0 + 16 * h + 4 * kq;  // first of this lane's four columns
+            // per-lane byte offset of (row yw, column xc) [conv] or of its 2x2 output block's (oy_off, ox_off) pixel [convT]
+            const unsigned vbase = !n_ok ? 0xFFFFFFFFu
+                : (TAPS == 9) ? (unsigned)(((yw * a.W + xc) * a.ldo + a.co_off + co) * ES)
+                              : (unsigned)((((2 * yw + oy_off) * OW + 2 * xc + ox_off) * a.ldo + a.co_off + co) * ES);
+            if (do_pool) {
+                const unsigned pbase = n_ok ? (unsigned)((((yw >> 1) * Wp + (xc >> 1)) * a.pool_ld + co) * ES) : 0xFFFFFFFFu;
 #pragma unroll
-        for (int i = 0; i < MT; ++i) {
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int xr = (r & 3) + 8 * (r >> 2);
-                const float v = fmaxf(acc[i][j][r] + sh, relu_lo);
-                if constexpr (HEAD) {                     // pixel (wave*MT + i, xr + 4 lh) of the TH x 32 tile, channel n
-                    lds[((wave * MT + i) * 32 + xr + 4 * lh) * HEAD_ROW + 32 * j + li] = n_ok ? v : 0.f;
-                    continue;
+                for (int r = 0; r < 4; r += 2) {
+                    const f32x4 &u = acc[h][j], &v = acc[2 * (MT - 1) + h][j];
+                    const float mx = fmaxf(fmaxf(fmaxf(u[r], u[r + 1]), fmaxf(v[r], v[r + 1])) + sh, relu_lo);
+                    if constexpr (TO_LDS) { Ps[(wave * 16 + 8 * h + 2 * kq + (r >> 1)) * TROW + 16 * j + i16] = (T)mx; continue; }
+                    const bool ok = interior || (yw + 1 < a.H && xc + r + 1 < a.W);
+                    store_out(pool_rsrc, mx, ok ? pbase : 0xFFFFFFFFu, (unsigned)(r >> 1) * ppix_bytes);
                 }
-                if constexpr (TO_LDS) { Ts[((wave * MT + i) * 32 + xr + 4 * lh) * TROW + 32 * j + li] = (T)v; continue; }
-                const bool ok = interior || (yw + i < a.H && x0 + xr + 4 * lh < a.W);
-                const unsigned soff = (TAPS == 9) ? (unsigned)(i * a.W + xr) * pix_bytes : (unsigned)(2 * i * OW + 2 * xr) * pix_bytes;
-                store_out(out_rsrc, v, ok ? vbase : 0xFFFFFFFFu, soff);
+            }
+#pragma unroll
+            for (int i = 0; i < MT; ++i) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const float v = fmaxf(acc[2 * i + h][j][r] + sh, relu_lo);
+                    const int xt = 16 * h + 4 * kq + r;       // pixel column inside the 32-wide tile
+                    if constexpr (HEAD) {                     // pixel (wave*MT + i, xt) of the TH x 32 tile, channel n
+                        lds[((wave * MT + i) * 32 + xt) * HEAD_ROW + 16 * j + i16] = n_ok ? v : 0.f;
+                        continue;
+                    }
+                    if constexpr (TO_LDS) { Ts[((wave * MT + i) * 32 + xt) * TROW + 16 * j + i16] = (T)v; continue; }
+                    const bool ok = interior || (yw + i < a.H && xc + r < a.W);
+                    const unsigned soff = (TAPS == 9) ? (unsigned)(i * a.W + r) * pix_bytes : (unsigned)(2 * i * OW + 2 * r) * pix_bytes;
+                    store_out(out_rsrc, v, ok ? vbase : 0xFFFFFFFFu, soff);
+                }
             }
         }
     }
@@ -322,7 +330,7 @@ static hipError_t launch_bf16_cfg(const ConvArgs &a, hipStream_t s)
     const int n_tiles = (n_total + BN - 1) / BN;
     const int nwg = m_tiles * n_tiles;
     constexpr int HALO = (TAPS == 9) ? 1 : 0;
-    constexpr size_t lds_stage = 2 * (size_t)(KC_BF16 + 8) * ((32 + 2 * HALO) * (TH + 2 * HALO) + TAPS * BN);
+    constexpr size_t lds_stage = 2 * (size_t)KC_BF16 * ((32 + 2 * HALO) * (TH + 2 * HALO) + TAPS * BN);
     constexpr size_t lds_head = HEAD ? sizeof(float) * (256 * (size_t)(BN + 4) + 4 * BN) : 0;     // [256 px][BN + 4] + [4 classes][BN]
     constexpr size_t lds = lds_stage > lds_head ? lds_stage : lds_head;
     auto kern = conv_mfma_bf16<T, TAPS, TH, BN, NFAST, OUT_LP, HEAD>;

@@ -1,34 +1,37 @@
-// conv_lp2.hip -- the 16-bit-operand conv3x3 for the WIDE layers (Cout a multiple of 128): a 4 x 4 register tile per wave.
-// bf16 or fp16 operands, fp32 accumulation on v_mfma_f32_32x32x16_{bf16,f16}; gfx950 only.
+// conv_lp2.hip -- the 16-bit-operand conv3x3 for the WIDE layers (Cout a multiple of 128): 128 pixels x 128 channels per wave.
+// bf16 or fp16 operands, fp32 accumulation on v_mfma_f32_16x16x32_{bf16,f16}; gfx950 only.
 //
-// Why a second kernel.  conv_mfma_bf16 (conv_lp.hip) gives a wave 2 x 2 blocks of 32 x 32: every MFMA needs one fresh 1 KB
-// fragment from LDS (2 A + 2 B reads per 4 MFMAs).  At 32 cycles per MFMA and four SIMDs that is 256 B/clk per CU = ALL of the
-// LDS's read rate (round 2 took the rate for 128 B/clk; it is 256 conflict-free, MI355X_MICROARCH.md): with the stores of the
-// staging beside them the matrix pipe cannot be much more than 50 % busy, and the counters say exactly that on the deep layers
-// (SQ_VALU_MFMA_BUSY_CYCLES: 0.44 of the cycles at 2.4 GHz = about half of the cycles at the clock this instruction stream
-// actually holds; a register-only loop of the same MFMA sustains 1.89 PFLOP/s at 1.80 GHz on this card,
-// tools/dev/mfma_clock_probe.hip).  Here a wave owns 4 image rows x 128 output channels = 4 x 4 blocks: 4 A + 4 B reads per
-// 16 MFMAs = 0.5 KB per MFMA = the LDS rate exactly, 256 accumulator registers, one wave per SIMD.
+// Why a second kernel.  conv_mfma_bf16 (conv_lp.hip) gives a wave 64 pixels x 64 channels: 8 fragment reads from LDS per 16
+// MFMAs of 16 cycles, i.e. 128 B/clk per CU of the LDS's 256 for the fragments alone, with the ds_writes of the register
+// staging beside them -- its matrix pipe is a third busy on the deep layers.  Here a wave owns 4 image rows x 32 columns x 128
+// output channels (8 x 8 blocks of 16 x 16: 256 accumulator registers, one wave per SIMD): 8 patch + 8 weight fragments per
+// 64 MFMAs, and the weights do not go through LDS at all -- all four waves of a workgroup need the same weight fragments, but
+// they are small and hot (one kernel's worth per 32 input channels: 72 KB), so every lane loads its 16-byte fragment straight
+// from L1/L2 with a buffer load whose (chunk, tap) displacement is a scalar offset -- the U ring of the fp32 Winograd kernels
+// -- three groups (96 MFMAs) ahead.  LDS carries only the input patch: 8 reads per 64 MFMAs and wave.
 //
-// Even that is the LDS rate EXACTLY, so the weights do not go through LDS at all: all four waves of a workgroup need the same
-// weight fragments, but they are small and hot (one kernel's worth per 32 input channels: 72 KB), so every lane loads its
-// 16-byte fragment straight from L1/L2 with a buffer load whose (chunk, tap, half) displacement is a scalar offset -- the U
-// ring of the fp32 Winograd kernels -- three groups (48 MFMAs) ahead.  LDS then carries only the input patch: 4 reads per 16
-// MFMAs = 0.25 KB per MFMA, half its rate; the weight loads take the other half of the operand traffic on the vector-memory
-// path (4 KB per 16 MFMAs and wave = 32 B/clk per CU of the L1's 64).
+// The MFMA shape.  Under dense 16-bit MFMA work the chip holds its clock down (1.7-1.9 GHz on these layers against 2.4
+// nominal: `clock_ghz_from_sq_busy` of the bench), so cycles saved by a tighter issue stream come back only partly as wall time
+// -- round 3 halved this kernel's LDS cycles by removing a 2-way bank conflict from every fragment read (counters:
+// SQ_LDS_BANK_CONFLICT 0.47 -> 0.08 of SQ_LDS_IDX_ACTIVE) and no layer moved by more than 1 % -- while the MFMA SHAPE is a lever
+// of its own: at equal cycles per FLOP the 16x16x32 form holds a higher clock than 32x32x16 (MI355X_MICROARCH.md, 'DVFS
+// give-back' item 7).  Same card, same tile, round 3 (profiles/r03_ab_mfma_shape.txt): every layer of this kernel 2.5-10 %
+// faster on 16x16x32, BASELINE config 3 2812 -> 3000 images/s, config 5 1840 -> 1898.  All 16-bit kernels are on that shape now.
 //
 // Workgroup = 4 waves = 16 rows x 32 columns of pixels x 128 output channels.  K is walked in chunks of 32 input channels:
 //   LDS: the 18 x 34 input patch of the chunk, 64 bytes per pixel, double-buffered (2 x 39,936 B); the next chunk's patch
-//        arrives by LDS-DMA (buffer_load ... lds, 16 bytes per lane: no staging registers, no ds_write), one load per group of
-//        16 MFMAs; rows cannot be padded that way, so the four 16-byte pieces of a pixel are permuted inside its 64 bytes
-//        for the 16-lane service groups of ds_read_b128 (lpr_common.h: lds_swz_row1 -- a fragment is one patch row x 32
-//        columns).  ONE barrier per chunk = per 288 MFMAs of a wave.  (Register-staged
-//        patches in 80-byte padded rows, the first form of this kernel, measured 0.6-0.75 % slower on config 3, same card.)
-//   per chunk and wave: 18 groups (9 taps x 2 halves) of 4 ds_read_b128 + 4 buffer_load_b128 + 16 MFMAs; the patch fragments
-//        are read one group ahead, the weight fragments three.
-// Same arithmetic as conv_mfma_bf16 (same products, fp32 accumulation in k order inside a tap, taps in raster order, chunks in
-// order), same epilogue semantics: + folded-BN shift, ReLU, one round-to-nearest-even to the 16-bit output, optional fused 2x2
-// max pooling (each wave holds rows 4w .. 4w+3: both row pairs in-lane).
+//        arrives by LDS-DMA (buffer_load ... lds, 16 bytes per lane: no staging registers, no ds_write), one load per group;
+//        rows cannot be padded that way, so the four 16-byte pieces of a pixel are permuted inside its 64 bytes for the 16-lane
+//        service groups of ds_read_b128 (lpr_common.h: lds_swz_row16).  ONE barrier per chunk = per 576 MFMAs of a wave.
+//   a wave's 4 rows x 32 columns are 8 pixel blocks m = (row m >> 1, column half m & 1), its 128 channels 8 channel blocks;
+//   one MFMA contracts a tap's whole 32-channel chunk: lane (i16 = lane & 15, kq = lane >> 4) supplies the pixel's / the output
+//        channel's input channels 8 kq .. + 8 -- piece kq of the pixel's 64 bytes, one ds_read_b128 / buffer load;
+//   a group is (tap, channel half): 4 weight fragments x the tap's 8 patch fragments = 32 MFMAs; the patch fragments are
+//        refilled one by one right after their last use in the tap's second group (28 MFMAs ahead of their next use).
+// Arithmetic: the same products and the same fp32 accumulation chain as conv_mfma_bf16 (chunks in order, taps in raster order,
+// one MFMA per tap and chunk): bit-identical results; same epilogue semantics: + folded-BN shift, ReLU, one
+// round-to-nearest-even to the 16-bit output, optional fused 2x2 max pooling (each wave holds rows 4w .. 4w+3: both row pairs
+// in-lane).
 #include <cstdlib>
 #include <type_traits>
 
@@ -39,15 +42,6 @@ namespace miunet {
 
 template <typename T> struct Lp2Vec { typedef T x8 __attribute__((ext_vector_type(8))); };
 
-__device__ __forceinline__ f32x16 mfma_lp2(Lp2Vec<__bf16>::x8 a, Lp2Vec<__bf16>::x8 b, f32x16 c)
-{
-    return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
-}
-__device__ __forceinline__ f32x16 mfma_lp2(Lp2Vec<_Float16>::x8 a, Lp2Vec<_Float16>::x8 b, f32x16 c)
-{
-    return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0);
-}
-
 struct LP2 {
     static constexpr int TH = 16, MT = 4;
     static constexpr int ROW = KC_BF16;                      // 16-bit elements per pixel (64 bytes, unpadded: pieces are swizzled)
@@ -57,261 +51,9 @@ struct LP2 {
     static constexpr size_t LDS_BYTES = 2 * 2 * (size_t)A_ELEMS;      // two patch buffers of 16-bit elements
 };
 
-// (A 4 x 2 variant -- 64 output channels, 128 accumulator registers, two workgroups per CU with one patch buffer each -- was
-// measured on the layers this kernel does not take: within 3 % of the 2 x 2 kernel either way, so it does not exist.)
-template <typename T, bool OUT_LP, int WD, int NT>
-__global__ __launch_bounds__(256, 1) void conv3x3_lp2(const ConvArgs a, const int tiles_x, const int tiles_y,
-                                                                    const int m_tiles, const int nwg, const int swz)
-{
-    typedef typename Lp2Vec<T>::x8 x8;
-    constexpr int ROW = LP2::ROW, PW = LP2::PW, MT = LP2::MT, BN = 32 * NT, TH = LP2::TH;
-    static_assert(NT == 4, "4 x 4 blocks of 32 x 32 per wave");
-    static_assert(18 % WD == 0, "ring depth must divide the group count");
-    extern __shared__ __attribute__((aligned(16))) float lds[];
-    T *const As = reinterpret_cast<T *>(lds);                // [2][NPIX][ROW]
-
-    const int tid = threadIdx.x;
-    const int lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int li = lane & 31, lh = lane >> 5;
-
-    const int L = xcd_remap(blockIdx.x, nwg);
-    const int n_tile = L / m_tiles;
-    int m = L - n_tile * m_tiles;
-    const int tx = m % tiles_x; m /= tiles_x;
-    const int ty = m % tiles_y;
-    const int b = m / tiles_y;
-    const int x0 = tx * 32, y0 = ty * TH, n0 = n_tile * BN;
-    const T *in_img = reinterpret_cast<const T *>(a.in) + (size_t)b * a.H * a.W * a.ldc;
-
-    // ---- patch loads: LDS-DMA (buffer_load ... lds, 16 bytes per lane: no staging registers, no ds_write); load i = wave + 4 k
-    // covers pixels 16 i .. + 16, lane l = (pixel l >> 2, slot l & 3), the piece in slot s of the pixel in patch column c is
-    // piece s ^ lds_swz_row1(c).  Offsets are multiples of 16 bytes (ldc % 8 == 0): the two low bits carry the piece index
-    // for the partial-last-chunk test of dma_a
-    typedef __attribute__((address_space(3))) void *lds_ptr;
-    constexpr int DMA_ITERS = (LP2::A_LOADS + 3) / 4;
-    unsigned dvoff[DMA_ITERS];
-#pragma unroll
-    for (int k = 0; k < DMA_ITERS; ++k) {
-        const int i = wave + 4 * k;
-        const int p = 16 * i + (lane >> 2);
-        const int py = p / PW, px = p - py * PW;
-        const int q = (lane & 3) ^ lds_swz_row1(swz, px, p);
-        const int gy = y0 - 1 + py, gx = x0 - 1 + px;
-        const bool inb = i < LP2::A_LOADS && p < LP2::NPIX && gy >= 0 && gy < a.H && gx >= 0 && gx < a.W;
-        dvoff[k] = inb ? ((unsigned)(((gy * a.W + gx) * a.ldc + 8 * q) * 2) | (unsigned)q) : 0xFFFFFFFFu;
-    }
-    const __amdgpu_buffer_rsrc_t in_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<T *>(in_img), 0, a.H * a.W * a.ldc * 2, 0x00020000);
-    auto dma_a = [&](int chunk, int buf, int k) {             // this wave's k-th load of a chunk's patch
-        if (wave + 4 * k < LP2::A_LOADS) {
-            const unsigned dv = dvoff[k];
-            // (a partial last chunk reads zeros; a dead lane stays out of range: 0xFFFFFFF0 is past every tensor)
-            const unsigned voff = (chunk * KC_BF16 + 8 * (int)(dv & 3u) < a.Cin) ? (dv & ~15u) : 0xFFFFFFFFu;
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(in_rsrc, (lds_ptr)(As + buf * LP2::A_ELEMS + (wave + 4 * k) * 16 * ROW), 16, voff, chunk * KC_BF16 * 2, 0, 0);
-        }
-    };
-
-    // ---- weight fragments straight from global memory: packed [chunk][tap][CoutPad][32]; lane (li, lh) of block j wants the
-    // 8 channels 16 g + 8 lh .. of output channel n0 + 32 j + li; the (chunk, tap, g) displacement is a scalar offset
-    const int nchunks = (a.Cin + KC_BF16 - 1) / KC_BF16;
-    const unsigned tap_bytes = (unsigned)a.CoutPad * KC_BF16 * 2;
-    const __amdgpu_buffer_rsrc_t w_rsrc =
-        __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(a.wpk), 0, (int)((size_t)nchunks * 9 * tap_bytes), 0x00020000);
-    const unsigned w_voff = (unsigned)(((n0 + li) * KC_BF16 + 8 * lh) * 2);
-    auto w_load = [&](int chunk, int grp, int j) {           // grp = 2 tap + g
-        return __builtin_bit_cast(x8, __builtin_amdgcn_raw_buffer_load_b128(w_rsrc, w_voff + (unsigned)(32 * j * KC_BF16 * 2),
-                                                                             (unsigned)(chunk * 9 + (grp >> 1)) * tap_bytes + (grp & 1) * 32, 0));
-    };
-
-    f32x16 acc[MT][NT];
-#pragma unroll
-    for (int i = 0; i < MT; ++i)
-#pragma unroll
-        for (int j = 0; j < NT; ++j)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-
-    unsigned aoff[6][3];                          // byte offset of piece lh (g = 0; g = 1 is ^ 32) of pixel (4 wave + r) * 34 + li + dx
-#pragma unroll
-    for (int r = 0; r < 6; ++r)
-#pragma unroll
-        for (int dx = 0; dx < 3; ++dx) {
-            const int p = (wave * MT + r) * PW + li + dx;
-            aoff[r][dx] = (unsigned)(p * 64 + ((lh ^ lds_swz_row1(swz, li + dx, p)) << 4));
-        }
-#pragma unroll
-    for (int k = 0; k < DMA_ITERS; ++k) dma_a(0, 0, k);
-    x8 wf[WD][NT];
-#pragma unroll
-    for (int k = 0; k < WD; ++k)
-#pragma unroll
-        for (int j = 0; j < NT; ++j) wf[k][j] = w_load(0, k, j);
-    __builtin_amdgcn_s_waitcnt(0x0F70 | ((WD * NT) & 15) | (((WD * NT) >> 4) << 14));      // the patch is older than the ring
-    __syncthreads();
-    for (int chunk = 0; chunk < nchunks; ++chunk) {
-        const int abuf = chunk & 1;
-        const bool more = chunk + 1 < nchunks;
-        const int nxt = more ? chunk + 1 : chunk;                          // the last chunk prefetches itself: straight-line code
-        const unsigned abase = (unsigned)(abuf * LP2::A_ELEMS * 2);
-        auto read_a = [&](int grp, x8 *af) {      // patch fragments of group grp = 2 tap + g
-            const int tap = grp >> 1, g = grp & 1, dy = tap / 3, dx = tap - 3 * dy;
-#pragma unroll
-            for (int i = 0; i < MT; ++i) af[i] = *reinterpret_cast<const x8 *>(reinterpret_cast<const char *>(As) + ((abase + aoff[i + dy][dx]) ^ (g ? 32u : 0u)));
-        };
-        x8 af[2][MT];
-        read_a(0, af[0]);
-#pragma unroll
-        for (int k = 0; k < 18; ++k) {
-            if (k + 1 < 18) read_a(k + 1, af[(k + 1) & 1]);               // one group ahead (LDS latency)
-            if (more && k < DMA_ITERS) dma_a(chunk + 1, abuf ^ 1, k);      // the next patch, one load per group
-            __builtin_amdgcn_sched_barrier(0);    // ... issued here, not sunk next to their use
-#pragma unroll
-            for (int i = 0; i < MT; ++i)
-#pragma unroll
-                for (int j = 0; j < NT; ++j) acc[i][j] = mfma_lp2(af[k & 1][i], wf[k % WD][j], acc[i][j]);
-            const int kn = k + WD;                // refill the ring slot three groups ahead (into the next chunk at the end)
-#pragma unroll
-            for (int j = 0; j < NT; ++j) wf[k % WD][j] = w_load(kn < 18 ? chunk : nxt, kn % 18, j);
-            __builtin_amdgcn_sched_barrier(0);
-        }
-        // this wave's patch loads are older than the weight ring (the youngest WD * NT loads): landed
-        __builtin_amdgcn_s_waitcnt(0x0F70 | ((WD * NT) & 15) | (((WD * NT) >> 4) << 14));
-        __syncthreads();
-    }
-
-    // ---- epilogue: + shift, ReLU, (16-bit rounding), buffer stores.  Lane = channel li of block j, register r = pixel
-    // column (r & 3) + 8 (r >> 2) + 4 lh of image row y0 + 4 wave + i.
-    typedef typename std::conditional<OUT_LP, T, float>::type OutT;
-    constexpr unsigned ES = sizeof(OutT);
-    const __amdgpu_buffer_rsrc_t out_rsrc = __builtin_amdgcn_make_buffer_rsrc(
-        reinterpret_cast<OutT *>(a.out) + (size_t)b * a.H * a.W * a.ldo, 0, (int)((size_t)a.H * a.W * a.ldo * ES), 0x00020000);
-    const bool do_pool = a.pool_out != nullptr;
-    const int Hp = a.H >> 1, Wp = a.W >> 1;
-    const __amdgpu_buffer_rsrc_t pool_rsrc = __builtin_amdgcn_make_buffer_rsrc(
-        do_pool ? reinterpret_cast<OutT *>(a.pool_out) + (size_t)b * Hp * Wp * a.pool_ld : reinterpret_cast<OutT *>(a.out), 0,
-        do_pool ? (int)((size_t)Hp * Wp * a.pool_ld * ES) : 0, 0x00020000);
-    const unsigned pix_bytes = (unsigned)a.ldo * ES, ppix_bytes = (unsigned)a.pool_ld * ES;
-    const float relu_lo = a.relu ? 0.f : -3.402823466e+38f;
-    const int yw = y0 + wave * MT;
-    auto store_out = [&](const __amdgpu_buffer_rsrc_t &rs, float v, unsigned voff, unsigned soff) {
-        if constexpr (OUT_LP) {
-            const T t = (T)v;                     // round-to-nearest-even, once, by the producer
-            __builtin_amdgcn_raw_buffer_store_b16(__builtin_bit_cast(unsigned short, t), rs, voff, soff, 0);
-        } else {
-            __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), rs, voff, soff, 0);
-        }
-    };
-    const bool interior = x0 + 32 <= a.W && y0 + TH <= a.H;
-    // the four shifts of this lane's channels, loaded BEFORE the first store: a load issued behind stores makes hipcc wait for
-    // vmcnt(0), i.e. for every store in flight (measured with s_memtime stamps: the epilogue was 14.8 k cycles of a 120 k tile)
-    float shj[NT];
-#pragma unroll
-    for (int j = 0; j < NT; ++j) shj[j] = n0 + 32 * j + li < a.Cout ? a.bias[n0 + 32 * j + li] : 0.f;
-    // 16-bit outputs leave through LDS (the patch buffers are dead: the K loop ended with a barrier): a wave drops one 32-pixel x
-    // 32-channel block at a time into its own [pixel][32 + 8 pad] tile with 2-byte writes and stores it as 16-byte pieces -- 32
-    // (+ 8 pooled) store instructions per wave and tile instead of 256 (+ 128).  Needs 16-byte aligned channel offsets.
-    if constexpr (OUT_LP) {
-        if (a.Cout % 8 == 0 && a.ldo % 8 == 0 && a.co_off % 8 == 0 && (!do_pool || a.pool_ld % 8 == 0)) {
-            typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
-            constexpr int TROW = 40;
-            T *const Ts = As + wave * (48 * TROW);       // [32 pixels][TROW] + pooled [16][TROW], wave-private
-            T *const Ps = Ts + 32 * TROW;
-            auto lds_epilogue = [&](auto interior_tag) {      // interior tiles: no per-store edge predicates (Cout % 128 == 0: no channel ones either)
-            constexpr bool INTERIOR = decltype(interior_tag)::value;
-#pragma unroll
-            for (int j = 0; j < NT; ++j) {
-                const float sh = shj[j];
-#pragma unroll
-                for (int i = 0; i < MT; ++i) {
-#pragma unroll
-                    for (int r = 0; r < 16; ++r)
-                        Ts[((r & 3) + 8 * (r >> 2) + 4 * lh) * TROW + li] = (T)fmaxf(acc[i][j][r] + sh, relu_lo);
-                    if (do_pool && (i & 1)) {     // rows i - 1 and i: the 2 x 2 blocks of (r, r + 1) of both; pooled column x >> 1
-#pragma unroll
-                        for (int r = 0; r < 16; r += 2) {
-                            const float mx = fmaxf(fmaxf(acc[i - 1][j][r], acc[i - 1][j][r + 1]), fmaxf(acc[i][j][r], acc[i][j][r + 1]));
-                            Ps[((((r & 3) + 8 * (r >> 2)) >> 1) + 2 * lh) * TROW + li] = (T)fmaxf(mx + sh, relu_lo);
-                        }
-                    }
-#pragma unroll
-                    for (int it = 0; it < 2; ++it) {
-                        const int e = lane + 64 * it, m = e >> 2, q = e & 3;
-                        const u32x4 v = *reinterpret_cast<const u32x4 *>(Ts + m * TROW + 8 * q);
-                        const bool ok = INTERIOR || (yw + i < a.H && x0 + m < a.W);
-                        __builtin_amdgcn_raw_buffer_store_b128(v, out_rsrc,
-                            ok ? (unsigned)((((yw + i) * a.W + x0 + m) * a.ldo + a.co_off + n0 + 32 * j + 8 * q) * 2) : 0xFFFFFFFFu, 0, 0);
-                        wide_store_guard();
-                    }
-                    if (do_pool && (i & 1)) {
-                        const int m = lane >> 2, q = lane & 3;              // 16 pooled pixels x 4 pieces = 64 lanes
-                        const u32x4 v = *reinterpret_cast<const u32x4 *>(Ps + m * TROW + 8 * q);
-                        const bool ok = INTERIOR || (yw + i < a.H && x0 + 2 * m + 1 < a.W);
-                        __builtin_amdgcn_raw_buffer_store_b128(v, pool_rsrc,
-                            ok ? (unsigned)(((((yw + i) >> 1) * Wp + (x0 >> 1) + m) * a.pool_ld + n0 + 32 * j + 8 * q) * 2) : 0xFFFFFFFFu, 0, 0);
-                        wide_store_guard();
-                    }
-                }
-            }
-            };
-            if (interior) lds_epilogue(std::true_type{});
-            else lds_epilogue(std::false_type{});
-            return;
-        }
-    }
-#pragma unroll
-    for (int j = 0; j < NT; ++j) {
-        const int co = n0 + 32 * j + li;
-        const bool n_ok = co < a.Cout;
-        const float sh = shj[j];
-        const unsigned vbase = n_ok ? (unsigned)(((yw * a.W + x0 + 4 * lh) * a.ldo + a.co_off + co) * ES) : 0xFFFFFFFFu;
-        if (do_pool) {
-            const unsigned pbase = n_ok ? (unsigned)((((yw >> 1) * Wp + ((x0 + 4 * lh) >> 1)) * a.pool_ld + co) * ES) : 0xFFFFFFFFu;
-#pragma unroll
-            for (int ip = 0; ip < MT / 2; ++ip)
-#pragma unroll
-                for (int r = 0; r < 16; r += 2) {
-                    const int xr = (r & 3) + 8 * (r >> 2);
-                    const float mx = fmaxf(fmaxf(fmaxf(acc[2 * ip][j][r], acc[2 * ip][j][r + 1]), fmaxf(acc[2 * ip + 1][j][r], acc[2 * ip + 1][j][r + 1])) + sh, relu_lo);
-                    const bool ok = interior || (yw + 2 * ip + 1 < a.H && x0 + xr + 4 * lh + 1 < a.W);
-                    store_out(pool_rsrc, mx, ok ? pbase : 0xFFFFFFFFu, (unsigned)(ip * Wp + (xr >> 1)) * ppix_bytes);
-                }
-        }
-#pragma unroll
-        for (int i = 0; i < MT; ++i) {
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int xr = (r & 3) + 8 * (r >> 2);
-                const float v = fmaxf(acc[i][j][r] + sh, relu_lo);
-                const bool ok = interior || (yw + i < a.H && x0 + xr + 4 * lh < a.W);
-                store_out(out_rsrc, v, ok ? vbase : 0xFFFFFFFFu, (unsigned)(i * a.W + xr) * pix_bytes);
-            }
-        }
-    }
-}
-
-// --------------------------------------------------------------------------------------------------------------------
-// The same tile on v_mfma_f32_16x16x32_{bf16,f16} (conv3x3_lp2s).  Under dense 16-bit MFMA work the chip holds its clock
-// down (1.7-1.9 GHz on these layers against 2.4 nominal: `clock_ghz_from_sq_busy` of the bench), so cycles saved by a
-// tighter issue stream come back only partly as wall time, while the MFMA SHAPE is a lever of its own: at equal cycles per
-// FLOP the 16x16x32 form holds a higher clock (MI355X_MICROARCH.md, 'DVFS give-back' item 7: 1.12-1.15 x the FLOP/s of the
-// 32x32x16 form on random data).  Same workgroup, same LDS patch ring, same weight ring; what changes:
-//   * a wave's 4 rows x 32 columns x 128 channels are 8 x 8 blocks of 16 pixels x 16 channels (4 accumulator registers
-//     each: the same 256); block m = (row r = m >> 1, column half h = m & 1);
-//   * one MFMA contracts a tap's whole 32-channel chunk: lane (i = lane & 15, kq = lane >> 4) supplies the pixel's / the
-//     output channel's 8 input channels 8 kq .. + 8 -- piece kq of the pixel's 64 bytes, one ds_read_b128 / buffer load;
-//   * a group is (tap, channel half): 4 weight fragments x the tap's 8 patch fragments = 32 MFMAs of 16 cycles (the same 512
-//     cycles as a group of the 32x32x16 form); the patch fragments are refilled one by one right after their last use in
-//     the tap's second group (28 MFMAs ahead of their next use), the weight ring is the same three groups deep;
-//   * LDS piece slots: q ^ 2 ((col >> 2) & 1) -- a 16-lane service group of this read holds columns {0-3, 12-15} with one
-//     piece index and {4-11} with the next (tools/dev/lds_bank_model.py).
-// Arithmetic: the same products; the fp32 sum of a tap's 32 channels is formed inside ONE instruction instead of two
-// chained ones, so results differ from the 32x32x16 kernels by fp32 re-association (not bit-identical to conv_mfma_bf16;
-// pinned to the rounded-operand oracle at 1e-4 and, in situ, to one 16-bit ulp).
-// In-place accumulation through inline asm: the builtin's 4-register destination is not tied to its accumulator operand
-// (only the wider MFMAs get the tied form), and with all 256 accumulator registers live hipcc then rotates the accumulators
-// through other registers -- copies through VGPRs at the loop head and spills inside the K loop.  "+a" pins each block to
-// its own AGPR quad.  Hazards: no accumulator is touched again for 32 MFMAs inside the loop, and a barrier separates the
-// last MFMA from the epilogue's first accumulator read.
+// In-place accumulation through inline asm (lpr_common.h): "+a" pins each block to its own AGPR quad.  Hazards: no accumulator
+// is touched again for 32 MFMAs inside the loop, and a wait plus a barrier separate the last MFMA from the epilogue's first
+// accumulator read.
 __device__ __forceinline__ void mfma_lp2s(f32x4 &c, Lp2Vec<__bf16>::x8 a, Lp2Vec<__bf16>::x8 b)
 {
     asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+a"(c) : "v"(a), "v"(b));
@@ -320,10 +62,9 @@ __device__ __forceinline__ void mfma_lp2s(f32x4 &c, Lp2Vec<_Float16>::x8 a, Lp2V
 {
     asm volatile("v_mfma_f32_16x16x32_f16 %0, %1, %2, %0" : "+a"(c) : "v"(a), "v"(b));
 }
-__device__ __forceinline__ int lds_swz_row16(int col) { return 2 * ((col >> 2) & 1); }
 
 template <typename T, bool OUT_LP>
-__global__ __launch_bounds__(256, 1) void conv3x3_lp2s(const ConvArgs a, const int tiles_x, const int tiles_y,
+__global__ __launch_bounds__(256, 1) void conv3x3_lp2(const ConvArgs a, const int tiles_x, const int tiles_y,
                                                        const int m_tiles, const int nwg)
 {
     typedef typename Lp2Vec<T>::x8 x8;
@@ -557,30 +298,14 @@ __global__ __launch_bounds__(256, 1) void conv3x3_lp2s(const ConvArgs a, const i
 }
 
 template <typename T, bool OUT_LP>
-static hipError_t launch_lp2s_cfg(const ConvArgs &a, hipStream_t s)
+static hipError_t launch_lp2_cfg(const ConvArgs &a, hipStream_t s)
 {
     const int tiles_x = (a.W + 31) / 32, tiles_y = (a.H + LP2::TH - 1) / LP2::TH;
     const int m_tiles = tiles_x * tiles_y * a.B;
     const int nwg = m_tiles * ((a.Cout + 127) / 128);
-    auto kern = conv3x3_lp2s<T, OUT_LP>;
+    auto kern = conv3x3_lp2<T, OUT_LP>;
     if (hipError_t e = ensure_dynamic_lds(kern, LP2::LDS_BYTES); e != hipSuccess) return e;
     hipLaunchKernelGGL(kern, dim3(nwg), dim3(256), LP2::LDS_BYTES, s, a, tiles_x, tiles_y, m_tiles, nwg);
-    return hipGetLastError();
-}
-
-template <typename T, bool OUT_LP, int NT>
-static hipError_t launch_lp2_cfg(const ConvArgs &a, hipStream_t s)
-{
-    constexpr int BN = 32 * NT;
-    constexpr size_t lds_bytes = LP2::LDS_BYTES;
-    const int tiles_x = (a.W + 31) / 32, tiles_y = (a.H + LP2::TH - 1) / LP2::TH;
-    const int m_tiles = tiles_x * tiles_y * a.B;
-    const int n_tiles = (a.Cout + BN - 1) / BN;
-    const int nwg = m_tiles * n_tiles;
-    // ring depth 3: a ring of 6 groups measured the same within 1 % and spills a register
-    auto kern = conv3x3_lp2<T, OUT_LP, 3, NT>;
-    if (hipError_t e = ensure_dynamic_lds(kern, lds_bytes); e != hipSuccess) return e;
-    hipLaunchKernelGGL(kern, dim3(nwg), dim3(256), lds_bytes, s, a, tiles_x, tiles_y, m_tiles, nwg, routing_of(a).lds_swz);
     return hipGetLastError();
 }
 
@@ -603,12 +328,8 @@ bool conv3x3_lp2_takes(const ConvArgs &a)
 hipError_t launch_conv3x3_lp2(const ConvArgs &a, bool fp16, hipStream_t s)
 {
     if (a.Cout % 128 != 0 || a.head_w != nullptr || a.ldc % 8) return hipErrorInvalidValue;
-    if (routing_of(a).lp2_shape == 16) {          // the 16x16x32 form (conv3x3_lp2s)
-        if (fp16) return a.out_lp ? launch_lp2s_cfg<_Float16, true>(a, s) : launch_lp2s_cfg<_Float16, false>(a, s);
-        return a.out_lp ? launch_lp2s_cfg<__bf16, true>(a, s) : launch_lp2s_cfg<__bf16, false>(a, s);
-    }
-    if (fp16) return a.out_lp ? launch_lp2_cfg<_Float16, true, 4>(a, s) : launch_lp2_cfg<_Float16, false, 4>(a, s);
-    return a.out_lp ? launch_lp2_cfg<__bf16, true, 4>(a, s) : launch_lp2_cfg<__bf16, false, 4>(a, s);
+    if (fp16) return a.out_lp ? launch_lp2_cfg<_Float16, true>(a, s) : launch_lp2_cfg<_Float16, false>(a, s);
+    return a.out_lp ? launch_lp2_cfg<__bf16, true>(a, s) : launch_lp2_cfg<__bf16, false>(a, s);
 }
 
 }  // namespace miunet

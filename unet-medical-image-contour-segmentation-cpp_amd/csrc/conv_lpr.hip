@@ -23,16 +23,19 @@ namespace miunet {
 //     the MFMAs -- one to two patches (22-87 KB) in flight per CU at any time, which is what 1/256 of the HBM bandwidth
 //     needs at its latency.  An LDS-DMA load places lane l's 16 bytes at base + 16 l, so rows cannot be padded; instead
 //     the four 16-byte pieces of a pixel are permuted inside its 64 bytes so that every 16-lane service group of a
-//     ds_read_b128 covers all sixteen 16-byte bank groups (lpr_common.h: lds_swz_rows2), and the permutation costs nothing --
+//     ds_read_b128 covers all sixteen 16-byte bank groups (lpr_common.h: lds_swz_row16), and the permutation costs nothing --
 //     it is the per-lane global offset of the load;
-//   * an MFMA row block is 2 image rows x 16 columns (not 1 x 32): the 32x32 accumulator then holds every 2 x 2 output
-//     block in ONE lane (registers r, r+1, r+8, r+9), so the fused max pooling stays in-lane;
+//   * the MFMA is v_mfma_f32_16x16x32 (lpr_common.h: under dense 16-bit MFMA work the chip holds a higher clock on this shape
+//     than on 32x32x16): a pixel block is one image row x 16 columns, lane (i16 = lane & 15, kq = lane >> 4) supplies the
+//     pixel's / the output channel's input channels 8 kq .. + 8 of a 32-channel plane, and holds output columns 4 kq .. + 4 of
+//     channel i16.  A wave's unit of work is still a ROW BLOCK of 2 image rows x 16 columns (two pixel blocks): every 2 x 2
+//     output block sits in ONE lane (registers r, r + 1 of both rows), so the fused max pooling stays in-lane;
 //   * one barrier per tile.  A wave waits for ITS loads of tile n+1 after the MFMAs of tile n and before its stores
 //     (vmcnt <= the loads it issued for the tiles after n+1: loads return in order, so that bound holds whatever the
 //     stores of tile n-1 do), the barrier at the head of the next tile publishes them;
 //   * outputs leave through a wave-private LDS tile as 16-byte stores (the conv_lp.hip epilogue, without its barrier).
-// Same products and the same fp32 accumulation order as conv_mfma_bf16 (chunks of 32 channels, taps in raster order, 16
-// channels per MFMA): bit-identical results (tests/test_gpu_bf16.py::test_conv3x3_resident_weights).
+// Same products and the same fp32 accumulation chain as the other 16x16x32 kernels (chunks of 32 channels in order, taps in
+// raster order, one MFMA per tap and chunk): bit-identical results (tests/test_gpu_bf16.py::test_conv3x3_resident_weights).
 // RB = row blocks (2 image rows x 16 columns each) a wave owns per tile: the tile is 8 RB rows x 32 columns.  RB = 2 halves
 // the halo re-read (18 x 34 pixels for 16 x 32 outputs: 1.20 x instead of 1.33 x), the barriers and the per-tile address
 // work per pixel, and gives a wave two independent accumulator chains; it needs a 39 KB patch per 32-channel plane, so it is
@@ -61,7 +64,7 @@ struct LPR {
 // run in the order of conv_mfma_bf16's fused head (four interleaved partial sums per class, folded at the end): the same
 // logits bit for bit.  `out` is never written.
 template <typename T, int CIN, int NBT, int NBUF, int RB, bool HEAD = false>
-__global__ __launch_bounds__(512, 1) void conv3x3_lpr(const ConvArgs a, const int tiles_x, const int tiles_y, const int ntiles, const int swz)
+__global__ __launch_bounds__(512, 1) void conv3x3_lpr(const ConvArgs a, const int tiles_x, const int tiles_y, const int ntiles)
 {
     typedef typename LprVec<T>::x8 x8;
     typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
@@ -70,7 +73,7 @@ __global__ __launch_bounds__(512, 1) void conv3x3_lpr(const ConvArgs a, const in
     static_assert(!HEAD || NBT == 1, "the fused head needs every channel of a pixel in one wave");
     static_assert(RB == 1 || CIN == 32, "two row blocks per wave: one 32-channel plane only (immediate LDS offsets, LDS size)");
     using GEO = LprGeom<RB>;
-    constexpr int PLANES = CIN / 32, KSTEPS = CIN / 16;
+    constexpr int PLANES = CIN / 32;
     constexpr bool SPLITN = CIN * NBT > 64;                   // 64 -> 64: a wave keeps ONE 32-channel block (144 weight registers) ...
     constexpr int MB = SPLITN ? 2 : 1;                        // ... for both column halves of its row pair; otherwise one row block,
     constexpr int NB = SPLITN ? 1 : NBT;                      // every channel block
@@ -83,7 +86,7 @@ __global__ __launch_bounds__(512, 1) void conv3x3_lpr(const ConvArgs a, const in
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int li = lane & 31, lh = lane >> 5;
+    const int i16 = lane & 15, kq = lane >> 4;
     const int rp = wave >> 1;                                 // row pair of the tile: image rows y0 + 2 rp, + 1
     const int ch0 = SPLITN ? 0 : (wave & 1);                  // first 16-column half
     const int blk0 = SPLITN ? (wave & 1) : 0;                 // first 32-channel block
@@ -91,32 +94,34 @@ __global__ __launch_bounds__(512, 1) void conv3x3_lpr(const ConvArgs a, const in
     T *const Ps = Ts + 32 * TROW;
     float *const Ys = reinterpret_cast<float *>(Ts);          // HEAD: [32 pixels][HEAD_ROW] fp32
 
-    // ---- the layer's weights, as MFMA B fragments: lane (li, lh) holds w[tap][16 ks + 8 lh .. + 8][32 (blk0 + j) + li]
+    // ---- the layer's weights, as MFMA B fragments: lane (i16, kq) holds w[tap][32 c + 8 kq .. + 8][32 blk0 + 16 jb + i16]
+    constexpr int NB16 = 2 * NB;                              // 16-channel blocks of this wave
     const T *const wpk = reinterpret_cast<const T *>(a.wpk);
-    x8 wreg[9][KSTEPS][NB];
-    float bias[NB];
+    x8 wreg[9][PLANES][NB16];
+    float bias[NB16];
 #pragma unroll
-    for (int j = 0; j < NB; ++j) {
-        const int n = 32 * (blk0 + j) + li;
-        bias[j] = a.bias[n];
+    for (int jb = 0; jb < NB16; ++jb) {
+        const int n = 32 * blk0 + 16 * jb + i16;
+        bias[jb] = a.bias[n];
 #pragma unroll
         for (int tap = 0; tap < 9; ++tap)
 #pragma unroll
-            for (int ks = 0; ks < KSTEPS; ++ks)
-                wreg[tap][ks][j] = *reinterpret_cast<const x8 *>(wpk + ((size_t)((ks >> 1) * 9 + tap) * a.CoutPad + n) * KC_BF16 + 16 * (ks & 1) + 8 * lh);
+            for (int c = 0; c < PLANES; ++c)
+                wreg[tap][c][jb] = *reinterpret_cast<const x8 *>(wpk + ((size_t)(c * 9 + tap) * a.CoutPad + n) * KC_BF16 + 8 * kq);
     }
 
-    // ---- per-lane LDS byte offsets of the A fragments inside a plane: pixel p = row block's (row li >> 4, column li & 15)
-    // displaced by the tap; 16-byte piece q = 2 g + lh sits in slot q ^ lds_swz_rows2(row, col) (lpr_common.h; the second
-    // row block of a wave is 8 rows down and the second column half 16 columns right: the same slots)
+    // ---- per-lane LDS byte offsets of the A fragments inside a plane: pixel (row 2 rp + mr, column 16 ch0 + i16) of the
+    // tile displaced by the tap, 16-byte piece kq in slot kq ^ lds_swz_row16(column) (lpr_common.h; the second row block of a
+    // wave is 8 rows down and the second column half 16 columns right: the same slots)
     unsigned aoff[9][2];
 #pragma unroll
     for (int tap = 0; tap < 9; ++tap) {
         const int dy = tap / 3, dx = tap - 3 * dy;
-        const int prow = 2 * rp + (li >> 4) + dy, pcol = 16 * ch0 + (li & 15) + dx;
-        const int p = prow * GEO::PW + pcol;
 #pragma unroll
-        for (int g = 0; g < 2; ++g) aoff[tap][g] = (unsigned)(p * 64 + (((2 * g + lh) ^ lds_swz_rows2(swz, prow, pcol, p)) << 4));
+        for (int mr = 0; mr < 2; ++mr) {
+            const int prow = 2 * rp + mr + dy, pcol = 16 * ch0 + i16 + dx;
+            aoff[tap][mr] = (unsigned)((prow * GEO::PW + pcol) * 64 + ((kq ^ lds_swz_row16(pcol)) << 4));
+        }
     }
 
     // ---- per-lane global byte offsets of this wave's patch loads, relative to the patch origin (y0 - 1, x0 - 1): load i =
@@ -127,7 +132,7 @@ __global__ __launch_bounds__(512, 1) void conv3x3_lpr(const ConvArgs a, const in
         const int i = wave + 8 * k, c = i / GEO::PLANE_LOADS, j = i - c * GEO::PLANE_LOADS;
         const int p = 16 * j + (lane >> 2);
         const int py = p / GEO::PW, px = p - py * GEO::PW;
-        const int q = (lane & 3) ^ lds_swz_rows2(swz, py, px, p);
+        const int q = (lane & 3) ^ lds_swz_row16(px);
         dvoff[k] = (i < TILE_LOADS && p < GEO::NPIX) ? (unsigned)(((py * a.W + px) * a.ldc + 32 * c + 8 * q) * 2) : 0xFFFFFFFFu;
     }
     const int my_loads = (TILE_LOADS - wave + 7) / 8;        // loads this wave issues per tile
@@ -202,7 +207,7 @@ __global__ __launch_bounds__(512, 1) void conv3x3_lpr(const ConvArgs a, const in
                 const int i = wave + 8 * k, c = i / GEO::PLANE_LOADS, j = i - c * GEO::PLANE_LOADS;
                 const int p = 16 * j + (lane >> 2);
                 const int py = p / GEO::PW, px = p - py * GEO::PW;
-                const int q = (lane & 3) ^ lds_swz_rows2(swz, py, px, p);
+                const int q = (lane & 3) ^ lds_swz_row16(px);
                 const int gy = y0 - 1 + py, gx = x0 - 1 + px;
                 const bool inb = p < GEO::NPIX && gy >= 0 && gy < a.H && gx >= 0 && gx < a.W;
                 const unsigned voff = inb ? (unsigned)(((gy * a.W + gx) * a.ldc + 32 * c + 8 * q) * 2) : 0xFFFFFFFFu;
@@ -230,34 +235,46 @@ __global__ __launch_bounds__(512, 1) void conv3x3_lpr(const ConvArgs a, const in
 
         // ---- tile n: 9 taps x Cin / 16 MFMAs per row block and channel block
         const unsigned base = (unsigned)((n % NBUF) * TILE_BYTES);
-        f32x16 acc[RB][MB][NB];
+        f32x4 acc[RB][MB][2][NB16];               // [row block][column half][row of the pair][16-channel block]; first written by tap 0
+        // the MFMAs are volatile asms (lpr_common.h) and LDS reads do not move across those: the software pipeline is written
+        // out -- the fragments of step t + 1 are requested before the MFMAs of step t (a step = one tap of one 32-channel plane)
+        x8 af[2][RB][MB][2];
+        auto read_step = [&](const int t, x8 (&dst)[RB][MB][2]) {
+            const int c = t / 9, tap = t - 9 * c;
+#pragma unroll
+            for (int rb = 0; rb < RB; ++rb)
+#pragma unroll
+                for (int mb = 0; mb < MB; ++mb)
+#pragma unroll
+                    for (int mr = 0; mr < 2; ++mr)
+                        dst[rb][mb][mr] = *reinterpret_cast<const x8 *>(smem + (base + aoff[tap][mr]) + c * GEO::PLANE_BYTES + rb * GEO::RB_BYTES + mb * 1024);
+        };
+        read_step(0, af[0]);
+#pragma unroll
+        for (int t = 0; t < 9 * PLANES; ++t) {
+            const int c = t / 9, tap = t - 9 * c;
+            if (t + 1 < 9 * PLANES) read_step(t + 1, af[(t + 1) & 1]);
+#pragma unroll
+            for (int rb = 0; rb < RB; ++rb)
+#pragma unroll
+                for (int mb = 0; mb < MB; ++mb)
+#pragma unroll
+                    for (int mr = 0; mr < 2; ++mr)
+#pragma unroll
+                        for (int jb = 0; jb < NB16; ++jb) {
+                            if (t == 0) mfma16_lpr_first(acc[rb][mb][mr][jb], af[t & 1][rb][mb][mr], wreg[tap][c][jb]);
+                            else mfma16_lpr(acc[rb][mb][mr][jb], af[t & 1][rb][mb][mr], wreg[tap][c][jb]);
+                        }
+        }
+        mfma16_drain();                           // (lpr_common.h: the epilogue below reads the accumulators with no barrier in between)
 #pragma unroll
         for (int rb = 0; rb < RB; ++rb)
 #pragma unroll
             for (int mb = 0; mb < MB; ++mb)
 #pragma unroll
-                for (int j = 0; j < NB; ++j)
+                for (int mr = 0; mr < 2; ++mr)
 #pragma unroll
-                    for (int r = 0; r < 16; ++r) acc[rb][mb][j][r] = 0.f;
-#pragma unroll
-        for (int c = 0; c < PLANES; ++c)
-#pragma unroll
-            for (int tap = 0; tap < 9; ++tap)
-#pragma unroll
-                for (int g = 0; g < 2; ++g) {
-                    x8 af[RB][MB];
-#pragma unroll
-                    for (int rb = 0; rb < RB; ++rb)
-#pragma unroll
-                        for (int mb = 0; mb < MB; ++mb)
-                            af[rb][mb] = *reinterpret_cast<const x8 *>(smem + (base + aoff[tap][g]) + c * GEO::PLANE_BYTES + rb * GEO::RB_BYTES + mb * 1024);
-#pragma unroll
-                    for (int rb = 0; rb < RB; ++rb)
-#pragma unroll
-                        for (int mb = 0; mb < MB; ++mb)
-#pragma unroll
-                            for (int j = 0; j < NB; ++j) acc[rb][mb][j] = mfma_lpr(af[rb][mb], wreg[tap][2 * c + g][j], acc[rb][mb][j]);
-                }
+                    for (int jb = 0; jb < NB16; ++jb) mfma16_settled(acc[rb][mb][mr][jb]);
 
         // ---- this wave's loads of tile n + 1 (older than everything it issued for tiles n + 2 .. n + LEAD)
         {
@@ -288,13 +305,16 @@ __global__ __launch_bounds__(512, 1) void conv3x3_lpr(const ConvArgs a, const in
 #pragma unroll
             for (int j = 0; j < NB; ++j) {
                 const int yb = y0 + 8 * rb;                   // first image row of this row block's group of four row pairs
-                // accumulator register r = pixel m = (r & 3) + 8 (r >> 2) + 4 lh of the row block: row m >> 4, column m & 15
+                // register r of block (row mr, 16-channel block jl of this 32-channel group) = pixel m = 16 mr + 4 kq + r of the
+                // row block (row m >> 4, column m & 15), channel 16 jl + i16
                 if constexpr (HEAD) {
 #pragma unroll
-                    for (int r = 0; r < 16; ++r) {
-                        const int m = (r & 3) + 8 * (r >> 2) + 4 * lh;
-                        Ys[m * LPR::HEAD_ROW + li] = fmaxf(acc[rb][mb][j][r] + bias[j], relu_lo);
-                    }
+                    for (int mr = 0; mr < 2; ++mr)
+#pragma unroll
+                        for (int jl = 0; jl < 2; ++jl)
+#pragma unroll
+                            for (int r = 0; r < 4; ++r)
+                                Ys[(16 * mr + 4 * kq + r) * LPR::HEAD_ROW + 16 * jl + i16] = fmaxf(acc[rb][mb][mr][2 * j + jl][r] + bias[2 * j + jl], relu_lo);
                     // lane = pixel (lanes 32..63 repeat 0..31 and store nothing); first maximum wins (src/process.cpp:158-170)
                     const int m = lane & 31;
                     f32x4 d4[3];
@@ -324,16 +344,21 @@ __global__ __launch_bounds__(512, 1) void conv3x3_lpr(const ConvArgs a, const in
                     continue;
                 }
 #pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int m = (r & 3) + 8 * (r >> 2) + 4 * lh;
-                    Ts[m * TROW + li] = (T)fmaxf(acc[rb][mb][j][r] + bias[j], relu_lo);
-                }
-                if (do_pool) {                // the 2 x 2 block of (r, r+1, r+8, r+9), r even < 8: pooled column (m & 15) >> 1
+                for (int mr = 0; mr < 2; ++mr)
 #pragma unroll
-                    for (int r = 0; r < 8; r += 2) {
-                        const float mx = fmaxf(fmaxf(acc[rb][mb][j][r], acc[rb][mb][j][r + 1]), fmaxf(acc[rb][mb][j][r + 8], acc[rb][mb][j][r + 9]));
-                        Ps[(((r & 3) >> 1) + 4 * (r >> 2) + 2 * lh) * TROW + li] = (T)fmaxf(mx + bias[j], relu_lo);
-                    }
+                    for (int jl = 0; jl < 2; ++jl)
+#pragma unroll
+                        for (int r = 0; r < 4; ++r)
+                            Ts[(16 * mr + 4 * kq + r) * TROW + 16 * jl + i16] = (T)fmaxf(acc[rb][mb][mr][2 * j + jl][r] + bias[2 * j + jl], relu_lo);
+                if (do_pool) {                // the 2 x 2 block of registers (r, r + 1) of both rows, r even: pooled column 2 kq + (r >> 1)
+#pragma unroll
+                    for (int jl = 0; jl < 2; ++jl)
+#pragma unroll
+                        for (int r = 0; r < 4; r += 2) {
+                            const f32x4 &u = acc[rb][mb][0][2 * j + jl], &v = acc[rb][mb][1][2 * j + jl];
+                            const float mx = fmaxf(fmaxf(u[r], u[r + 1]), fmaxf(v[r], v[r + 1]));
+                            Ps[(2 * kq + (r >> 1)) * TROW + 16 * jl + i16] = (T)fmaxf(mx + bias[2 * j + jl], relu_lo);
+                        }
                 }
 #pragma unroll
                 for (int it = 0; it < 2; ++it) {
@@ -368,7 +393,7 @@ static hipError_t launch_lpr_cfg(const ConvArgs &a, hipStream_t s)
     static_assert(lds <= 160 * 1024, "LDS of one CU");
     auto kern = conv3x3_lpr<T, CIN, NBT, NBUF, RB, HEAD>;
     if (hipError_t e = ensure_dynamic_lds(kern, lds); e != hipSuccess) return e;
-    hipLaunchKernelGGL(kern, dim3(grid), dim3(512), lds, s, a, tiles_x, tiles_y, ntiles, routing_of(a).lds_swz);
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(512), lds, s, a, tiles_x, tiles_y, ntiles);
     return hipGetLastError();
 }
 

@@ -20,7 +20,8 @@ namespace miunet {
 //     would need 174 KB);
 //   * LDS: 2 x 52 KB patch ring (LDS-DMA loads, pieces permuted as in conv_lpr.hip: lpr_common.h) + 32 KB exchange + 20 KB output scratch;
 //   * two barriers per tile (patch complete / partial sums published).
-// Arithmetic: the same products as conv_mfma_bf16, fp32 accumulation inside each K half in its order, then ONE extra fp32
+// Arithmetic (v_mfma_f32_16x16x32, one MFMA per tap and 32-channel chunk as in every 16-bit kernel): the same products as
+// conv_mfma_bf16, fp32 accumulation inside each K half in its order, then ONE extra fp32
 // add of the two halves -- (c0 + c1) + (c2 + c3) instead of ((c0 + c1) + c2) + c3: not bit-identical to the 2 x 2 kernel
 // (the other resident-weight kernels are), identical to fp32 re-association noise before the single 16-bit rounding
 // (tests/test_gpu_bf16.py::test_conv3x3_resident_weights_k_split, tests/test_gpu_insitu.py).
@@ -40,7 +41,7 @@ struct LPRK {
 };
 
 template <typename T>
-__global__ __launch_bounds__(512, 1) void conv3x3_lprk(const ConvArgs a, const int tiles_x, const int tiles_y, const int ntiles, const int swz)
+__global__ __launch_bounds__(512, 1) void conv3x3_lprk(const ConvArgs a, const int tiles_x, const int tiles_y, const int ntiles)
 {
     typedef typename LprVec<T>::x8 x8;
     typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
@@ -50,35 +51,38 @@ __global__ __launch_bounds__(512, 1) void conv3x3_lprk(const ConvArgs a, const i
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int li = lane & 31, lh = lane >> 5;
+    const int i16 = lane & 15, kq = lane >> 4;                // v_mfma_f32_16x16x32 lane roles (lpr_common.h)
     const int kh = wave & 1;                                  // K half: input channels 64 kh .. + 64 (patch planes 2 kh, 2 kh + 1)
     const int blk = (wave >> 1) & 1;                          // 32-channel output block
     const int rp = wave >> 2;                                 // row pair of the tile: image rows y0 + 2 rp, + 1
     char *const Xs = smem + LPRK::NBUF * LPRK::TILE_BYTES;    // [8 waves][16 registers][64 lanes] fp32
     T *const Ts = reinterpret_cast<T *>(smem + LPRK::NBUF * LPRK::TILE_BYTES + 8 * LPRK::X_BYTES + wave * LPRK::SCR_BYTES);
 
-    // ---- this wave's half of the block's weights, as MFMA B fragments: lane (li, lh) holds w[tap][64 kh + 16 ks + 8 lh .. + 8][32 blk + li]
+    // ---- this wave's half of the block's weights, as MFMA B fragments: lane (i16, kq) holds
+    // w[tap][64 kh + 32 c + 8 kq .. + 8][32 blk + 16 jb + i16]
     const T *const wpk = reinterpret_cast<const T *>(a.wpk);
-    x8 wreg[9][4];
-    const int n = 32 * blk + li;
-    const float bias = a.bias[n];
+    x8 wreg[9][2][2];
+    float bias[2];
 #pragma unroll
-    for (int tap = 0; tap < 9; ++tap)
+    for (int jb = 0; jb < 2; ++jb) {
+        const int n = 32 * blk + 16 * jb + i16;
+        bias[jb] = a.bias[n];
 #pragma unroll
-        for (int ks = 0; ks < 4; ++ks) {
-            const int kg = 4 * kh + ks;                       // 16-channel step of the whole reduction
-            wreg[tap][ks] = *reinterpret_cast<const x8 *>(wpk + ((size_t)((kg >> 1) * 9 + tap) * a.CoutPad + n) * KC_BF16 + 16 * (kg & 1) + 8 * lh);
-        }
+        for (int tap = 0; tap < 9; ++tap)
+#pragma unroll
+            for (int c = 0; c < 2; ++c)
+                wreg[tap][c][jb] = *reinterpret_cast<const x8 *>(wpk + ((size_t)((2 * kh + c) * 9 + tap) * a.CoutPad + n) * KC_BF16 + 8 * kq);
+    }
 
-    // ---- per-lane LDS byte offsets of the A fragments inside a plane (first 16-column half; the second is + 1024)
+    // ---- per-lane LDS byte offsets of the A fragments inside a plane: pixel (row 2 rp + mr, column i16) displaced by the tap,
+    // piece kq in slot kq ^ lds_swz_row16(column) (first 16-column half; the second is + 1024)
     unsigned aoff[9][2];
 #pragma unroll
     for (int tap = 0; tap < 9; ++tap) {
         const int dy = tap / 3, dx = tap - 3 * dy;
-        const int prow = 2 * rp + (li >> 4) + dy, pcol = (li & 15) + dx;
-        const int p = prow * LPRK::PW + pcol;
 #pragma unroll
-        for (int g = 0; g < 2; ++g) aoff[tap][g] = (unsigned)(p * 64 + (((2 * g + lh) ^ lds_swz_rows2(swz, prow, pcol, p)) << 4));
+        for (int mr = 0; mr < 2; ++mr)
+            aoff[tap][mr] = (unsigned)(((2 * rp + mr + dy) * LPRK::PW + i16 + dx) * 64 + ((kq ^ lds_swz_row16(i16 + dx)) << 4));
     }
 
     // ---- per-lane global byte offsets of this wave's patch loads, relative to the patch origin (y0 - 1, x0 - 1)
@@ -88,7 +92,7 @@ __global__ __launch_bounds__(512, 1) void conv3x3_lprk(const ConvArgs a, const i
         const int i = wave + 8 * k, c = i / LPRK::PLANE_LOADS, j = i - c * LPRK::PLANE_LOADS;
         const int p = 16 * j + (lane >> 2);
         const int py = p / LPRK::PW, px = p - py * LPRK::PW;
-        const int q = (lane & 3) ^ lds_swz_rows2(swz, py, px, p);
+        const int q = (lane & 3) ^ lds_swz_row16(px);
         dvoff[k] = (i < LPRK::TILE_LOADS && p < LPRK::NPIX) ? (unsigned)(((py * a.W + px) * a.ldc + 32 * c + 8 * q) * 2) : 0xFFFFFFFFu;
     }
 
@@ -133,7 +137,7 @@ __global__ __launch_bounds__(512, 1) void conv3x3_lprk(const ConvArgs a, const i
                 const int i = wave + 8 * k, c = i / LPRK::PLANE_LOADS, j = i - c * LPRK::PLANE_LOADS;
                 const int p = 16 * j + (lane >> 2);
                 const int py = p / LPRK::PW, px = p - py * LPRK::PW;
-                const int q = (lane & 3) ^ lds_swz_rows2(swz, py, px, p);
+                const int q = (lane & 3) ^ lds_swz_row16(px);
                 const int gy = y0 - 1 + py, gx = x0 - 1 + px;
                 const bool inb = p < LPRK::NPIX && gy >= 0 && gy < a.H && gx >= 0 && gx < a.W;
                 const unsigned voff = inb ? (unsigned)(((gy * a.W + gx) * a.ldc + 32 * c + 8 * q) * 2) : 0xFFFFFFFFu;
@@ -153,43 +157,58 @@ __global__ __launch_bounds__(512, 1) void conv3x3_lprk(const ConvArgs a, const i
 
         // ---- tile t: this wave's K half -- 9 taps x 4 k-steps for both 16-column halves of its row pair
         const unsigned base = (unsigned)((t % LPRK::NBUF) * LPRK::TILE_BYTES + 2 * kh * LPRK::PLANE_BYTES);
-        f32x16 acc[2];
+        f32x4 acc[2][2][2];                       // [column half][row of the pair][16-channel block]; first written by step 0
+        // 144 weight + 32 accumulator registers leave no room for a second fragment set: each fragment is refilled for step t + 1
+        // right after its two MFMAs of step t (six MFMAs = 96 cycles ahead of its next use; the SIMD's other wave covers the rest)
+        x8 af[2][2];
+        auto read_frag = [&](const int t, const int mb, const int mr) {
+            const int c = t / 9, tap = t - 9 * c;
+            return *reinterpret_cast<const x8 *>(smem + (base + aoff[tap][mr]) + c * LPRK::PLANE_BYTES + mb * 1024);
+        };
 #pragma unroll
         for (int mb = 0; mb < 2; ++mb)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) acc[mb][r] = 0.f;
+            for (int mr = 0; mr < 2; ++mr) af[mb][mr] = read_frag(0, mb, mr);
 #pragma unroll
-        for (int c = 0; c < 2; ++c)
+        for (int t = 0; t < 18; ++t) {
+            const int c = t / 9, tap = t - 9 * c;
 #pragma unroll
-            for (int tap = 0; tap < 9; ++tap)
+            for (int mb = 0; mb < 2; ++mb)
 #pragma unroll
-                for (int g = 0; g < 2; ++g) {
-                    x8 af[2];
+                for (int mr = 0; mr < 2; ++mr) {
 #pragma unroll
-                    for (int mb = 0; mb < 2; ++mb)
-                        af[mb] = *reinterpret_cast<const x8 *>(smem + (base + aoff[tap][g]) + c * LPRK::PLANE_BYTES + mb * 1024);
-#pragma unroll
-                    for (int mb = 0; mb < 2; ++mb) acc[mb] = mfma_lpr(af[mb], wreg[tap][2 * c + g], acc[mb]);
+                    for (int jb = 0; jb < 2; ++jb) {
+                        if (t == 0) mfma16_lpr_first(acc[mb][mr][jb], af[mb][mr], wreg[tap][c][jb]);
+                        else mfma16_lpr(acc[mb][mr][jb], af[mb][mr], wreg[tap][c][jb]);
+                    }
+                    if (t + 1 < 18) af[mb][mr] = read_frag(t + 1, mb, mr);
                 }
+        }
+        mfma16_drain();                           // (lpr_common.h: the exchange below reads the accumulators with no barrier in between)
+#pragma unroll
+        for (int mb = 0; mb < 2; ++mb)
+#pragma unroll
+            for (int mr = 0; mr < 2; ++mr)
+#pragma unroll
+                for (int jb = 0; jb < 2; ++jb) mfma16_settled(acc[mb][mr][jb]);
 
         // ---- exchange: hand the partner (the other K half of the same block) the half it finishes, keep column half kh
         {
             f32x4 *const xw = reinterpret_cast<f32x4 *>(Xs + wave * LPRK::X_BYTES) + lane;
-            const f32x16 &give = acc[1 - kh];
 #pragma unroll
-            for (int q = 0; q < 4; ++q) xw[64 * q] = f32x4{ give[4 * q], give[4 * q + 1], give[4 * q + 2], give[4 * q + 3] };
+            for (int q = 0; q < 4; ++q) xw[64 * q] = acc[1 - kh][q >> 1][q & 1];
         }
         lpr_wait_vm<0>();                     // this wave's share of tile t + 1's patch has landed (and tile t - 1's stores are out)
         __syncthreads();                      // partial sums published
-        f32x16 sum = acc[kh];
+        f32x4 sum[2][2];
         {
             const f32x4 *const xr = reinterpret_cast<const f32x4 *>(Xs + (wave ^ 1) * LPRK::X_BYTES) + lane;
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
                 const f32x4 v = xr[64 * q];
+                const f32x4 mine = acc[kh][q >> 1][q & 1];
                 // channels 0..63 first, then 64..127: the order a single chain would have added them in
-                if (kh == 0) { sum[4 * q] += v.x; sum[4 * q + 1] += v.y; sum[4 * q + 2] += v.z; sum[4 * q + 3] += v.w; }
-                else { sum[4 * q] = v.x + sum[4 * q]; sum[4 * q + 1] = v.y + sum[4 * q + 1]; sum[4 * q + 2] = v.z + sum[4 * q + 2]; sum[4 * q + 3] = v.w + sum[4 * q + 3]; }
+                sum[q >> 1][q & 1] = kh == 0 ? mine + v : v + mine;
             }
         }
 
@@ -203,12 +222,14 @@ __global__ __launch_bounds__(512, 1) void conv3x3_lprk(const ConvArgs a, const i
             reinterpret_cast<T *>(a.out) + (size_t)b * a.H * a.W * a.ldo, 0, a.H * a.W * a.ldo * 2, 0x00020000);
         const unsigned osoff = (unsigned)(((y0 * a.W + x0) * a.ldo) * 2);
         const bool edge = y0 + LPRK::TH > a.H || x0 + 32 > a.W;
-        // accumulator register r = pixel m = (r & 3) + 8 (r >> 2) + 4 lh of the row block: row m >> 4, column m & 15
+        // register r of block (row mr, 16-channel block jb) = pixel m = 16 mr + 4 kq + r of the row block, channel 16 jb + i16
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int m = (r & 3) + 8 * (r >> 2) + 4 * lh;
-            Ts[m * TROW + li] = (T)fmaxf(sum[r] + bias, relu_lo);
-        }
+        for (int mr = 0; mr < 2; ++mr)
+#pragma unroll
+            for (int jb = 0; jb < 2; ++jb)
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                    Ts[(16 * mr + 4 * kq + r) * TROW + 16 * jb + i16] = (T)fmaxf(sum[mr][jb][r] + bias[jb], relu_lo);
 #pragma unroll
         for (int it = 0; it < 2; ++it) {
             const int e = lane + 64 * it, m = e >> 2, q = e & 3;
@@ -249,7 +270,7 @@ static hipError_t launch_lprk(const ConvArgs &a, hipStream_t s)
     static_assert(LPRK::LDS_BYTES <= 160 * 1024, "LDS of one CU");
     auto kern = conv3x3_lprk<T>;
     if (hipError_t e = ensure_dynamic_lds(kern, LPRK::LDS_BYTES); e != hipSuccess) return e;
-    hipLaunchKernelGGL(kern, dim3(grid), dim3(512), LPRK::LDS_BYTES, s, a, tiles_x, tiles_y, ntiles, routing_of(a).lds_swz);
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(512), LPRK::LDS_BYTES, s, a, tiles_x, tiles_y, ntiles);
     return hipGetLastError();
 }
 

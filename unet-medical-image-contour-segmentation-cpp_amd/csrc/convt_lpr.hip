@@ -17,22 +17,23 @@ namespace miunet {
 //     32-pixel row blocks (Cin <= 128: all Cout / 32 channel blocks of the tap) or half of the tap's channels (Cin = 256):
 //     Cin / 16 x NBW B-fragments = 16, 64 or 128 weight registers, loaded once;
 //   * LDS holds only input tiles: 32 KB each (256, 128 or 64 pixels x Cin), a ring of three filled by LDS-DMA loads two
-//     tiles ahead, pieces permuted inside a pixel's 64 bytes for the 16-lane service groups of ds_read_b128 (lpr_common.h: lds_swz_row1);
+//     tiles ahead, pieces permuted inside a pixel's 64 bytes for the 16-lane service groups of ds_read_b128 (lpr_common.h: lds_swz_row16);
 //   * a row block's accumulators (NBW x 16 registers) are rounded once and leave through a wave-private LDS tile as 16-byte
 //     stores: every output pixel of the tap gets its 64 or 128 contiguous bytes in one piece;
 //   * one barrier per tile, waits counted as in conv_lpr.hip (a wave waits for ITS loads of tile n + 1 after the MFMAs of
 //     tile n and before its stores).
-// Same products and fp32 accumulation order as conv_mfma_bf16<TAPS = 1>: bit-identical outputs
+// v_mfma_f32_16x16x32, one MFMA per 32-channel chunk as in every 16-bit kernel: the same products and fp32 accumulation chain as
+// conv_mfma_bf16<TAPS = 1>: bit-identical outputs
 // (tests/test_gpu_bf16.py::test_convT_resident_weights).
 //
 // CIN = 64 / 128 / 256, NBW = 32-channel blocks per wave, COSPLIT = waves w >> 2 split the tap's channels (else its row blocks)
 template <typename T, int CIN, int NBW, bool COSPLIT>
-__global__ __launch_bounds__(512, 1) void convT2x2_lpr(const ConvArgs a, const int tiles_x, const int tiles_y, const int ntiles, const int swz)
+__global__ __launch_bounds__(512, 1) void convT2x2_lpr(const ConvArgs a, const int tiles_x, const int tiles_y, const int ntiles)
 {
     typedef typename LprVec<T>::x8 x8;
     typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
     typedef __attribute__((address_space(3))) void *lds_ptr;
-    constexpr int PLANES = CIN / 32, KSTEPS = CIN / 16;
+    constexpr int PLANES = CIN / 32, NB16 = 2 * NBW;
     constexpr int TILE_BYTES = 32 * 1024, TILE_LOADS = 32;    // every tile is 32 KB: 32 wave-wide loads, four per wave
     constexpr int M = TILE_BYTES / (CIN * 2);                  // pixels per tile: 256 / 128 / 64
     constexpr int TR = M / 32;                                 // image rows per tile (row block = 1 row x 32 columns)
@@ -47,38 +48,36 @@ __global__ __launch_bounds__(512, 1) void convT2x2_lpr(const ConvArgs a, const i
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int li = lane & 31, lh = lane >> 5;
+    const int i16 = lane & 15, kq = lane >> 4;                 // v_mfma_f32_16x16x32 lane roles (lpr_common.h)
     const int kidx = wave & 3, half = wave >> 2;               // tap dy = kidx >> 1, dx = kidx & 1
     const int dy = kidx >> 1, dx = kidx & 1;
     const int mb0 = COSPLIT ? 0 : half * MBW;                  // first row block
     const int co0 = COSPLIT ? half * 32 * NBW : 0;             // first channel of the tap
     T *const Ts = reinterpret_cast<T *>(smem + NBUF * TILE_BYTES + wave * SCR_BYTES);
 
-    // ---- weights: [Cin / 32][N = 4 Cout (n = kidx Cout + co)][32]; lane (li, lh) holds w[16 ks + 8 lh .. + 8][n]
+    // ---- weights: [Cin / 32][N = 4 Cout (n = kidx Cout + co)][32]; lane (i16, kq) holds w[32 c + 8 kq .. + 8][n]
     const T *const wpk = reinterpret_cast<const T *>(a.wpk);
-    x8 wreg[KSTEPS][NBW];
-    float bias[NBW];
+    x8 wreg[PLANES][NB16];
+    float bias[NB16];
 #pragma unroll
-    for (int j = 0; j < NBW; ++j) {
-        const int co = co0 + 32 * j + li;
+    for (int j = 0; j < NB16; ++j) {
+        const int co = co0 + 16 * j + i16;
         bias[j] = a.bias[co];
 #pragma unroll
-        for (int ks = 0; ks < KSTEPS; ++ks)
-            wreg[ks][j] = *reinterpret_cast<const x8 *>(wpk + ((size_t)(ks >> 1) * a.CoutPad + (size_t)kidx * a.Cout + co) * KC_BF16 + 16 * (ks & 1) + 8 * lh);
+        for (int c = 0; c < PLANES; ++c)
+            wreg[c][j] = *reinterpret_cast<const x8 *>(wpk + ((size_t)c * a.CoutPad + (size_t)kidx * a.Cout + co) * KC_BF16 + 8 * kq);
     }
 
-    // ---- A fragments: pixel p = 32 mb + li of the tile (one image row x 32 columns), piece q = 2 g + lh in slot
-    // q ^ lds_swz_row1(column li) (lpr_common.h; the same for every mb)
-    unsigned aoff[2];
-#pragma unroll
-    for (int g = 0; g < 2; ++g) aoff[g] = (unsigned)(li * 64 + (((2 * g + lh) ^ lds_swz_row1(swz, li, li)) << 4));
+    // ---- A fragments: pixel 32 mb + 16 h + i16 of the tile (row block mb = one image row x 32 columns, column half h), piece kq
+    // in slot kq ^ lds_swz_row16(column) (lpr_common.h; the same for every mb and h)
+    const unsigned aoff = (unsigned)(i16 * 64 + ((kq ^ lds_swz_row16(i16)) << 4));
 
     // ---- this wave's four patch loads: load i = wave + 8 k = pixels 16 (i % PLANE_LOADS) .. + 16 of plane i / PLANE_LOADS
     unsigned dvoff[4];
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
         const int i = wave + 8 * k, c = i / PLANE_LOADS, j = i - c * PLANE_LOADS;
-        const int p = 16 * j + (lane >> 2), q = (lane & 3) ^ lds_swz_row1(swz, p & 31, p);
+        const int p = 16 * j + (lane >> 2), q = (lane & 3) ^ lds_swz_row16(p & 31);
         dvoff[k] = (unsigned)((((p >> 5) * a.W + (p & 31)) * a.ldc + 32 * c + 8 * q) * 2);
     }
 
@@ -144,26 +143,41 @@ __global__ __launch_bounds__(512, 1) void convT2x2_lpr(const ConvArgs a, const i
 #pragma unroll
         for (int mi = 0; mi < MBW; ++mi) {
             const int mb = mb0 + mi;
-            f32x16 acc[NBW];
+            f32x4 acc[2][NB16];                   // [column half][16-channel block]; first written by plane 0
+            x8 af[2][2];                          // the fragments of plane c + 1 are requested before the MFMAs of plane c (conv_lpr.hip)
+            auto read_plane = [&](const int c, x8 (&dst)[2]) {
 #pragma unroll
-            for (int j = 0; j < NBW; ++j)
+                for (int h = 0; h < 2; ++h)
+                    dst[h] = *reinterpret_cast<const x8 *>(smem + (base + aoff) + c * PLANE_BYTES + mb * 2048 + h * 1024);
+            };
+            read_plane(0, af[0]);
 #pragma unroll
-                for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
+            for (int c = 0; c < PLANES; ++c) {
+                if (c + 1 < PLANES) read_plane(c + 1, af[(c + 1) & 1]);
 #pragma unroll
-            for (int ks = 0; ks < KSTEPS; ++ks) {
-                const x8 af = *reinterpret_cast<const x8 *>(smem + (base + aoff[ks & 1]) + (ks >> 1) * PLANE_BYTES + mb * 2048);
+                for (int h = 0; h < 2; ++h)
 #pragma unroll
-                for (int j = 0; j < NBW; ++j) acc[j] = mfma_lpr(af, wreg[ks][j], acc[j]);
+                    for (int j = 0; j < NB16; ++j) {
+                        if (c == 0) mfma16_lpr_first(acc[h][j], af[c & 1][h], wreg[c][j]);
+                        else mfma16_lpr(acc[h][j], af[c & 1][h], wreg[c][j]);
+                    }
             }
+            mfma16_drain();                       // (lpr_common.h: the stores below read the accumulators with no barrier in between)
+#pragma unroll
+            for (int h = 0; h < 2; ++h)
+#pragma unroll
+                for (int j = 0; j < NB16; ++j) mfma16_settled(acc[h][j]);
             // this wave's loads of tile n + 1: older than the four it issued for tile n + 2, and waited for before ANY store of
             // tile n (a store issued first would sit in front of them in the count)
             if (mi == 0) lpr_wait_vm_n(n + 2 < nt ? 4 : 0);
-            // accumulator register r = pixel column (r & 3) + 8 (r >> 2) + 4 lh of row y0 + mb, lane = channel li of block j
+            // register r of block (h, j) = pixel column 16 h + 4 kq + r of row y0 + mb, lane = channel i16 of the 16-channel block j
 #pragma unroll
-            for (int j = 0; j < NBW; ++j)
+            for (int h = 0; h < 2; ++h)
 #pragma unroll
-                for (int r = 0; r < 16; ++r)
-                    Ts[((r & 3) + 8 * (r >> 2) + 4 * lh) * TROW + 32 * j + li] = (T)fmaxf(acc[j][r] + bias[j], relu_lo);
+                for (int j = 0; j < NB16; ++j)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r)
+                        Ts[(16 * h + 4 * kq + r) * TROW + 16 * j + i16] = (T)fmaxf(acc[h][j][r] + bias[j], relu_lo);
             const unsigned osoff = (unsigned)(((2 * (y0 + mb) * OW + 2 * x0) * a.ldo) * 2);
 #pragma unroll
             for (int it = 0; it < OITERS; ++it) {
@@ -190,7 +204,7 @@ static hipError_t launch_convt_lpr_cfg(const ConvArgs &a, hipStream_t s)
     static_assert(lds <= 160 * 1024, "LDS of one CU");
     auto kern = convT2x2_lpr<T, CIN, NBW, COSPLIT>;
     if (hipError_t e = ensure_dynamic_lds(kern, lds); e != hipSuccess) return e;
-    hipLaunchKernelGGL(kern, dim3(grid), dim3(512), lds, s, a, tiles_x, tiles_y, ntiles, routing_of(a).lds_swz);
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(512), lds, s, a, tiles_x, tiles_y, ntiles);
     return hipGetLastError();
 }
 

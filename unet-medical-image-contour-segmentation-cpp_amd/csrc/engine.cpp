@@ -897,8 +897,6 @@ Routing Routing::from_env()
     r.wino4s = num("MIUNET_WINO4S", 1);
     r.convt_small = num("MIUNET_CONVT_SMALL", 1) != 0;
     r.first_mfma = num("MIUNET_FIRST_MFMA", 1) != 0;
-    r.lds_swz = num("MIUNET_LDS_SWZ", 1);
-    r.lp2_shape = num("MIUNET_LP2_SHAPE", 32);
     int dev = 0;
     hipDeviceProp_t p;
     if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&p, dev) == hipSuccess && p.multiProcessorCount > 0)

@@ -25,9 +25,6 @@ struct Routing {
     int wino4s = 1;           // MIUNET_WINO4S: 0 never, 1 grids that fill the chip twice over, 2 every one-block case
     bool convt_small = true;  // MIUNET_CONVT_SMALL=0: the per-tap transposed conv never shrinks its tile
     bool first_mfma = true;   // MIUNET_FIRST_MFMA=0: the 16-bit pipelines' first layer stays on the VALU kernel
-    int lp2_shape = 32;       // MIUNET_LP2_SHAPE: the wide kernel's MFMA shape -- 32 = v_mfma_f32_32x32x16, 16 = v_mfma_f32_16x16x32 (conv3x3_lp2s)
-    int lds_swz = 1;          // MIUNET_LDS_SWZ: 1 = piece slots of the LDS-DMA patch images laid out for the 16-lane service groups
-                              // of ds_read_b128 (lpr_common.h); 0 = the round-2 layout (2-way bank conflicts), kept for A/B
     static Routing from_env();            // reads the environment and the current device's properties (engine.cpp)
 };
 
