@@ -44,7 +44,7 @@ def test_resident_weight_kernels_do_not_spill(tmp_path):
     """conv_lpr.hip counts its own LDS-DMA loads with vmcnt; a register spill adds scratch loads and stores to the same
     counter, and hipcc's waits for THOSE drain the patch ring (measured: the fused-head variant 0.27 -> 0.53 ms with 24 scratch
     accesses per tile).  Every instantiation must fit its register budget."""
-    for src, kernels in (("conv_lpr.hip", 14), ("convt_lpr.hip", 6), ("conv_lprk.hip", 2)):       # shapes x two operand types
+    for src, kernels in (("conv_lpr.hip", 12), ("convt_lpr.hip", 6), ("conv_lprk.hip", 2)):       # shapes x two operand types
         asm = tmp_path / (src + ".s")
         subprocess.run([HIPCC, "-O3", "-std=c++17", "--offload-arch=gfx950", "-S", "--cuda-device-only", "-o", str(asm),
                         os.path.join(CSRC, src)], check=True, capture_output=True, timeout=600)

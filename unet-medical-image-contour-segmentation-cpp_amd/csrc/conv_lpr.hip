@@ -52,20 +52,13 @@ struct LPR {
     static constexpr int SCR_BYTES = (32 + 8) * TROW * 2;         // per wave: [32 pixels][TROW] + pooled [8][TROW]
     static constexpr int HEAD_ROW = 32 + 4;                       // floats per pixel of the fused head's tile (conflict-free b128 rows)
     static constexpr int HEAD_SCR_BYTES = 32 * HEAD_ROW * 4;      // per wave: [32 pixels][HEAD_ROW] fp32
-    static constexpr size_t lds_bytes(int plane_bytes, int cin, int cout, int nbuf, bool head)
+    static constexpr size_t lds_bytes(int plane_bytes, int cin, int nbuf, bool head)
     {
-        // (the 64 -> 64 head keeps THREE fp32 tiles per wave pair: both column halves of channels 0..31, one of channels 32..63)
-        return (size_t)nbuf * (cin / 32) * plane_bytes + (head && cout == 64 ? 12 : 8) * (head ? HEAD_SCR_BYTES : SCR_BYTES) + (head ? 3 * cout * 4 : 0);
+        return (size_t)nbuf * (cin / 32) * plane_bytes + 8 * (head ? HEAD_SCR_BYTES : SCR_BYTES) + (head ? 3 * 32 * 4 : 0);
     }
 };
 
 // CIN = 32 or 64 input channels (exactly), NBT = 1 or 2 blocks of 32 output channels (Cout = 32 NBT exactly), NBUF = patch ring
-// HEAD, 64 -> 64 (the last conv of a base-64 network, BASELINE config 3): the wave pair of a row pair holds 32 channels each, so
-// a pixel's 64 channels meet in LDS -- the wave with channels 0..31 drops its post-ReLU fp32 tiles (both column halves) there,
-// its partner adds its own tile and runs the head's sixteen steps in the order of the one-wave sum (four interleaved partial
-// sums per class over channels 0..63, fold, bias, argmax): the same logits bit for bit as conv_mfma_bf16's fused head.  One
-// extra barrier per tile; the head's weights are read from LDS as broadcasts (96 + 144 registers of weights do not fit); a
-// patch ring of two (the tiles take the third slot's room).
 // HEAD (Cout = 32, at most three classes): the layer feeds the network's fp32 1x1 head + argmax (ConvArgs::head_w).  The
 // post-ReLU fp32 row block crosses the wave's LDS scratch, lane = pixel, the head's weights stay in registers (96), the sums
 // run in the order of conv_mfma_bf16's fused head (four interleaved partial sums per class, folded at the end): the same
@@ -76,16 +69,14 @@ __global__ __launch_bounds__(512, 1) void conv3x3_lpr(const ConvArgs a, const in
     typedef typename LprVec<T>::x8 x8;
     typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
     typedef __attribute__((address_space(3))) void *lds_ptr;
-    static_assert((CIN == 32 || CIN == 64) && (NBT == 1 || NBT == 2) && NBUF >= 2, "narrow layers only");
-    static_assert(!HEAD || NBT == 1 || (CIN == 64 && RB == 1), "the fused head: every channel of a pixel in one wave, or 64 -> 64 across the wave pair");
+    static_assert((CIN == 32 || CIN == 64) && (NBT == 1 || NBT == 2) && NBUF >= 3, "narrow layers only");
+    static_assert(!HEAD || NBT == 1, "the fused head needs every channel of a pixel in one wave");
     static_assert(RB == 1 || CIN == 32, "two row blocks per wave: one 32-channel plane only (immediate LDS offsets, LDS size)");
     using GEO = LprGeom<RB>;
     constexpr int PLANES = CIN / 32;
     constexpr bool SPLITN = CIN * NBT > 64;                   // 64 -> 64: a wave keeps ONE 32-channel block (144 weight registers) ...
     constexpr int MB = SPLITN ? 2 : 1;                        // ... for both column halves of its row pair; otherwise one row block,
     constexpr int NB = SPLITN ? 1 : NBT;                      // every channel block
-    constexpr bool HEAD2 = HEAD && SPLITN;                    // the 64 -> 64 head: partial sums cross the wave pair
-    constexpr int COUT = 32 * NBT;
     constexpr int TILE_BYTES = PLANES * GEO::PLANE_BYTES;
     constexpr int TILE_LOADS = PLANES * GEO::PLANE_LOADS;
     constexpr int DMA_ITERS = (TILE_LOADS + 7) / 8;
@@ -167,19 +158,17 @@ __global__ __launch_bounds__(512, 1) void conv3x3_lpr(const ConvArgs a, const in
     // HEAD: head_w[k][c] (classes past head_classes = 0) goes through LDS once.  Read straight from global its address is
     // uniform, so hipcc keeps the 96 values in SGPRs, spills them into VGPR lanes and restores each with a v_readlane per use
     // (149 per tile); read back from LDS they are ordinary per-lane registers.
-    f32x4 wh[HEAD && !HEAD2 ? 3 : 1][8];
+    f32x4 wh[HEAD ? 3 : 1][8];
     float hb[3] = { 0.f, 0.f, 0.f };
-    float *const WhL = reinterpret_cast<float *>(smem + NBUF * TILE_BYTES + (HEAD2 ? 12 : 8) * LPR::HEAD_SCR_BYTES);      // HEAD: [3][COUT]
     if constexpr (HEAD) {
-        if (tid < 3 * COUT) WhL[tid] = tid / COUT < a.head_classes ? a.head_w[tid] : 0.f;
+        float *const WhL = reinterpret_cast<float *>(smem + NBUF * TILE_BYTES + 8 * LPR::HEAD_SCR_BYTES);      // [3][32]
+        if (tid < 3 * 32) WhL[tid] = tid / 32 < a.head_classes ? a.head_w[tid] : 0.f;
         __syncthreads();
 #pragma unroll
         for (int k = 0; k < 3; ++k) {
             if (k < a.head_classes) hb[k] = a.head_b[k];
-            if constexpr (!HEAD2) {
 #pragma unroll
-                for (int c4 = 0; c4 < 8; ++c4) wh[k][c4] = *reinterpret_cast<const f32x4 *>(WhL + k * 32 + 4 * c4);
-            }
+            for (int c4 = 0; c4 < 8; ++c4) wh[k][c4] = *reinterpret_cast<const f32x4 *>(WhL + k * 32 + 4 * c4);
         }
     }
 
@@ -249,38 +238,33 @@ __global__ __launch_bounds__(512, 1) void conv3x3_lpr(const ConvArgs a, const in
         f32x4 acc[RB][MB][2][NB16];               // [row block][column half][row of the pair][16-channel block]; first written by tap 0
         // the MFMAs are volatile asms (lpr_common.h) and LDS reads do not move across those: the software pipeline is written
         // out -- the fragments of step t + 1 are requested before the MFMAs of step t (a step = one tap of one 32-channel plane)
-        constexpr int AFB = HEAD2 ? 1 : 2;        // fragment sets: two (step t + 1 requested before the MFMAs of step t), or one that is
-        x8 af[AFB][RB][MB][2];                    // refilled fragment by fragment right after its last use (the 64 -> 64 head: no registers to spare)
-        auto read_frag = [&](const int t, const int rb, const int mb, const int mr) {
-            const int c = t / 9, tap = t - 9 * c;
-            return *reinterpret_cast<const x8 *>(smem + (base + aoff[tap][mr]) + c * GEO::PLANE_BYTES + rb * GEO::RB_BYTES + mb * 1024);
-        };
+        x8 af[2][RB][MB][2];
         auto read_step = [&](const int t, x8 (&dst)[RB][MB][2]) {
+            const int c = t / 9, tap = t - 9 * c;
 #pragma unroll
             for (int rb = 0; rb < RB; ++rb)
 #pragma unroll
                 for (int mb = 0; mb < MB; ++mb)
 #pragma unroll
-                    for (int mr = 0; mr < 2; ++mr) dst[rb][mb][mr] = read_frag(t, rb, mb, mr);
+                    for (int mr = 0; mr < 2; ++mr)
+                        dst[rb][mb][mr] = *reinterpret_cast<const x8 *>(smem + (base + aoff[tap][mr]) + c * GEO::PLANE_BYTES + rb * GEO::RB_BYTES + mb * 1024);
         };
         read_step(0, af[0]);
 #pragma unroll
         for (int t = 0; t < 9 * PLANES; ++t) {
             const int c = t / 9, tap = t - 9 * c;
-            if (AFB == 2 && t + 1 < 9 * PLANES) read_step(t + 1, af[(t + 1) % AFB]);
+            if (t + 1 < 9 * PLANES) read_step(t + 1, af[(t + 1) & 1]);
 #pragma unroll
             for (int rb = 0; rb < RB; ++rb)
 #pragma unroll
                 for (int mb = 0; mb < MB; ++mb)
 #pragma unroll
-                    for (int mr = 0; mr < 2; ++mr) {
+                    for (int mr = 0; mr < 2; ++mr)
 #pragma unroll
                         for (int jb = 0; jb < NB16; ++jb) {
-                            if (t == 0) mfma16_lpr_first(acc[rb][mb][mr][jb], af[t % AFB][rb][mb][mr], wreg[tap][c][jb]);
-                            else mfma16_lpr(acc[rb][mb][mr][jb], af[t % AFB][rb][mb][mr], wreg[tap][c][jb]);
+                            if (t == 0) mfma16_lpr_first(acc[rb][mb][mr][jb], af[t & 1][rb][mb][mr], wreg[tap][c][jb]);
+                            else mfma16_lpr(acc[rb][mb][mr][jb], af[t & 1][rb][mb][mr], wreg[tap][c][jb]);
                         }
-                        if (AFB == 1 && t + 1 < 9 * PLANES) af[0][rb][mb][mr] = read_frag(t + 1, rb, mb, mr);
-                    }
         }
         mfma16_drain();                           // (lpr_common.h: the epilogue below reads the accumulators with no barrier in between)
 #pragma unroll
@@ -314,60 +298,6 @@ __global__ __launch_bounds__(512, 1) void conv3x3_lpr(const ConvArgs a, const in
         const unsigned osoff = (unsigned)(((y0 * a.W + x0) * a.ldo) * 2);
         const unsigned psoff = (unsigned)((((y0 >> 1) * Wp + (x0 >> 1)) * a.pool_ld) * 2);
         const bool edge = y0 + GEO::TH > a.H || x0 + 32 > a.W;
-        if constexpr (HEAD2) {
-            // this pair's tiles: [0], [1] = channels 0..31 of column halves 0, 1 (written by the pair's first wave), [2] = channels
-            // 32..63 of the column half its partner is working on; [32 pixels][HEAD_ROW] fp32 each
-            float *const Tp = reinterpret_cast<float *>(smem + NBUF * TILE_BYTES) + rp * 3 * (LPR::HEAD_SCR_BYTES / 4);
-            auto drop_tile = [&](const int mb, float *const dst) {
-#pragma unroll
-                for (int mr = 0; mr < 2; ++mr)
-#pragma unroll
-                    for (int jl = 0; jl < 2; ++jl)
-#pragma unroll
-                        for (int r = 0; r < 4; ++r)
-                            dst[(16 * mr + 4 * kq + r) * LPR::HEAD_ROW + 16 * jl + i16] = fmaxf(acc[0][mb][mr][jl][r] + bias[jl], relu_lo);
-            };
-            if (blk0 == 0) {
-                drop_tile(0, Tp);
-                drop_tile(1, Tp + LPR::HEAD_SCR_BYTES / 4);
-            }
-            __syncthreads();                      // tiles of channels 0..31 published (the barrier at the head of the next tile frees them)
-            if (blk0 == 1) {
-                const int m = lane & 31;          // lane = pixel (lanes 32..63 repeat 0..31 and store nothing)
-#pragma unroll
-                for (int mb = 0; mb < 2; ++mb) {
-                    drop_tile(mb, Tp + 2 * (LPR::HEAD_SCR_BYTES / 4));
-                    f32x4 d4[3];
-#pragma unroll
-                    for (int k = 0; k < 3; ++k) d4[k] = f32x4{ 0.f, 0.f, 0.f, 0.f };
-                    // (a real loop, four steps per trip: fully unrolled, hipcc keeps all 16 tile reads and 48 broadcast reads of the
-                    // weights in flight and spills the layer's resident weights to make room)
-#pragma unroll 4
-                    for (int c4 = 0; c4 < 16; ++c4) {
-                        const float *const src = (c4 < 8 ? Tp + mb * (LPR::HEAD_SCR_BYTES / 4) : Tp + 2 * (LPR::HEAD_SCR_BYTES / 4)) + m * LPR::HEAD_ROW + 4 * (c4 & 7);
-                        const f32x4 yv = *reinterpret_cast<const f32x4 *>(src);
-#pragma unroll
-                        for (int k = 0; k < 3; ++k) d4[k] += yv * *reinterpret_cast<const f32x4 *>(WhL + k * COUT + 4 * c4);
-                    }
-                    const int py = y0 + 2 * rp + (m >> 4), px = x0 + 16 * mb + (m & 15);
-                    if (lane < 32 && py < a.H && px < a.W) {
-                        const size_t hw = (size_t)a.H * a.W, pin = (size_t)py * a.W + px;
-                        float best = -3.402823466e+38f;
-                        int idx = 0;
-#pragma unroll
-                        for (int k = 0; k < 3; ++k) {
-                            if (k < a.head_classes) {
-                                const float d = ((d4[k].x + d4[k].y) + (d4[k].z + d4[k].w)) + hb[k];
-                                if (a.head_logits != nullptr) a.head_logits[((size_t)b * a.head_classes + k) * hw + pin] = d;
-                                if (d > best) { best = d; idx = k; }
-                            }
-                        }
-                        a.head_labels[(size_t)b * hw + pin] = (uint8_t)idx;
-                    }
-                }
-            }
-            continue;
-        }
 #pragma unroll
         for (int rb = 0; rb < RB; ++rb)
 #pragma unroll
@@ -377,7 +307,7 @@ __global__ __launch_bounds__(512, 1) void conv3x3_lpr(const ConvArgs a, const in
                 const int yb = y0 + 8 * rb;                   // first image row of this row block's group of four row pairs
                 // register r of block (row mr, 16-channel block jl of this 32-channel group) = pixel m = 16 mr + 4 kq + r of the
                 // row block (row m >> 4, column m & 15), channel 16 jl + i16
-                if constexpr (HEAD && !HEAD2) {
+                if constexpr (HEAD) {
 #pragma unroll
                     for (int mr = 0; mr < 2; ++mr)
 #pragma unroll
@@ -459,7 +389,7 @@ static hipError_t launch_lpr_cfg(const ConvArgs &a, hipStream_t s)
     const int ntiles = tiles_x * tiles_y * a.B;
     const int cus = routing_of(a).cus;
     const int grid = ntiles < cus ? ntiles : cus;
-    constexpr size_t lds = LPR::lds_bytes(GEO::PLANE_BYTES, CIN, 32 * NBT, NBUF, HEAD);
+    constexpr size_t lds = LPR::lds_bytes(GEO::PLANE_BYTES, CIN, NBUF, HEAD);
     static_assert(lds <= 160 * 1024, "LDS of one CU");
     auto kern = conv3x3_lpr<T, CIN, NBT, NBUF, RB, HEAD>;
     if (hipError_t e = ensure_dynamic_lds(kern, lds); e != hipSuccess) return e;
@@ -470,8 +400,8 @@ static hipError_t launch_lpr_cfg(const ConvArgs &a, hipStream_t s)
 static bool lpr_shape_ok(const ConvArgs &a)
 {
     if (a.wpk == nullptr) return false;
-    if (a.head_w != nullptr) {                // fused head: 32 -> 32 or 64 -> 64 channels, at most three classes, fp32 tile (never stored), no pooling
-        if (!((a.Cin == 32 && a.Cout == 32) || (a.Cin == 64 && a.Cout == 64)) || a.head_classes < 1 || a.head_classes > 3 || a.out_lp || a.pool_out != nullptr || a.head_labels == nullptr ||
+    if (a.head_w != nullptr) {                // fused head: 32 -> 32 channels, at most three classes, fp32 tile (never stored), no pooling
+        if (a.Cin != 32 || a.Cout != 32 || a.head_classes < 1 || a.head_classes > 3 || a.out_lp || a.pool_out != nullptr || a.head_labels == nullptr ||
             a.head_b == nullptr)
             return false;
     } else if (!a.out_lp) {
@@ -501,7 +431,7 @@ static hipError_t launch_lpr(const ConvArgs &a, hipStream_t s)
     const int rb_env = routing_of(a).lpr_rb;                // MIUNET_LPR_RB = 1: 8-row tiles for every shape (A/B, parity tests)
     // the fused head keeps 8-row tiles: with two row blocks its 96 head-weight registers spill, and scratch traffic shares
     // vmcnt with the patch DMA (the compiler's waits for it drain the ring: measured 0.27 -> 0.53 ms)
-    if (a.head_w != nullptr) return a.Cin == 32 ? launch_lpr_cfg<T, 32, 1, 4, 1, true>(a, s) : launch_lpr_cfg<T, 64, 2, 2, 1, true>(a, s);
+    if (a.head_w != nullptr) return launch_lpr_cfg<T, 32, 1, 4, 1, true>(a, s);
     if (rb_env == 2) {
         if (a.Cin == 32 && a.Cout == 32) return launch_lpr_cfg<T, 32, 1, 3, 2>(a, s);
         if (a.Cin == 32) return launch_lpr_cfg<T, 32, 2, 4, 1>(a, s);      // 32 -> 64 with two row blocks spills (144 weight + 64 accumulator registers)
