@@ -47,7 +47,7 @@ sys.path.insert(0, PKG)
 # PFLOP/s for a register-only bf16 MFMA loop (the clock drops to 1.80 GHz under dense 16-bit matrix work), 6.29 TB/s for an HBM copy
 # -- as the practical ceilings their design notes argue against; those are never the denominator of a reported fraction.
 FP32_PEAK_TFLOPS = 157.3      # fp32 matrix peak (v_mfma_f32_32x32x2_f32 / 16x16x4_f32); the fp32 loop holds 2.38 GHz: 155.6 TF/s measured
-LP_PEAK_TFLOPS = 2500.0       # dense bf16 / fp16 MFMA peak (v_mfma_f32_32x32x16_{bf16,f16})
+LP_PEAK_TFLOPS = 2500.0       # dense bf16 / fp16 MFMA peak (the same per clock for v_mfma_f32_16x16x32 and 32x32x16; the kernels use 16x16x32)
 HBM_PEAK_GBS = 8000.0
 
 # multiplies the MFMA pipe executes per algorithmic (direct-convolution) multiply, by kernel family
@@ -178,7 +178,7 @@ def roofline_from_stats(stats, spec_macs, ips_per_gpu, tag):
     red = WINOGRAD_REDUCTION.get(dom_kernel, 1.0)
     algorithmic = dom_flops / (dom_ms * 1e-3) / 1e12 if dom_ms else 0.0
     executed = algorithmic / red
-    insn = ("v_mfma_f32_32x32x16_f16" if "fp16" in dom_kernel else "v_mfma_f32_32x32x16_bf16" if lp
+    insn = ("v_mfma_f32_16x16x32_f16" if "fp16" in dom_kernel else "v_mfma_f32_16x16x32_bf16" if lp
             else "v_mfma_f32_16x16x4_f32" if dom_kernel == "conv3x3_wino4" else "v_mfma_f32_32x32x2_f32")
     pmc, pmc_src = pmc_summary(tag)
     rk = (pmc or {}).get("kernels", {}).get(ROCPROF_NAME.get(dom_kernel, ""), {})

@@ -54,9 +54,9 @@ typedef struct mi_unet_config {
 #define MI_UNET_CONV_WINOGRAD16 3   /* same algorithm, 8-wave tiling on v_mfma_f32_16x16x4_f32 (two waves per SIMD) */
 #define MI_UNET_CONV_BF16 4         /* BASELINE config 3: bf16 conv operands (weights packed bf16, activations rounded to
                                        bf16 once by the kernel that produces them and kept bf16 in HBM), fp32 accumulate on
-                                       v_mfma_f32_32x32x16_bf16.  NOT the fp32 metric: logits follow the bf16-operand oracle. */
+                                       v_mfma_f32_16x16x32_bf16.  NOT the fp32 metric: logits follow the bf16-operand oracle. */
 #define MI_UNET_CONV_FP16 5         /* BASELINE config 5's arithmetic: the same kernels with IEEE half operands
-                                       (v_mfma_f32_32x32x16_f16), fp32 accumulate */
+                                       (v_mfma_f32_16x16x32_f16), fp32 accumulate */
 #define MI_UNET_CONV_DEFAULT MI_UNET_CONV_WINOGRAD
 
 /* Fills *cfg with the reference's constants: 512x512x1, base 64, 4 levels, 3 classes, max_batch 16, device 0. */

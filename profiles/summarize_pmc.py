@@ -7,7 +7,7 @@ per-kernel summary that bench.py quotes in its `roofline` object:
                               stores.  Both calibrate on this workload's known-byte kernels (conv3x3_first writes exactly
                               1 GiB at batch 16).
   SQ_VALU_MFMA_BUSY_CYCLES -> matrix-pipe busy fraction.  The counter adds the issue cycles of every MFMA on every SIMD
-                              (64 per v_mfma_f32_32x32x2_f32, 32 per v_mfma_f32_16x16x4_f32 and per 32x32x16 bf16 --
+                              (64 per v_mfma_f32_32x32x2_f32, 32 per v_mfma_f32_16x16x4_f32 and per 32x32x16 bf16, 16 per 16x16x32 bf16 --
                               checked against instruction counts of kernels whose MFMA count is known), so
                               mfma_busy = cycles / (1024 SIMDs x launch duration x 2.4 GHz), the launch duration taken from
                               the same pass's dispatch timestamps -- the fraction of the NOMINAL peak, comparable with

@@ -100,12 +100,12 @@ inline int convT_taps_cpad(int cout) { return (cout + NPAD - 1) / NPAD * NPAD; }
 long long convT_taps_grid(const ConvArgs &a);
 hipError_t launch_convT2x2_taps(const ConvArgs &a, hipStream_t s);
 
-// BASELINE config 3: bf16 operands, fp32 accumulate on v_mfma_f32_32x32x16_bf16.  Activations are bf16 in HBM too (rounded
+// BASELINE config 3: bf16 operands, fp32 accumulate on v_mfma_f32_16x16x32_bf16 (lpr_common.h: the shape the chip clocks highest).  Activations are bf16 in HBM too (rounded
 // once, RNE, by the kernel that produces them); a.wpk holds bf16 weights packed [Cin/32][taps][CoutPad][32].
 constexpr int KC_BF16 = 32;
 hipError_t launch_conv3x3_bf16(const ConvArgs &a, hipStream_t s);
 hipError_t launch_convT2x2_bf16(const ConvArgs &a, hipStream_t s);
-// the same kernels on v_mfma_f32_32x32x16_f16 (BASELINE config 5's arithmetic); a.wpk holds IEEE half weights, same packing
+// the same kernels on v_mfma_f32_16x16x32_f16 (BASELINE config 5's arithmetic); a.wpk holds IEEE half weights, same packing
 hipError_t launch_conv3x3_fp16(const ConvArgs &a, hipStream_t s);
 hipError_t launch_convT2x2_fp16(const ConvArgs &a, hipStream_t s);
 // The wide layers (Cout % 128 == 0) of the same pipelines on a 4 x 4 register tile per wave (conv_lp2.hip): half the LDS bytes
