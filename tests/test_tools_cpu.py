@@ -86,10 +86,10 @@ def test_lds_layouts_of_the_16bit_kernels_are_conflict_free():
     counters of profiles/r03_ab_lds_swizzle.txt agree with both)."""
     sys.path.insert(0, os.path.join(ROOT, "tools", "dev"))
     import lds_bank_model as m
-    for name, fn in m.SHIPPED_16BIT.items():
+    for name, fn in list(m.SHIPPED_16BIT.items()) + list(m.SHIPPED_FP32.items()):
         mean, worst = fn()
         assert mean == 4.0 and worst == 4, (name, mean, worst)
-    assert m.round2_frag32_rows2() == (8.0, 8) and m.round2_frag32_row1() == (8.0, 8)
+    assert m.round2_frag32_rows2() == (8.0, 8) and m.round2_frag32_row1() == (8.0, 8) and m.round2_wino4_v() == (8.0, 8)
     # the kernels' permutation is the model's: one source line each
     src = open(os.path.join(ROOT, "unet-medical-image-contour-segmentation-cpp_amd", "csrc", "lpr_common.h")).read()
     assert "lds_swz_row16(int col) { return 2 * ((col >> 2) & 1); }" in src

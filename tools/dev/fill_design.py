@@ -119,10 +119,11 @@ out["R03_LP_TABLES"] = (lp_table(LB, f"Config 3, batch 16 per launch (`profiles/
                         + f"\n\nCounters (`profiles/{tag}_pmc_fp16.json`): " + pmc_line("pmc_fp16.json") + ".")
 kb = [x for x in LB if x[1].endswith("16k")][0]
 kf = [x for x in LF if x[1].endswith("16k")][0]
-out["R03_LPRK_RESULT"] = (f"Same card (`profiles/r03_ab_role_branches_and_lprk.txt`): config 3 `up4.c1` 0.668 → 0.631 ms (this profile run: {kb[2]:.3f} ms = {kb[3]:.0f} TFLOP/s, "
-                          f"{kb[4] / 1e3:.1f} TB/s algorithmic; config 5's 128 → 64 layer {kf[2]:.3f} ms) — off the 2×2 kernel, but only 5 % faster, and the counters say why: every MFMA of this "
-                          "layer needs a fresh 1 KB A fragment from LDS (weights of TWO channel blocks would have to be resident to use a fragment twice: 288 registers again), i.e. 4 SIMDs × 1 KB per 32 cycles "
-                          "= 128 B/clk = the LDS's whole bandwidth, shared with the 52 KB-per-tile DMA writes and the exchange; `SQ_VALU_MFMA_BUSY` 0.41.  The layer is LDS-bound at K = 128, not HBM- or MFMA-bound.")
+out["R03_LPRK_RESULT"] = (f"This profile run: config 3 `up4.c1` {kb[2]:.3f} ms = {kb[3]:.0f} TFLOP/s, {kb[4] / 1e3:.1f} TB/s algorithmic (round 2 on the 2×2 kernel: 0.668 ms; "
+                          f"on 32×32×16: 0.631); config 5's 128 → 64 layer {kf[2]:.3f} ms.")
+out["R03_C3"] = f"{cfg['bf16']['value']:.0f}"
+out["R03_C3TF"] = f"{cfg['bf16']['roofline']['whole_net_algorithmic_tflops']:.0f}"
+out["R03_C5"] = f"{cfg['fp16']['value']:.0f}"
 out["R03_DIST"] = (f"{dist['value']:.0f} images/s weak at one rank with the RCCL gather in the timed loop; configs[3] strong loop {c4.get('value', 0):.0f} images/s at one rank, "
                    f"gathered label maps verified; `group`: {b['group']['runs'][0]['host_gather']['images_per_s']:.0f} images/s from host buffers in one process, "
                    f"{b['group']['runs'][1]['host_gather']['images_per_s']:.0f} with two ranks sharing the card")

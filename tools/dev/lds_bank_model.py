@@ -101,12 +101,19 @@ def round2_frag32_row1(pw=34):
     return _mean(out)
 
 
-def wino4_v(vrow_floats=20):
+def wino4_v():
     """csrc/conv_wino4.hip / conv_wino4s.hip `v_rd` (fp32, v_mfma_f32_16x16x4_f32): lane = (tile j16 = lane & 15, channel quad
-    kq = lane >> 4), rows of VROW floats.  2-way conflicted under the real grouping; these kernels spend 12-25 % of their time
-    with the LDS array busy, so the layout was left alone."""
+    kq = lane >> 4), 64-byte rows, quad q of tile t in slot q ^ 2 ((t >> 2) & 1) (csrc/wino4_common.h: v_swz)."""
     def addr(lane):
-        return (lane & 15) * vrow_floats * 4 + 16 * (lane >> 4)
+        j, kq = lane & 15, lane >> 4
+        return j * 64 + ((kq ^ swz_row16(j)) << 4)
+    return _mean([cycles(addr)])
+
+
+def round2_wino4_v():
+    """Rounds 1-2: the same read on 80-byte padded rows ("5 t mod 16 is a bijection": for 16 consecutive lanes)."""
+    def addr(lane):
+        return (lane & 15) * 80 + 16 * (lane >> 4)
     return _mean([cycles(addr)])
 
 
@@ -114,16 +121,17 @@ SHIPPED_16BIT = {
     "conv3x3_lpr / lprk / lp2 patch fragments (16x16x32: one row x 16 columns, piece in the lane)": frag16_patch,
     "conv_mfma_bf16 patch and weight fragments, convT2x2_lpr fragments (64-byte rows)": frag16_rows64,
 }
+SHIPPED_FP32 = {"fp32 F(4x4) V fragments (64-byte rows, quads permuted)": wino4_v}
 
 
 def report():
     print("LDS cycles per ds_read_b128, mean / worst (4 = conflict-free)")
-    for name, fn in SHIPPED_16BIT.items():
+    for name, fn in list(SHIPPED_16BIT.items()) + list(SHIPPED_FP32.items()):
         m, w = fn()
         print(f"  shipped   {name:96s} {m:5.2f} / {w}")
     for name, fn in (("round 2: 32x32x16 fragments of two rows x 16 columns, slot = piece ^ ((pixel >> 1) & 3)", round2_frag32_rows2),
                      ("round 2: 32x32x16 fragments of one row x 32 columns, same slots", round2_frag32_row1),
-                     ("fp32 F(4x4) V fragments (80-byte rows; unchanged)", wino4_v)):
+                     ("rounds 1-2: fp32 F(4x4) V fragments in 80-byte padded rows", round2_wino4_v)):
         m, w = fn()
         print(f"  reference {name:96s} {m:5.2f} / {w}")
 

@@ -24,7 +24,7 @@ namespace miunet {
 //   * the raw 18x18 halo patch is staged through a double-buffered LDS image, 16 channels (64 bytes per pixel) at a
 //     time, two chunks ahead of the MFMAs, by LDS-DMA loads (no staging registers, no ds_write; one load every fourth
 //     position rather than a burst); V = B^T d B is built from it into a double-buffered LDS image
-//     [pos][tile][16 + 4 pad] (80-byte rows: 5i mod 16 is a bijection -> conflict-free ds_read_b128);
+//     [pos][tile][16] (64-byte rows, channel quads permuted for the 16-lane service groups of ds_read_b128: wino4_common.h);
 //   * the forward transform is cut by ROWS of B^T: waves 0 and 1 build two rows each (xi = 1,2 and 3,4, which share
 //     their sub-expressions), waves 2 and 3 one row each (xi = 0 and 5); every lane = (tile, channel quad); the pieces
 //     are threaded between the MFMAs of the chunk that precedes their use;
@@ -136,7 +136,7 @@ __global__ __launch_bounds__(256, 1) void conv3x3_wino4_f32(const ConvArgs a, co
     const int p_rstride = rstep * W4::RAW_ROW * WINO4_KC;
     const int xi_a = two ? (wrole == 0 ? 1 : 3) : (wrole == 2 ? 0 : 5);
     const float c_alpha = wrole == 0 ? -4.f : -1.f, c_beta = wrole == 0 ? 1.f : 2.f;
-    float *const v_wr_a = Vs + xi_a * 6 * VPOS + t_tile * VROW + 4 * t_quad;      // + buf*VBUF + nu*VPOS; row b = + 6*VPOS
+    float *const v_wr_a = Vs + xi_a * 6 * VPOS + t_tile * VROW + 4 * (t_quad ^ v_swz(t_tile));      // + buf*VBUF + nu*VPOS; row b = + 6*VPOS
     f32x4 px_[4];                             // patch column k of this lane's rows
     f32x4 cR[2][6];                           // rows of B^T d (row b only on the two-row waves)
     f32x4 e_[4];
@@ -204,7 +204,7 @@ __global__ __launch_bounds__(256, 1) void conv3x3_wino4_f32(const ConvArgs a, co
         return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(u_rsrc, u_voff + blk * 16 * WINO4_KC * 4,
                                                                               (chunk * 36 + p) * u_pos_bytes, 0));
     };
-    const float *const v_rd = Vs + j16 * VROW + 4 * kq;                       // + buf*VBUF + pos*VPOS
+    const float *const v_rd = Vs + j16 * VROW + 4 * (kq ^ v_swz(j16));                       // + buf*VBUF + pos*VPOS
 
     int c_begin = 0, nchunks = all_chunks;    // this workgroup's K range [c_begin, nchunks)
     // SPLITK: raw partial sums into this slice's slab [B][H][W][Cout]; shift, ReLU and pooling belong to the reduce kernel

@@ -12,8 +12,8 @@
 //
 // Shape.  Workgroup = 4 waves = a 16x16 block of output pixels (16 tiles of 4x4) x 64 output channels; wave w owns 16
 // channels for all 36 positions: 36 accumulators of 4 registers = 144, the whole kernel inside 256 registers
-// (__launch_bounds__(256, 2)).  LDS = ONE V image [36][16 tiles][16 + 4] (46,080 B) + ONE raw patch image
-// [18 rows][20 slots][16 channels] (23,552 B) = 69,632 B, twice per CU.  A K-chunk of 16 input channels is three phases:
+// (__launch_bounds__(256, 2)).  LDS = ONE V image [36][16 tiles][16] (36,864 B) + ONE raw patch image
+// [18 rows][20 slots][16 channels] (23,552 B) = 60,416 B, twice per CU.  A K-chunk of 16 input channels is three phases:
 //      wait for the chunk's raw patch (LDS-DMA, vmcnt) | barrier | forward transform raw -> V | barrier |
 //      144 MFMAs per wave, with the DMA of the NEXT chunk's patch and the U ring (16-byte buffer loads, three positions
 //      ahead) issued between them
@@ -31,9 +31,9 @@ namespace miunet {
 
 struct W4S {
     static constexpr int HEAD_ROW = 64 + 4;                 // floats per pixel of the head's LDS tile (conflict-free b128 rows)
-    static constexpr size_t LDS_BYTES = sizeof(float) * (W4::VBUF + W4::RAW_FLOATS);          // 69,632
-    static constexpr size_t LDS_BYTES_HEAD = sizeof(float) * (256 * HEAD_ROW + 4 * 64);       // the head tile reuses all of it + its weights
-    static_assert(sizeof(float) * 256 * HEAD_ROW <= LDS_BYTES, "head tile must fit the V + raw region");
+    static constexpr size_t LDS_BYTES = sizeof(float) * (W4::VBUF + W4::RAW_FLOATS);          // 60,416
+    static constexpr size_t LDS_BYTES_HEAD = sizeof(float) * (256 * HEAD_ROW + 4 * 64);       // the head tile (larger than V + raw) + its weights
+    static_assert(LDS_BYTES <= sizeof(float) * 256 * HEAD_ROW, "the head launch's allocation must cover the K loop's V + raw images");
 };
 
 // UD = U prefetch distance in positions (36 % UD == 0).  The ring is carried across the chunk boundary: its first UD loads of
@@ -100,7 +100,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wino4s_f32(const ConvArgs a, c
     const int p_rstride = rstep * W4::RAW_ROW * WINO4_KC;
     const int xi_a = two ? (wave == 0 ? 1 : 3) : (wave == 2 ? 0 : 5);
     const float c_alpha = wave == 0 ? -4.f : -1.f, c_beta = wave == 0 ? 1.f : 2.f;
-    float *const v_wr_a = Vs + xi_a * 6 * VPOS + t_tile * VROW + 4 * t_quad;      // + nu*VPOS; row b = + 6*VPOS
+    float *const v_wr_a = Vs + xi_a * 6 * VPOS + t_tile * VROW + 4 * (t_quad ^ v_swz(t_tile));      // + nu*VPOS; row b = + 6*VPOS
     auto transform = [&]() {
         f32x4 cR[2][6];                       // rows of B^T d (row b only on the two-row waves)
 #pragma unroll
@@ -147,7 +147,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wino4s_f32(const ConvArgs a, c
     auto u_load = [&](int chunk, int p) {
         return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(u_rsrc, u_voff, (chunk * 36 + p) * u_pos_bytes, 0));
     };
-    const float *const v_rd = Vs + j16 * VROW + 4 * kq;                       // + pos*VPOS
+    const float *const v_rd = Vs + j16 * VROW + 4 * (kq ^ v_swz(j16));                       // + pos*VPOS
 
     // the loads that open the tile: the raw patch of chunk 0 straight into LDS, then the U ring
 #pragma unroll
