@@ -8,7 +8,14 @@
 // 64 MFMAs, and the weights do not go through LDS at all -- all four waves of a workgroup need the same weight fragments, but
 // they are small and hot (one kernel's worth per 32 input channels: 72 KB), so every lane loads its 16-byte fragment straight
 // from L1/L2 with a buffer load whose (chunk, tap) displacement is a scalar offset -- the U ring of the fp32 Winograd kernels
-// -- three groups (96 MFMAs) ahead.  LDS carries only the input patch: 8 reads per 64 MFMAs and wave.
+// -- SIX groups (192 MFMAs = 3 072 cycles) ahead.  LDS carries only the input patch: 8 reads per 64 MFMAs and wave.
+//
+// What the K loop waits for (timing-only builds, same card, profiles/r03_ab_lp2_k_loop.txt): without the patch DMA inside the loop
+// config 3's step is 5 % shorter, without the weight refills 8 %, without both 10 % -- a wave's vmcnt counts its loads IN ORDER, so a wait
+// for a weight fragment is also a wait for every patch DMA issued before it (HBM latency against a ring lead of three groups = 1 536
+// cycles in round 2).  A ring of six groups: config 3 +2.8 %, config 5 +1.6 % (nine: no better); it fits since the accumulators are
+// pinned in AGPRs (96 of the 256 VGPRs).  The rest of that 10 % needs the operand streams off the MFMA waves' own counters (loader
+// waves, or weights staged through LDS for the whole workgroup): next round.
 //
 // The MFMA shape.  Under dense 16-bit MFMA work the chip holds its clock down (1.7-1.9 GHz on these layers against 2.4
 // nominal: `clock_ghz_from_sq_busy` of the bench), so cycles saved by a tighter issue stream come back only partly as wall time
@@ -27,7 +34,8 @@
 //   one MFMA contracts a tap's whole 32-channel chunk: lane (i16 = lane & 15, kq = lane >> 4) supplies the pixel's / the output
 //        channel's input channels 8 kq .. + 8 -- piece kq of the pixel's 64 bytes, one ds_read_b128 / buffer load;
 //   a group is (tap, channel half): 4 weight fragments x the tap's 8 patch fragments = 32 MFMAs; the patch fragments are
-//        refilled one by one right after their last use in the tap's second group (28 MFMAs ahead of their next use).
+//        refilled one by one right after their last use in the tap's second group (28 MFMAs ahead of their next use); the weight
+//        ring is six groups deep.
 // Arithmetic: the same products and the same fp32 accumulation chain as conv_mfma_bf16 (chunks in order, taps in raster order,
 // one MFMA per tap and chunk): bit-identical results; same epilogue semantics: + folded-BN shift, ReLU, one
 // round-to-nearest-even to the 16-bit output, optional fused 2x2 max pooling (each wave holds rows 4w .. 4w+3: both row pairs
@@ -63,13 +71,17 @@ __device__ __forceinline__ void mfma_lp2s(f32x4 &c, Lp2Vec<_Float16>::x8 a, Lp2V
     asm volatile("v_mfma_f32_16x16x32_f16 %0, %1, %2, %0" : "+a"(c) : "v"(a), "v"(b));
 }
 
-template <typename T, bool OUT_LP>
+// EXP != 0: timing-only experiment builds (MIUNET_LP2_EXP; results are WRONG, never routed by default; DESIGN 5.1 "what the K loop
+// of the wide kernel waits for"): 1 = no patch DMA inside the K loop (every chunk multiplies chunk 0's patch), 2 = the weight ring
+// is never refilled, 3 = both
+template <typename T, bool OUT_LP, int EXP = 0, int WD = 6>
 __global__ __launch_bounds__(256, 1) void conv3x3_lp2(const ConvArgs a, const int tiles_x, const int tiles_y,
                                                        const int m_tiles, const int nwg)
 {
     typedef typename Lp2Vec<T>::x8 x8;
     constexpr int ROW = LP2::ROW, PW = LP2::PW, MT = LP2::MT, BN = 128, TH = LP2::TH;
-    constexpr int MB = 2 * MT, NB = BN / 16, WD = 3;         // 8 pixel blocks x 8 channel blocks per wave; weight ring depth in groups
+    constexpr int MB = 2 * MT, NB = BN / 16;                 // 8 pixel blocks x 8 channel blocks per wave; WD = weight ring depth in groups
+    static_assert(18 % WD == 0, "the ring depth must divide the groups of a chunk");
     extern __shared__ __attribute__((aligned(16))) float lds[];
     T *const As = reinterpret_cast<T *>(lds);                // [2][NPIX][ROW]
 
@@ -160,7 +172,9 @@ __global__ __launch_bounds__(256, 1) void conv3x3_lp2(const ConvArgs a, const in
 #pragma unroll
         for (int g = 0; g < 18; ++g) {
             const int tap = g >> 1, jh = g & 1;
-            if (more && g < DMA_ITERS) dma_a(chunk + 1, abuf ^ 1, g);      // the next patch, one load per group
+            // the next patch, one load per group from the chunk's first group on (two per group in its first five groups, or one per
+            // group in its last ten, measured the same or 1 % slower: profiles/r03_ab_lp2_k_loop.txt)
+            if (more && g < DMA_ITERS && !(EXP & 1)) dma_a(chunk + 1, abuf ^ 1, g);
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int mb = 0; mb < MB; ++mb) {
@@ -171,9 +185,11 @@ __global__ __launch_bounds__(256, 1) void conv3x3_lp2(const ConvArgs a, const in
                     __builtin_amdgcn_sched_barrier(0);
                 }
             }
-            const int gn = g + WD;                // refill the ring slot three groups ahead (into the next chunk at the end)
+            const int gn = g + WD;                // refill the ring slot WD groups ahead (into the next chunk at the end)
+            if constexpr (!(EXP & 2)) {
 #pragma unroll
-            for (int jj = 0; jj < 4; ++jj) wf[g % WD][jj] = w_load(gn < 18 ? chunk : nxt, gn % 18, jj);
+                for (int jj = 0; jj < 4; ++jj) wf[g % WD][jj] = w_load(gn < 18 ? chunk : nxt, gn % 18, jj);
+            }
             __builtin_amdgcn_sched_barrier(0);
         }
         __builtin_amdgcn_s_waitcnt(0x0F70 | ((WD * 4) & 15) | (((WD * 4) >> 4) << 14));    // this wave's patch loads have landed
@@ -303,9 +319,16 @@ static hipError_t launch_lp2_cfg(const ConvArgs &a, hipStream_t s)
     const int tiles_x = (a.W + 31) / 32, tiles_y = (a.H + LP2::TH - 1) / LP2::TH;
     const int m_tiles = tiles_x * tiles_y * a.B;
     const int nwg = m_tiles * ((a.Cout + 127) / 128);
-    auto kern = conv3x3_lp2<T, OUT_LP>;
-    if (hipError_t e = ensure_dynamic_lds(kern, LP2::LDS_BYTES); e != hipSuccess) return e;
-    hipLaunchKernelGGL(kern, dim3(nwg), dim3(256), LP2::LDS_BYTES, s, a, tiles_x, tiles_y, m_tiles, nwg);
+    static const int exp = [] { const char *e = getenv("MIUNET_LP2_EXP"); return e ? atoi(e) : 0; }();      // timing-only builds (see the kernel)
+    auto launch = [&](auto kern) {
+        if (hipError_t e = ensure_dynamic_lds(kern, LP2::LDS_BYTES); e != hipSuccess) return e;
+        hipLaunchKernelGGL(kern, dim3(nwg), dim3(256), LP2::LDS_BYTES, s, a, tiles_x, tiles_y, m_tiles, nwg);
+        return hipSuccess;
+    };
+    static const int wd = [] { const char *e = getenv("MIUNET_LP2_WD"); return e ? atoi(e) : 6; }();           // A/B: =3, the ring depth of round 2
+    hipError_t e = exp == 1 ? launch(conv3x3_lp2<T, OUT_LP, 1>) : exp == 2 ? launch(conv3x3_lp2<T, OUT_LP, 2>)
+                 : exp == 3 ? launch(conv3x3_lp2<T, OUT_LP, 3>) : wd == 3 ? launch(conv3x3_lp2<T, OUT_LP, 0, 3>) : launch(conv3x3_lp2<T, OUT_LP, 0>);
+    if (e != hipSuccess) return e;
     return hipGetLastError();
 }
 
