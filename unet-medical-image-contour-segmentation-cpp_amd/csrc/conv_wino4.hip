@@ -53,6 +53,9 @@ __device__ __forceinline__ void mfma16_vgpr(f32x4 &acc, const float a, const flo
 // EXP = 5 (correct results): the two-block kernel PERSISTENT -- one workgroup per CU walks its XCD's tiles, the raw-patch DMA of
 // tile T+1 is issued before the epilogue of tile T, its U ring after it (hipcc spills 33 loop-invariant registers around the tile
 // loop; reloaded once per tile, outside the K loop).
+#ifndef W4_UD2
+#define W4_UD2 6                              // U ring depth of the two-block kernel in positions (A/B builds: -DW4_UD2=9, 12, 18)
+#endif
 template <int NB, bool HEAD, bool SPLITK, int EXP = 0>
 __global__ __launch_bounds__(256, 1) void conv3x3_wino4_f32(const ConvArgs a, const int tiles_x, const int tiles_y,
                                                             const int m_tiles, const int nwg)
@@ -60,7 +63,7 @@ __global__ __launch_bounds__(256, 1) void conv3x3_wino4_f32(const ConvArgs a, co
     constexpr int VROW = W4::VROW, VPOS = W4::VPOS, VBUF = W4::VBUF;
     constexpr int HEAD_ROW = 64 + 4;          // floats per pixel of the head's LDS tile (conflict-free b128 rows)
     static_assert(!HEAD || NB == 1, "the fused head needs every channel of a pixel in one workgroup");
-    constexpr int UD = NB == 1 ? 9 : 6;       // U prefetch distance in positions (36 % UD == 0); the one-block variant has registers to spare
+    constexpr int UD = NB == 1 ? 9 : W4_UD2;  // U prefetch distance in positions (36 % UD == 0); the one-block variant has registers to spare
     extern __shared__ __attribute__((aligned(16))) float lds[];
     float *const Vs = lds;                    // [2][36][16][VROW]
     float *const Raw = lds + 2 * VBUF;        // [2][18 rows][20 slots][16]: the input halo patch of one 16-channel chunk, double-buffered
