@@ -37,10 +37,18 @@ struct W4S {
 };
 
 // UD = U prefetch distance in positions (36 % UD == 0).  The ring is carried across the chunk boundary: its first UD loads of
-// chunk c+1 fly during the barriers and the transform of that chunk, at 4 UD live registers there.  UD = 3 is the deepest
-// ring that compiles without spills next to the transform's temporaries; refilling a deeper ring (6, 9) AFTER the transform
-// instead was measured 15-40 % slower on these layers (spills, and the refill's latency at the head of every MFMA phase).
-template <bool HEAD, int UD>
+// chunk c+1 fly during the barriers and the transform of that chunk, at 4 UD live registers there.  Round 3 priced the K loop's
+// operand streams with timing-only builds (EXP below, profiles/r03_ab_wino4s_k_loop.txt): never refilling the U ring makes these
+// layers 15-25 % faster, no patch DMA inside the loop 12-20 % -- a ring of three positions is 384 cycles of lead against an L2
+// round trip, and a wave's vmcnt counts its loads in order.  UD = 6 is the deepest ring that compiles without spills next to the
+// transform's temporaries since the branch-free role code (round 2: three): these layers -3 ... -10 %, the step 17.19 -> 16.89 ms
+// same card.  Nine and twelve positions fit only with the two-row waves building their rows one after the other (24 fewer live
+// registers, the patch column read twice): slower than six with the one-pass transform.  (Round 2: refilling a deeper ring AFTER the
+// transform instead measured 15-40 % slower -- spills, and the refill's latency at the head of every MFMA phase.)
+// EXP != 0: timing-only experiment builds (MIUNET_W4S_EXP; results are WRONG, never routed by default; switch the numeric guard off,
+// MIUNET_WINO4_GUARD=0, or it sends the whole plan to F(2x2)): 1 = the U ring is never refilled, 2 = no raw-patch DMA inside the K
+// loop, 3 = both
+template <bool HEAD, int UD, int EXP = 0>
 __global__ __launch_bounds__(256, 2) void conv3x3_wino4s_f32(const ConvArgs a, const int tiles_x, const int tiles_y,
                                                              const int m_tiles, const int nwg)
 {
@@ -101,6 +109,15 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wino4s_f32(const ConvArgs a, c
     const int xi_a = two ? (wave == 0 ? 1 : 3) : (wave == 2 ? 0 : 5);
     const float c_alpha = wave == 0 ? -4.f : -1.f, c_beta = wave == 0 ? 1.f : 2.f;
     float *const v_wr_a = Vs + xi_a * 6 * VPOS + t_tile * VROW + 4 * (t_quad ^ v_swz(t_tile));      // + nu*VPOS; row b = + 6*VPOS
+    auto column_pass = [&](const f32x4 *c, float *dst) {
+        const f32x4 e0 = c[4] - 4.f * c[2], e1 = c[3] - 4.f * c[1], e2 = pk_sub(c[4], c[2]), e3 = pk_sub(c[3], c[1]);
+        *reinterpret_cast<f32x4 *>(dst + 0 * VPOS) = 4.f * c[0] - 5.f * c[2] + c[4];
+        *reinterpret_cast<f32x4 *>(dst + 1 * VPOS) = e0 + e1;
+        *reinterpret_cast<f32x4 *>(dst + 2 * VPOS) = pk_sub(e0, e1);
+        *reinterpret_cast<f32x4 *>(dst + 3 * VPOS) = e2 + 2.f * e3;
+        *reinterpret_cast<f32x4 *>(dst + 4 * VPOS) = e2 - 2.f * e3;
+        *reinterpret_cast<f32x4 *>(dst + 5 * VPOS) = 4.f * c[1] - 5.f * c[3] + c[5];
+    };
     auto transform = [&]() {
         f32x4 cR[2][6];                       // rows of B^T d (row b only on the two-row waves)
 #pragma unroll
@@ -127,15 +144,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wino4s_f32(const ConvArgs a, c
 #pragma unroll
         for (int row = 0; row < 2; ++row) {
             if (row == 1 && !two) break;
-            const f32x4 *c = cR[row];
-            float *dst = v_wr_a + row * 6 * VPOS;
-            const f32x4 e0 = c[4] - 4.f * c[2], e1 = c[3] - 4.f * c[1], e2 = pk_sub(c[4], c[2]), e3 = pk_sub(c[3], c[1]);
-            *reinterpret_cast<f32x4 *>(dst + 0 * VPOS) = 4.f * c[0] - 5.f * c[2] + c[4];
-            *reinterpret_cast<f32x4 *>(dst + 1 * VPOS) = e0 + e1;
-            *reinterpret_cast<f32x4 *>(dst + 2 * VPOS) = pk_sub(e0, e1);
-            *reinterpret_cast<f32x4 *>(dst + 3 * VPOS) = e2 + 2.f * e3;
-            *reinterpret_cast<f32x4 *>(dst + 4 * VPOS) = e2 - 2.f * e3;
-            *reinterpret_cast<f32x4 *>(dst + 5 * VPOS) = 4.f * c[1] - 5.f * c[3] + c[5];
+            column_pass(cR[row], v_wr_a + row * 6 * VPOS);
         }
     };
 
@@ -180,13 +189,13 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wino4s_f32(const ConvArgs a, c
             f32x4 avn = av;
             if (p + 1 < 36) avn = *reinterpret_cast<const f32x4 *>(v_rd + (p + 1) * VPOS);   // V fragment one position ahead
             // one DMA load every fourth position, not a burst: 16 line misses at a time keep the VMEM queue moving
-            if (more && p % 4 == 0 && p / 4 < W4::RAW_ITERS) raw_dma_one(chunk + 1, p / 4);
+            if (more && p % 4 == 0 && p / 4 < W4::RAW_ITERS && !(EXP & 2)) raw_dma_one(chunk + 1, p / 4);
             __builtin_amdgcn_sched_barrier(0);
             const f32x4 bv = u[p % UD];
 #pragma unroll
             for (int s = 0; s < 4; ++s) acc[p] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[s], bv[s], acc[p], 0, 0, 0);
             const int pn = p + UD;                                                              // refill the ring slot
-            u[p % UD] = u_load(pn < 36 ? chunk : nxt, pn % 36);
+            if constexpr (!(EXP & 1)) u[p % UD] = u_load(pn < 36 ? chunk : nxt, pn % 36);
             av = avn;
             __builtin_amdgcn_sched_barrier(0);
         }
@@ -340,10 +349,15 @@ static hipError_t launch_wino4s_cfg(const ConvArgs &a, hipStream_t s)
     // file for its accumulators alone) would first have to win back.
     static const bool one_wg = [] { const char *e = getenv("MIUNET_WINO4S_ONE_WG"); return e && e[0] == '1'; }();
     if (one_wg) lds_bytes = 96 * 1024;
-    auto kern = conv3x3_wino4s_f32<HEAD, 3>;
-    if (hipError_t e = ensure_dynamic_lds(kern, lds_bytes); e != hipSuccess) return e;
-    hipLaunchKernelGGL(kern, dim3(nwg), dim3(256), lds_bytes, s, a, tiles_x, tiles_y, m_tiles, nwg);
-    return hipGetLastError();
+    static const int exp = [] { const char *e = getenv("MIUNET_W4S_EXP"); return e ? atoi(e) : 0; }();        // timing-only builds (see the kernel)
+    auto launch = [&](auto kern) {
+        if (hipError_t e = ensure_dynamic_lds(kern, lds_bytes); e != hipSuccess) return e;
+        hipLaunchKernelGGL(kern, dim3(nwg), dim3(256), lds_bytes, s, a, tiles_x, tiles_y, m_tiles, nwg);
+        return hipGetLastError();
+    };
+    static const int ud = [] { const char *e = getenv("MIUNET_W4S_UD"); return e ? atoi(e) : 6; }();            // A/B: =3, the ring depth of round 2
+    return exp == 1 ? launch(conv3x3_wino4s_f32<HEAD, 3, 1>) : exp == 2 ? launch(conv3x3_wino4s_f32<HEAD, 3, 2>)
+         : exp == 3 ? launch(conv3x3_wino4s_f32<HEAD, 3, 3>) : ud == 3 ? launch(conv3x3_wino4s_f32<HEAD, 3>) : launch(conv3x3_wino4s_f32<HEAD, 6>);
 }
 
 // Same contract as the one-block variant of launch_conv3x3_wino4 (a.wpk4 = U packed [Cin/16][36][CoutPad][16]); no split-K.
