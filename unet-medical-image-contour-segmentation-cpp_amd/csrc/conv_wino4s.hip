@@ -48,7 +48,11 @@ struct W4S {
 // EXP != 0: timing-only experiment builds (MIUNET_W4S_EXP; results are WRONG, never routed by default; switch the numeric guard off,
 // MIUNET_WINO4_GUARD=0, or it sends the whole plan to F(2x2)): 1 = the U ring is never refilled, 2 = no raw-patch DMA inside the K
 // loop, 3 = both
-template <bool HEAD, int UD, int EXP = 0>
+// LATE: the next chunk's raw patch is requested in the LAST six positions of the MFMA phase instead of at every fourth position from
+// the first on: a wave's vmcnt is in order, so every U fragment younger than a patch request waits for HBM with it; requested late,
+// the patch's latency falls into the wait in front of the next transform, which the co-resident workgroup's MFMAs cover
+// (inc.c2 -2 %, up4.c1 -2.8 %, the others unchanged: profiles/r03_ab_wino4s_k_loop.txt).
+template <bool HEAD, int UD, int EXP = 0, bool LATE = true>
 __global__ __launch_bounds__(256, 2) void conv3x3_wino4s_f32(const ConvArgs a, const int tiles_x, const int tiles_y,
                                                              const int m_tiles, const int nwg)
 {
@@ -177,7 +181,8 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wino4s_f32(const ConvArgs a, c
     int chunk = 0;                            // at least one chunk: a do-while has no zero-trip path to merge accumulators with
     do {
         // the patch DMA of this chunk is older than the UD youngest loads (the U ring): wait for everything but those
-        __builtin_amdgcn_s_waitcnt(0x0F70 | (UD & 15) | ((UD >> 4) << 14));
+        constexpr int LEFT = LATE ? 0 : UD;           // (late patch requests interleave with the ring's refills: wait for everything)
+        __builtin_amdgcn_s_waitcnt(0x0F70 | (LEFT & 15) | ((LEFT >> 4) << 14));
         __syncthreads();                      // every wave's part of the patch has landed; nobody reads V any more
         transform();
         __syncthreads();                      // V complete, the raw image is free again
@@ -189,7 +194,10 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wino4s_f32(const ConvArgs a, c
             f32x4 avn = av;
             if (p + 1 < 36) avn = *reinterpret_cast<const f32x4 *>(v_rd + (p + 1) * VPOS);   // V fragment one position ahead
             // one DMA load every fourth position, not a burst: 16 line misses at a time keep the VMEM queue moving
-            if (more && p % 4 == 0 && p / 4 < W4::RAW_ITERS && !(EXP & 2)) raw_dma_one(chunk + 1, p / 4);
+            if (more && !(EXP & 2)) {             // one DMA load per position (16 line misses at a time keep the VMEM queue moving)
+                if (!LATE && p % 4 == 0 && p / 4 < W4::RAW_ITERS) raw_dma_one(chunk + 1, p / 4);
+                if (LATE && p >= 36 - W4::RAW_ITERS) raw_dma_one(chunk + 1, p - (36 - W4::RAW_ITERS));
+            }
             __builtin_amdgcn_sched_barrier(0);
             const f32x4 bv = u[p % UD];
 #pragma unroll
@@ -355,9 +363,10 @@ static hipError_t launch_wino4s_cfg(const ConvArgs &a, hipStream_t s)
         hipLaunchKernelGGL(kern, dim3(nwg), dim3(256), lds_bytes, s, a, tiles_x, tiles_y, m_tiles, nwg);
         return hipGetLastError();
     };
-    static const int ud = [] { const char *e = getenv("MIUNET_W4S_UD"); return e ? atoi(e) : 6; }();            // A/B: =3, the ring depth of round 2
-    return exp == 1 ? launch(conv3x3_wino4s_f32<HEAD, 3, 1>) : exp == 2 ? launch(conv3x3_wino4s_f32<HEAD, 3, 2>)
-         : exp == 3 ? launch(conv3x3_wino4s_f32<HEAD, 3, 3>) : ud == 3 ? launch(conv3x3_wino4s_f32<HEAD, 3>) : launch(conv3x3_wino4s_f32<HEAD, 6>);
+    static const int ud = [] { const char *e = getenv("MIUNET_W4S_UD"); return e ? atoi(e) : 6; }();            // A/B: =3 round 2's ring and early patch requests, =60 ring of six with early requests
+    return exp == 1 ? launch(conv3x3_wino4s_f32<HEAD, 3, 1, false>) : exp == 2 ? launch(conv3x3_wino4s_f32<HEAD, 3, 2, false>)
+         : exp == 3 ? launch(conv3x3_wino4s_f32<HEAD, 3, 3, false>) : ud == 3 ? launch(conv3x3_wino4s_f32<HEAD, 3, 0, false>)
+         : ud == 60 ? launch(conv3x3_wino4s_f32<HEAD, 6, 0, false>) : launch(conv3x3_wino4s_f32<HEAD, 6>);
 }
 
 // Same contract as the one-block variant of launch_conv3x3_wino4 (a.wpk4 = U packed [Cin/16][36][CoutPad][16]); no split-K.
