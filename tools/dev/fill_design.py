@@ -148,6 +148,7 @@ out["R03_SINGLE"] = (f"Mean over 16 files of 2048×1536: **{fs['single_image_ms'
                      "3.7–4.3 ms by run (the overlay PNG's sixteen deflate threads are the noisy term).")
 out["R03_SINGLE_SHORT"] = f"10.6 → {fs['single_image_ms']:.1f} ms per 2048×1536 file"
 out["R03_STEP"] = f"{b['ms_per_step']:.2f}"
+out["R03_FP32"] = f"{b['value']:.0f}"
 out["R03_SEG"] = f"{d1['images_per_s']:.0f} images/s against the network's {b['value']:.0f}"
 
 p_ = os.path.join(ROOT, "DESIGN.md")
