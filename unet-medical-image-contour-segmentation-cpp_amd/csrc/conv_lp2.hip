@@ -313,6 +313,188 @@ __global__ __launch_bounds__(256, 1) void conv3x3_lp2(const ConvArgs a, const in
     }
 }
 
+// --------------------------------------------------------------------------------------------------------------------
+// conv3x3_lp2n -- the same workgroup tile with the CHANNELS, not the rows, split over the four waves: the kernel the wide layers
+// run on (16-bit outputs with 16-byte aligned channel offsets; anything else, and MIUNET_LP2_NSPLIT=0, takes conv3x3_lp2).  Same
+// card, round 3 (profiles/r03_ab_lp2_k_loop.txt block 4): every wide layer 2-10 % faster.  Why: the timing-only builds of conv3x3_lp2 say
+// its largest in-loop wait is for the weight fragments, which each of its four waves fetches in full (8 per tap).  Here wave w
+// owns channels 32 w .. + 32 of all 16 rows x 32 columns (32 pixel blocks x 2 channel blocks: the same 256 accumulator registers):
+// 2 weight fragments per tap and wave -- a quarter of the L1 / L2 traffic -- and a ring NINE taps deep in 72 registers, i.e. one
+// whole chunk (9 216 cycles) of lead, beyond any patch DMA's latency in the wave's in-order vmcnt.  The price is on the LDS side:
+// every wave reads every patch fragment (32 per tap and wave instead of 8; 128 B/clk per CU of the LDS's 256, conflict-free).
+template <typename T, int AD = 8>
+__global__ __launch_bounds__(256, 1) void conv3x3_lp2n(const ConvArgs a, const int tiles_x, const int tiles_y,
+                                                        const int m_tiles, const int nwg)
+{
+    typedef typename Lp2Vec<T>::x8 x8;
+    typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+    constexpr int ROW = LP2::ROW, PW = LP2::PW, BN = 128, TH = LP2::TH, TROW = 40;
+    constexpr int MB = 2 * TH, WT = 9;                       // 32 pixel blocks (row m >> 1, column half m & 1); weight ring in taps; AD = patch-fragment ring
+    static_assert(288 % AD == 0, "the fragment ring must divide a chunk's 288 fragments");       // (4 and 16 measured the same as 8)
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    T *const As = reinterpret_cast<T *>(lds);                // [2][NPIX][ROW]
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int i16 = lane & 15, kq = lane >> 4;
+
+    const int L = xcd_remap(blockIdx.x, nwg);
+    const int n_tile = L / m_tiles;
+    int m = L - n_tile * m_tiles;
+    const int tx = m % tiles_x; m /= tiles_x;
+    const int ty = m % tiles_y;
+    const int b = m / tiles_y;
+    const int x0 = tx * 32, y0 = ty * TH, c0 = n_tile * BN + 32 * wave;       // this wave's first output channel
+    const T *in_img = reinterpret_cast<const T *>(a.in) + (size_t)b * a.H * a.W * a.ldc;
+
+    typedef __attribute__((address_space(3))) void *lds_ptr;
+    constexpr int DMA_ITERS = (LP2::A_LOADS + 3) / 4;
+    static_assert(DMA_ITERS == 10, "one patch load per tap and one more in the first");
+    unsigned dvoff[DMA_ITERS];
+#pragma unroll
+    for (int k = 0; k < DMA_ITERS; ++k) {
+        const int i = wave + 4 * k;
+        const int p = 16 * i + (lane >> 2);
+        const int py = p / PW, px = p - py * PW;
+        const int q = (lane & 3) ^ lds_swz_row16(px);
+        const int gy = y0 - 1 + py, gx = x0 - 1 + px;
+        const bool inb = i < LP2::A_LOADS && p < LP2::NPIX && gy >= 0 && gy < a.H && gx >= 0 && gx < a.W;
+        dvoff[k] = inb ? ((unsigned)(((gy * a.W + gx) * a.ldc + 8 * q) * 2) | (unsigned)q) : 0xFFFFFFFFu;
+    }
+    const __amdgpu_buffer_rsrc_t in_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<T *>(in_img), 0, a.H * a.W * a.ldc * 2, 0x00020000);
+    auto dma_a = [&](int chunk, int buf, int k) {
+        if (wave + 4 * k < LP2::A_LOADS) {
+            const unsigned dv = dvoff[k];
+            const unsigned voff = (chunk * KC_BF16 + 8 * (int)(dv & 3u) < a.Cin) ? (dv & ~15u) : 0xFFFFFFFFu;
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(in_rsrc, (lds_ptr)(As + buf * LP2::A_ELEMS + (wave + 4 * k) * 16 * ROW), 16, voff, chunk * KC_BF16 * 2, 0, 0);
+        }
+    };
+
+    const int nchunks = (a.Cin + KC_BF16 - 1) / KC_BF16;
+    const unsigned tap_bytes = (unsigned)a.CoutPad * KC_BF16 * 2;
+    const __amdgpu_buffer_rsrc_t w_rsrc =
+        __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(a.wpk), 0, (int)((size_t)nchunks * 9 * tap_bytes), 0x00020000);
+    const unsigned w_voff = (unsigned)(((c0 + i16) * KC_BF16 + 8 * kq) * 2);
+    auto w_load = [&](int chunk, int tap, int jl) {
+        return __builtin_bit_cast(x8, __builtin_amdgcn_raw_buffer_load_b128(w_rsrc, w_voff + (unsigned)(jl * 16 * KC_BF16 * 2), (unsigned)(chunk * 9 + tap) * tap_bytes, 0));
+    };
+
+    f32x4 acc[MB][2];
+#pragma unroll
+    for (int i = 0; i < MB; ++i)
+#pragma unroll
+        for (int jl = 0; jl < 2; ++jl) acc[i][jl] = f32x4{ 0.f, 0.f, 0.f, 0.f };
+
+    unsigned aoff[3];                             // piece kq of patch pixel (row 0, column i16 + dx); patch row and column half are immediates
+#pragma unroll
+    for (int dx = 0; dx < 3; ++dx) aoff[dx] = (unsigned)((i16 + dx) * 64 + ((kq ^ lds_swz_row16(i16 + dx)) << 4));
+#pragma unroll
+    for (int k = 0; k < DMA_ITERS; ++k) dma_a(0, 0, k);
+    x8 wf[WT][2];
+#pragma unroll
+    for (int t = 0; t < WT; ++t)
+#pragma unroll
+        for (int jl = 0; jl < 2; ++jl) wf[t][jl] = w_load(0, t, jl);
+    __builtin_amdgcn_s_waitcnt(0x0F70 | ((WT * 2) & 15) | (((WT * 2) >> 4) << 14));      // the patch is older than the ring
+    __syncthreads();
+    for (int chunk = 0; chunk < nchunks; ++chunk) {
+        const int abuf = chunk & 1;
+        const bool more = chunk + 1 < nchunks;
+        const int nxt = more ? chunk + 1 : chunk;                          // the last chunk prefetches itself: straight-line code
+        const unsigned abase = (unsigned)(abuf * LP2::A_ELEMS * 2);
+        auto read_a = [&](int q) {                // fragment q = 32 tap + m of the chunk
+            const int tap = q >> 5, mb = q & 31, dy = tap / 3, dx = tap - 3 * dy;
+            return *reinterpret_cast<const x8 *>(reinterpret_cast<const char *>(As) + (abase + aoff[dx]) + (((mb >> 1) + dy) * PW * 64 + (mb & 1) * 1024));
+        };
+        x8 af[AD];
+#pragma unroll
+        for (int q = 0; q < AD; ++q) af[q] = read_a(q);
+#pragma unroll
+        for (int tap = 0; tap < 9; ++tap) {
+            if (more) {                           // the next patch: one load per tap (two in the first)
+                dma_a(chunk + 1, abuf ^ 1, tap);
+                if (tap == 0) dma_a(chunk + 1, abuf ^ 1, 9);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int mb = 0; mb < MB; ++mb) {
+                const int q = 32 * tap + mb;
+#pragma unroll
+                for (int jl = 0; jl < 2; ++jl) mfma_lp2s(acc[mb][jl], af[q % AD], wf[tap][jl]);
+                if (q + AD < 288) af[q % AD] = read_a(q + AD);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+#pragma unroll
+            for (int jl = 0; jl < 2; ++jl) wf[tap][jl] = w_load(nxt, tap, jl);             // this tap of the next chunk: nine taps ahead
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        // this wave's patch loads are older than the two youngest weight loads: landed
+        __builtin_amdgcn_s_waitcnt(0x0F70 | 2);
+        __syncthreads();
+    }
+
+    // ---- epilogue: + shift, ReLU, 16-bit rounding; a row's 32 pixels x this wave's 32 channels through the wave's LDS tile, 16-byte stores
+    const __amdgpu_buffer_rsrc_t out_rsrc = __builtin_amdgcn_make_buffer_rsrc(
+        reinterpret_cast<T *>(a.out) + (size_t)b * a.H * a.W * a.ldo, 0, (int)((size_t)a.H * a.W * a.ldo * 2), 0x00020000);
+    const bool do_pool = a.pool_out != nullptr;
+    const int Hp = a.H >> 1, Wp = a.W >> 1;
+    const __amdgpu_buffer_rsrc_t pool_rsrc = __builtin_amdgcn_make_buffer_rsrc(
+        do_pool ? reinterpret_cast<T *>(a.pool_out) + (size_t)b * Hp * Wp * a.pool_ld : reinterpret_cast<T *>(a.out), 0,
+        do_pool ? (int)((size_t)Hp * Wp * a.pool_ld * 2) : 0, 0x00020000);
+    const float relu_lo = a.relu ? 0.f : -3.402823466e+38f;
+    const bool interior = x0 + 32 <= a.W && y0 + TH <= a.H;
+    float shj[2];
+#pragma unroll
+    for (int jl = 0; jl < 2; ++jl) shj[jl] = c0 + 16 * jl + i16 < a.Cout ? a.bias[c0 + 16 * jl + i16] : 0.f;
+    T *const Ts = As + wave * (48 * TROW);       // [32 pixels][TROW] + pooled [16][TROW], wave-private
+    T *const Ps = Ts + 32 * TROW;
+    auto lds_epilogue = [&](auto interior_tag) {
+        constexpr bool INTERIOR = decltype(interior_tag)::value;
+#pragma unroll
+        for (int i = 0; i < TH; ++i) {
+#pragma unroll
+            for (int h = 0; h < 2; ++h)
+#pragma unroll
+                for (int jl = 0; jl < 2; ++jl)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r)
+                        Ts[(16 * h + 4 * kq + r) * TROW + 16 * jl + i16] = (T)fmaxf(acc[2 * i + h][jl][r] + shj[jl], relu_lo);
+            if (do_pool && (i & 1)) {
+#pragma unroll
+                for (int h = 0; h < 2; ++h)
+#pragma unroll
+                    for (int jl = 0; jl < 2; ++jl)
+#pragma unroll
+                        for (int r = 0; r < 4; r += 2) {
+                            const f32x4 &u = acc[2 * (i - 1) + h][jl], &v = acc[2 * i + h][jl];
+                            const float mx = fmaxf(fmaxf(u[r], u[r + 1]), fmaxf(v[r], v[r + 1]));
+                            Ps[(8 * h + 2 * kq + (r >> 1)) * TROW + 16 * jl + i16] = (T)fmaxf(mx + shj[jl], relu_lo);
+                        }
+            }
+#pragma unroll
+            for (int it = 0; it < 2; ++it) {
+                const int e = lane + 64 * it, mm = e >> 2, q = e & 3;
+                const u32x4 v = *reinterpret_cast<const u32x4 *>(Ts + mm * TROW + 8 * q);
+                const bool ok = (INTERIOR || (y0 + i < a.H && x0 + mm < a.W)) && c0 + 8 * q < a.Cout;
+                __builtin_amdgcn_raw_buffer_store_b128(v, out_rsrc,
+                    ok ? (unsigned)((((y0 + i) * a.W + x0 + mm) * a.ldo + a.co_off + c0 + 8 * q) * 2) : 0xFFFFFFFFu, 0, 0);
+                wide_store_guard();
+            }
+            if (do_pool && (i & 1)) {
+                const int mm = lane >> 2, q = lane & 3;
+                const u32x4 v = *reinterpret_cast<const u32x4 *>(Ps + mm * TROW + 8 * q);
+                const bool ok = (INTERIOR || (y0 + i < a.H && x0 + 2 * mm + 1 < a.W)) && c0 + 8 * q < a.Cout;
+                __builtin_amdgcn_raw_buffer_store_b128(v, pool_rsrc,
+                    ok ? (unsigned)(((((y0 + i) >> 1) * Wp + (x0 >> 1) + mm) * a.pool_ld + c0 + 8 * q) * 2) : 0xFFFFFFFFu, 0, 0);
+                wide_store_guard();
+            }
+        }
+    };
+    if (interior) lds_epilogue(std::true_type{});
+    else lds_epilogue(std::false_type{});
+}
+
 template <typename T, bool OUT_LP>
 static hipError_t launch_lp2_cfg(const ConvArgs &a, hipStream_t s)
 {
@@ -323,13 +505,18 @@ static hipError_t launch_lp2_cfg(const ConvArgs &a, hipStream_t s)
     auto launch = [&](auto kern) {
         if (hipError_t e = ensure_dynamic_lds(kern, LP2::LDS_BYTES); e != hipSuccess) return e;
         hipLaunchKernelGGL(kern, dim3(nwg), dim3(256), LP2::LDS_BYTES, s, a, tiles_x, tiles_y, m_tiles, nwg);
-        return hipSuccess;
+        return hipGetLastError();
     };
     static const int wd = [] { const char *e = getenv("MIUNET_LP2_WD"); return e ? atoi(e) : 6; }();           // A/B: =3, the ring depth of round 2
+    static const int nsplit = [] { const char *e = getenv("MIUNET_LP2_NSPLIT"); return e ? atoi(e) : 1; }();     // A/B: =0, rows split over the waves (conv3x3_lp2)
+    if constexpr (OUT_LP) {
+        if (nsplit && exp == 0 && a.Cout % 8 == 0 && a.ldo % 8 == 0 && a.co_off % 8 == 0 && (a.pool_out == nullptr || a.pool_ld % 8 == 0)) {
+            return launch(conv3x3_lp2n<T>);
+        }
+    }
     hipError_t e = exp == 1 ? launch(conv3x3_lp2<T, OUT_LP, 1>) : exp == 2 ? launch(conv3x3_lp2<T, OUT_LP, 2>)
                  : exp == 3 ? launch(conv3x3_lp2<T, OUT_LP, 3>) : wd == 3 ? launch(conv3x3_lp2<T, OUT_LP, 0, 3>) : launch(conv3x3_lp2<T, OUT_LP, 0>);
-    if (e != hipSuccess) return e;
-    return hipGetLastError();
+    return e;
 }
 
 // Which layers it takes (measured per layer at batch 16, r02): faster than the 2 x 2 kernel of conv_lp.hip from Cin = 256 up
