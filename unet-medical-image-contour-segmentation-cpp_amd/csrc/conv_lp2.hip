@@ -1,5 +1,9 @@
-// conv_lp2.hip -- the 16-bit-operand conv3x3 for the WIDE layers (Cout a multiple of 128): 128 pixels x 128 channels per wave.
-// bf16 or fp16 operands, fp32 accumulation on v_mfma_f32_16x16x32_{bf16,f16}; gfx950 only.
+// conv_lp2.hip -- the 16-bit-operand conv3x3 for the WIDE layers (Cout a multiple of 128): a workgroup of four waves owns 16 rows x 32
+// columns x 128 output channels, 256 accumulator registers per wave.  bf16 or fp16 operands, fp32 accumulation on
+// v_mfma_f32_16x16x32_{bf16,f16}; gfx950 only.  Two kernels share that tile: conv3x3_lp2 (first below: the ROWS split over the waves,
+// 4 rows x 32 columns x 128 channels per wave) and conv3x3_lp2n (further down: the CHANNELS split over the waves, 16 rows x 32 columns x
+// 32 channels per wave) -- the wide layers run on the second since round 3; the first serves fp32 outputs and unaligned channel
+// offsets, and carries the timing-only builds that led to the second.
 //
 // Why a second kernel.  conv_mfma_bf16 (conv_lp.hip) gives a wave 64 pixels x 64 channels: 8 fragment reads from LDS per 16
 // MFMAs of 16 cycles, i.e. 128 B/clk per CU of the LDS's 256 for the fragments alone, with the ds_writes of the register
