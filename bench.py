@@ -62,7 +62,7 @@ ROCPROF_NAME = {"conv3x3_wino": "miunet::conv3x3_wino_f32<*>", "conv3x3_wino16":
                 "convT2x2_mfma": "miunet::conv_mfma_f32<*>", "conv3x3_first": "miunet::conv3x3_first_kernel<*>",
                 "conv3x3_bf16": "miunet::conv_mfma_bf16<*>", "conv3x3_fp16": "miunet::conv_mfma_bf16<*>",
                 "convT2x2_bf16": "miunet::conv_mfma_bf16<*>", "convT2x2_fp16": "miunet::conv_mfma_bf16<*>",
-                "conv3x3_bf16w": "miunet::conv3x3_lp2<*>", "conv3x3_fp16w": "miunet::conv3x3_lp2<*>",
+                "conv3x3_bf16w": "miunet::conv3x3_lp2n<*>", "conv3x3_fp16w": "miunet::conv3x3_lp2n<*>",
                 "conv3x3_bf16r": "miunet::conv3x3_lpr<*>", "conv3x3_fp16r": "miunet::conv3x3_lpr<*>",
                 "conv3x3_bf16k": "miunet::conv3x3_lprk<*>", "conv3x3_fp16k": "miunet::conv3x3_lprk<*>",
                 "convT2x2_bf16r": "miunet::convT2x2_lpr<*>", "convT2x2_fp16r": "miunet::convT2x2_lpr<*>"}

@@ -82,11 +82,11 @@ rows.append(f"| **configs[1]** (the metric) | 1 | fp32 | 16 | **{b['value']:.0f}
 for key, x, bb, pmc in (("bf16", cfg.get("bf16"), bf, "pmc_bf16.json"), ("fp16", cfg.get("fp16"), fp, "pmc_fp16.json")):
     if not x:
         continue
-    pk = json.load(open(os.path.join(D, pmc)))["kernels"].get("miunet::conv3x3_lp2<*>", {})
+    pk = json.load(open(os.path.join(D, pmc)))["kernels"].get("miunet::conv3x3_lp2n<*>", {})
     name = "configs[2]" if key == "bf16" else "configs[4] (network half; the one-call pipeline half: §7)"
     batch = "128 (micro-batches of 16)" if key == "bf16" else "8 × 1024²×3"
     rows.append(f"| {name} | 1 | {key} operands / fp32 acc | {batch} | {x['value']:.0f} (profile run: {bb['value']:.0f}) | {x['ms_per_image']:.3f} | {x['roofline']['whole_net_algorithmic_tflops']:.0f} | "
-                f"`conv3x3_lp2` {x['roofline']['frac']:.3f} of 2.5 PF ({pk.get('mfma_busy', 0):.2f} busy; {pk.get('mfma_busy_at_measured_clock', 0):.2f} at the {pk.get('clock_ghz_from_sq_busy', 0):.2f} GHz it ran at) | "
+                f"`conv3x3_lp2n` {x['roofline']['frac']:.3f} of 2.5 PF ({pk.get('mfma_busy', 0):.2f} busy; {pk.get('mfma_busy_at_measured_clock', 0):.2f} at the {pk.get('clock_ghz_from_sq_busy', 0):.2f} GHz it ran at) | "
                 f"logits {x['parity']['max_abs_logit_err']:.3f} from the fp32 oracle ({x['parity']['max_abs_err_vs_16bit_oracle']:.3f} from the {key}-operand oracle), 0 label mismatches above the {x['parity']['margin']} margin; per launch: §2 |")
 c4 = (dist.get("configs") or [{}])[0]
 rows.append(f"| configs[3] | 1 of 8 (no node) | fp32 | 512 | {g512['value']:.0f} on one GPU (micro-batches of 16); one-rank RCCL rehearsal of the strong loop: {c4.get('value', 0):.0f} | {1e3 / g512['value']:.3f} | — | as configs[1] | gathered label maps verified: {c4.get('gathered_label_maps_verified')}; **N > 1 unmeasured** |")
@@ -106,7 +106,7 @@ def lp_table(rows_, title):
 def pmc_line(f):
     pk = json.load(open(os.path.join(D, f)))["kernels"]
     parts = []
-    for k in ("miunet::conv3x3_lp2<*>", "miunet::conv3x3_lpr<*>", "miunet::conv3x3_lprk<*>", "miunet::conv_mfma_bf16<*>", "miunet::convT2x2_lpr<*>"):
+    for k in ("miunet::conv3x3_lp2n<*>", "miunet::conv3x3_lpr<*>", "miunet::conv3x3_lprk<*>", "miunet::conv_mfma_bf16<*>", "miunet::convT2x2_lpr<*>"):
         v = pk.get(k)
         if v:
             parts.append(f"`{k.split('::')[1][:-3]}` {v['mfma_busy']:.2f} busy ({v.get('mfma_busy_at_measured_clock', 0):.2f} at {v.get('clock_ghz_from_sq_busy', 0):.2f} GHz), {v.get('hbm_bytes_per_launch', 0) / 1e6:.0f} MB per launch")
