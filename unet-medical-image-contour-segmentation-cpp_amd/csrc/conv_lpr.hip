@@ -64,7 +64,7 @@ struct LPR {
 // run in the order of conv_mfma_bf16's fused head (four interleaved partial sums per class, folded at the end): the same
 // logits bit for bit.  `out` is never written.
 template <typename T, int CIN, int NBT, int NBUF, int RB, bool HEAD = false>
-__global__ __launch_bounds__(512, 1) void conv3x3_lpr(const ConvArgs a, const int tiles_x, const int tiles_y, const int ntiles)
+__global__ __launch_bounds__(512, 1) void conv3x3_lpr(const ConvArgs a, const int tiles_x, const int tiles_y, const int ntiles, const int exp)
 {
     typedef typename LprVec<T>::x8 x8;
     typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
@@ -231,7 +231,8 @@ __global__ __launch_bounds__(512, 1) void conv3x3_lpr(const ConvArgs a, const in
 
     for (int n = 0; n < nt; ++n) {
         __syncthreads();                      // tile n is complete in LDS (every wave waited for its share); tile n - 1 is consumed
-        if (n + LEAD < nt) issue_dma(n + LEAD);               // ... into the slot tile n - 1 just left
+        // (exp: timing-only switches, MIUNET_LPR_EXP, results WRONG -- 1 = no patch DMA after the ring's first fill, 2 = no output stores)
+        if (n + LEAD < nt && !(exp & 1)) issue_dma(n + LEAD);      // ... into the slot tile n - 1 just left
 
         // ---- tile n: 9 taps x Cin / 16 MFMAs per row block and channel block
         const unsigned base = (unsigned)((n % NBUF) * TILE_BYTES);
@@ -365,7 +366,7 @@ __global__ __launch_bounds__(512, 1) void conv3x3_lpr(const ConvArgs a, const in
                     const int e = lane + 64 * it, m = e >> 2, q = e & 3;
                     const u32x4 v = *reinterpret_cast<const u32x4 *>(Ts + m * TROW + 8 * q);
                     unsigned voff = ovoff[mb][j][it];
-                    if (edge && !(yb + 2 * rp + (m >> 4) < a.H && x0 + 16 * (ch0 + mb) + (m & 15) < a.W)) voff = 0xFFFFFFFFu;
+                    if ((edge && !(yb + 2 * rp + (m >> 4) < a.H && x0 + 16 * (ch0 + mb) + (m & 15) < a.W)) || (exp & 2)) voff = 0xFFFFFFFFu;
                     __builtin_amdgcn_raw_buffer_store_b128(v, out_rsrc, voff, osoff + (unsigned)(8 * rb * a.W * a.ldo * 2), 0);
                     wide_store_guard();
                 }
@@ -393,7 +394,8 @@ static hipError_t launch_lpr_cfg(const ConvArgs &a, hipStream_t s)
     static_assert(lds <= 160 * 1024, "LDS of one CU");
     auto kern = conv3x3_lpr<T, CIN, NBT, NBUF, RB, HEAD>;
     if (hipError_t e = ensure_dynamic_lds(kern, lds); e != hipSuccess) return e;
-    hipLaunchKernelGGL(kern, dim3(grid), dim3(512), lds, s, a, tiles_x, tiles_y, ntiles);
+    static const int exp = [] { const char *e = getenv("MIUNET_LPR_EXP"); return e ? atoi(e) : 0; }();          // timing-only switches (see the kernel)
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(512), lds, s, a, tiles_x, tiles_y, ntiles, exp);
     return hipGetLastError();
 }
 
