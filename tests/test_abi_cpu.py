@@ -46,3 +46,44 @@ def test_null_handle_is_an_error():
     L = binding.lib()
     assert L.mi_unet_sync(None) != 0
     assert b"null engine handle" in L.mi_unet_last_error()
+
+
+def test_staging_copy_pool_copies_every_byte(tmp_path):
+    """csrc/copy_pool.h (the pageable -> pinned staging copy of the RAW-in entry points and the tiles / masks copy-out) against
+    memcpy for 2..16 parts over sizes in [1 MB, 1 MB + 64 KB]: the floored piece size of round 3 dropped the last bytes of any
+    image whose size / parts was a whole number of pages (ADVICE r03) -- a stale sample in the pinned ring then changed the
+    min/max normalisation of the whole tile."""
+    import subprocess
+
+    exe = tmp_path / "copy_pool_test"
+    subprocess.check_call(["g++", "-O1", "-std=c++17", "-pthread", "-o", str(exe), os.path.join(ROOT, "tests", "cpu", "copy_pool_test.cpp")])
+    r = subprocess.run([str(exe)], capture_output=True, timeout=300)
+    assert r.returncode == 0, r.stdout.decode()[-2000:] + r.stderr.decode()[-2000:]
+    assert b"all copy pool checks passed" in r.stdout
+
+
+def test_product_library_has_no_experiment_kernels():
+    """The reference's engine has exactly one behaviour (src/process.cpp:147).  The timing-only kernel instantiations (results
+    WRONG by design) and the environment switches that select them exist only in the lab build (`make lab`: libmiunet_exp.so,
+    -DMIUNET_EXPERIMENTS); libmiunet.so must contain neither the instantiations nor the variable names (VERDICT r03 #2)."""
+    import subprocess
+
+    so = binding.LIB_PATH
+    syms = subprocess.run(["nm", "-C", so], capture_output=True, check=True).stdout.decode()
+    bad = []
+    for line in syms.splitlines():
+        m = re.search(r"conv3x3_wino4_f32<\d+, \w+, \w+, (\d+)>", line)
+        if m and m.group(1) != "0":
+            bad.append(line)
+        m = re.search(r"conv3x3_wino4s_f32<\w+, (\d+), (\d+), (\w+)>", line)
+        if m and (m.group(2) != "0" or m.group(1) != "6" or m.group(3) != "true"):
+            bad.append(line)
+        m = re.search(r"conv3x3_lp2<.*, (\d+), (\d+)>", line)
+        if m and (m.group(1) != "0" or m.group(2) != "6"):
+            bad.append(line)
+    assert not bad, "\n".join(bad[:10])
+    assert "conv3x3_wino4_f32<2, false, false, 0>" in syms          # the check above looked at real names
+    blob = open(so, "rb").read()
+    for name in (b"MIUNET_W4_EXP", b"MIUNET_W4S_EXP", b"MIUNET_LP2_EXP", b"MIUNET_LPR_EXP", b"MIUNET_WINO4S_ONE_WG", b"MIUNET_W4S_UD",
+                 b"MIUNET_LP2_WD", b"MIUNET_LP2_NSPLIT", b"MIUNET_LP2_MINCIN", b"MIUNET_CONVT_CFG", b"MIUNET_CONVT_WPS", b"MIUNET_FIRST_RBW"):
+        assert name not in blob, name.decode()

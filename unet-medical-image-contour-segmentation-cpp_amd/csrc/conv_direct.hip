@@ -257,8 +257,11 @@ hipError_t launch_convT2x2_mfma(const ConvArgs &a, hipStream_t s)
 {
     if (a.Cin % 4 || a.ldc % 4 || a.CoutPad % NPAD) return hipErrorInvalidValue;
     // a GEMM column tile must not straddle two (dy,dx) taps unless masked per lane: co/kidx are per lane, so any Cout works
-    static int cfg = -1;
-    if (cfg < 0) { const char *e = getenv("MIUNET_CONVT_CFG"); cfg = e ? atoi(e) : 1; }
+#ifdef MIUNET_EXPERIMENTS                              // lab build only: the product library has one route per shape
+    static const int cfg = [] { const char *e = getenv("MIUNET_CONVT_CFG"); return e ? atoi(e) : 1; }();
+#else
+    constexpr int cfg = 1;
+#endif
     switch (cfg) {
     case 0: return launch_conv_cfg<1, 8, 64, 16, false>(a, s);
     case 1: return launch_conv_cfg<1, 8, 64, 16, true>(a, s);

@@ -505,21 +505,30 @@ static hipError_t launch_lp2_cfg(const ConvArgs &a, hipStream_t s)
     const int tiles_x = (a.W + 31) / 32, tiles_y = (a.H + LP2::TH - 1) / LP2::TH;
     const int m_tiles = tiles_x * tiles_y * a.B;
     const int nwg = m_tiles * ((a.Cout + 127) / 128);
-    static const int exp = [] { const char *e = getenv("MIUNET_LP2_EXP"); return e ? atoi(e) : 0; }();      // timing-only builds (see the kernel)
     auto launch = [&](auto kern) {
         if (hipError_t e = ensure_dynamic_lds(kern, LP2::LDS_BYTES); e != hipSuccess) return e;
         hipLaunchKernelGGL(kern, dim3(nwg), dim3(256), LP2::LDS_BYTES, s, a, tiles_x, tiles_y, m_tiles, nwg);
         return hipGetLastError();
     };
+#ifdef MIUNET_EXPERIMENTS                              // lab build only (libmiunet_exp.so, tools/dev/ab*.sh): never in libmiunet.so
+    static const int exp = [] { const char *e = getenv("MIUNET_LP2_EXP"); return e ? atoi(e) : 0; }();      // timing-only builds (see the kernel)
     static const int wd = [] { const char *e = getenv("MIUNET_LP2_WD"); return e ? atoi(e) : 6; }();           // A/B: =3, the ring depth of round 2
     static const int nsplit = [] { const char *e = getenv("MIUNET_LP2_NSPLIT"); return e ? atoi(e) : 1; }();     // A/B: =0, rows split over the waves (conv3x3_lp2)
+#else
+    constexpr int exp = 0, nsplit = 1;
+#endif
     if constexpr (OUT_LP) {
         if (nsplit && exp == 0 && a.Cout % 8 == 0 && a.ldo % 8 == 0 && a.co_off % 8 == 0 && (a.pool_out == nullptr || a.pool_ld % 8 == 0)) {
             return launch(conv3x3_lp2n<T>);
         }
     }
-    hipError_t e = exp == 1 ? launch(conv3x3_lp2<T, OUT_LP, 1>) : exp == 2 ? launch(conv3x3_lp2<T, OUT_LP, 2>)
-                 : exp == 3 ? launch(conv3x3_lp2<T, OUT_LP, 3>) : wd == 3 ? launch(conv3x3_lp2<T, OUT_LP, 0, 3>) : launch(conv3x3_lp2<T, OUT_LP, 0>);
+#ifdef MIUNET_EXPERIMENTS
+    if (exp == 1) return launch(conv3x3_lp2<T, OUT_LP, 1>);
+    if (exp == 2) return launch(conv3x3_lp2<T, OUT_LP, 2>);
+    if (exp == 3) return launch(conv3x3_lp2<T, OUT_LP, 3>);
+    if (wd == 3) return launch(conv3x3_lp2<T, OUT_LP, 0, 3>);
+#endif
+    hipError_t e = launch(conv3x3_lp2<T, OUT_LP, 0>);
     return e;
 }
 
@@ -535,7 +544,11 @@ bool conv3x3_lp2_takes(const ConvArgs &a)
     const long long nwg = (long long)((a.W + 31) / 32) * ((a.H + LP2::TH - 1) / LP2::TH) * a.B * (a.Cout / 128);
     // from Cin = 128 since the 16-byte-store epilogue (same card, config 3: down1.c2 0.333 -> 0.322 ms, up3.c2 0.313 -> 0.298, down2.c1
     // 0.159 -> 0.154; config 5 unchanged); MIUNET_LP2_MINCIN moves the threshold
+#ifdef MIUNET_EXPERIMENTS
     static const int min_cin = [] { const char *m = getenv("MIUNET_LP2_MINCIN"); return m ? atoi(m) : 128; }();
+#else
+    constexpr int min_cin = 128;
+#endif
     return a.Cin >= min_cin && nwg >= 192;
 }
 

@@ -64,8 +64,14 @@ struct LPR {
 // run in the order of conv_mfma_bf16's fused head (four interleaved partial sums per class, folded at the end): the same
 // logits bit for bit.  `out` is never written.
 template <typename T, int CIN, int NBT, int NBUF, int RB, bool HEAD = false>
-__global__ __launch_bounds__(512, 1) void conv3x3_lpr(const ConvArgs a, const int tiles_x, const int tiles_y, const int ntiles, const int exp)
+__global__ __launch_bounds__(512, 1) void conv3x3_lpr(const ConvArgs a, const int tiles_x, const int tiles_y, const int ntiles, const int exp_arg)
 {
+#ifdef MIUNET_EXPERIMENTS
+    const int exp = exp_arg;                  // timing-only switches of the lab build (MIUNET_LPR_EXP)
+#else
+    constexpr int exp = 0;                    // the product library has one behaviour
+    (void)exp_arg;
+#endif
     typedef typename LprVec<T>::x8 x8;
     typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
     typedef __attribute__((address_space(3))) void *lds_ptr;
@@ -394,7 +400,11 @@ static hipError_t launch_lpr_cfg(const ConvArgs &a, hipStream_t s)
     static_assert(lds <= 160 * 1024, "LDS of one CU");
     auto kern = conv3x3_lpr<T, CIN, NBT, NBUF, RB, HEAD>;
     if (hipError_t e = ensure_dynamic_lds(kern, lds); e != hipSuccess) return e;
+#ifdef MIUNET_EXPERIMENTS                              // lab build only (libmiunet_exp.so, tools/dev/ab*.sh): never in libmiunet.so
     static const int exp = [] { const char *e = getenv("MIUNET_LPR_EXP"); return e ? atoi(e) : 0; }();          // timing-only switches (see the kernel)
+#else
+    constexpr int exp = 0;
+#endif
     hipLaunchKernelGGL(kern, dim3(grid), dim3(512), lds, s, a, tiles_x, tiles_y, ntiles, exp);
     return hipGetLastError();
 }

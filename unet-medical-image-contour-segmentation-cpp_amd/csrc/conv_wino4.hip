@@ -519,6 +519,7 @@ static hipError_t launch_wino4_cfg(const ConvArgs &a0, hipStream_t s)
         hipLaunchKernelGGL(kern, dim3(grid), dim3(256), W4::LDS_BYTES, s, a, tiles_x, tiles_y, m_tiles, grid);
         return launch_wino_splitk_reduce(a, s);
     }
+#ifdef MIUNET_EXPERIMENTS                              // lab build only (libmiunet_exp.so, tools/dev/ab*.sh): never in libmiunet.so
     if constexpr (NB == 2 && !HEAD) {                  // timing-only experiment builds of the two-block kernel (see the kernel's EXP)
         static const int exp = [] { const char *e = getenv("MIUNET_W4_EXP"); return e ? atoi(e) : 0; }();
         if (exp >= 1 && exp <= 5) {
@@ -532,6 +533,7 @@ static hipError_t launch_wino4_cfg(const ConvArgs &a0, hipStream_t s)
             return hipGetLastError();
         }
     }
+#endif
     auto kern = conv3x3_wino4_f32<NB, HEAD, false>;
     if (hipError_t e = ensure_dynamic_lds(kern, W4::LDS_BYTES); e != hipSuccess) return e;
     // one-block variant: persistent, one workgroup per CU (144 KB of LDS each); two-block variant: one tile per workgroup

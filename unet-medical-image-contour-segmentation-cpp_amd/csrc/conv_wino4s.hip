@@ -355,18 +355,25 @@ static hipError_t launch_wino4s_cfg(const ConvArgs &a, hipStream_t s)
     // resident per CU -- the same kernel, same instructions, without its co-resident partner.  What that costs is what any
     // one-workgroup-per-CU re-tiling of these layers (a 32-tile block on v_mfma_f32_32x32x2_f32 needs 56 % of the register
     // file for its accumulators alone) would first have to win back.
+#ifdef MIUNET_EXPERIMENTS                              // lab build only (libmiunet_exp.so, tools/dev/ab*.sh): never in libmiunet.so
     static const bool one_wg = [] { const char *e = getenv("MIUNET_WINO4S_ONE_WG"); return e && e[0] == '1'; }();
     if (one_wg) lds_bytes = 96 * 1024;
     static const int exp = [] { const char *e = getenv("MIUNET_W4S_EXP"); return e ? atoi(e) : 0; }();        // timing-only builds (see the kernel)
+    static const int ud = [] { const char *e = getenv("MIUNET_W4S_UD"); return e ? atoi(e) : 6; }();            // A/B: =3 round 2's ring and early patch requests, =60 ring of six with early requests
+#endif
     auto launch = [&](auto kern) {
         if (hipError_t e = ensure_dynamic_lds(kern, lds_bytes); e != hipSuccess) return e;
         hipLaunchKernelGGL(kern, dim3(nwg), dim3(256), lds_bytes, s, a, tiles_x, tiles_y, m_tiles, nwg);
         return hipGetLastError();
     };
-    static const int ud = [] { const char *e = getenv("MIUNET_W4S_UD"); return e ? atoi(e) : 6; }();            // A/B: =3 round 2's ring and early patch requests, =60 ring of six with early requests
-    return exp == 1 ? launch(conv3x3_wino4s_f32<HEAD, 3, 1, false>) : exp == 2 ? launch(conv3x3_wino4s_f32<HEAD, 3, 2, false>)
-         : exp == 3 ? launch(conv3x3_wino4s_f32<HEAD, 3, 3, false>) : ud == 3 ? launch(conv3x3_wino4s_f32<HEAD, 3, 0, false>)
-         : ud == 60 ? launch(conv3x3_wino4s_f32<HEAD, 6, 0, false>) : launch(conv3x3_wino4s_f32<HEAD, 6>);
+#ifdef MIUNET_EXPERIMENTS
+    if (exp == 1) return launch(conv3x3_wino4s_f32<HEAD, 3, 1, false>);
+    if (exp == 2) return launch(conv3x3_wino4s_f32<HEAD, 3, 2, false>);
+    if (exp == 3) return launch(conv3x3_wino4s_f32<HEAD, 3, 3, false>);
+    if (ud == 3) return launch(conv3x3_wino4s_f32<HEAD, 3, 0, false>);
+    if (ud == 60) return launch(conv3x3_wino4s_f32<HEAD, 6, 0, false>);
+#endif
+    return launch(conv3x3_wino4s_f32<HEAD, 6>);
 }
 
 // Same contract as the one-block variant of launch_conv3x3_wino4 (a.wpk4 = U packed [Cin/16][36][CoutPad][16]); no split-K.

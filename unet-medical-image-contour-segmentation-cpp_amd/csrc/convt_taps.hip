@@ -224,7 +224,11 @@ static long long taps_grid(const ConvArgs &a, const TapsShape &t)
 }
 static TapsShape taps_shape(const ConvArgs &a)
 {
+#ifdef MIUNET_EXPERIMENTS                              // lab build only: the product library has one route per shape
     static const int mode = [] { const char *e = getenv("MIUNET_CONVT_WPS"); return e ? atoi(e) : 2; }();
+#else
+    constexpr int mode = 2;
+#endif
     if (mode != 2) {
         if (a.Cout > 256) return { 1, 16, 1 };
         if (a.Cout > 128) return { 2, 8, 1 };

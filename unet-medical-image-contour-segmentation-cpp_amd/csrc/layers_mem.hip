@@ -238,7 +238,11 @@ static hipError_t launch_first_mfma_t(const uint8_t *img, const float *lut256, c
 {
     // row blocks per wave: 2 (8-row tiles: 68-112 registers, five to seven waves per SIMD) measured 0.242 -> 0.223 ms on config
     // 5's first layer against 4 (16-row tiles, 116-192 registers), same card; MIUNET_FIRST_RBW=4 keeps the taller tile
+#ifdef MIUNET_EXPERIMENTS                              // lab build only: the product library has one route per shape
     static const int rbw = [] { const char *e = getenv("MIUNET_FIRST_RBW"); return (e && atoi(e) == 4) ? 4 : 2; }();
+#else
+    constexpr int rbw = 2;
+#endif
     const int tiles_x = (W + 31) / 32, tiles_y = (H + 4 * rbw - 1) / (4 * rbw);
     const long long blocks = (long long)B * tiles_x * tiles_y;
     if (blocks <= 0 || blocks > 0x7FFFFFFFLL) return hipErrorInvalidValue;
