@@ -161,6 +161,10 @@ def parity_gate(eng, blob, imgs_host, n, mode="fp32"):
     return rec, oracle_s
 
 
+VERBOSE = False               # --verbose: the per-family arrays stay in the JSON line (they always go to gpurun_out/bench_families.json)
+FAMILY_TABLES = {}
+
+
 def roofline_from_stats(stats, spec_macs, ips_per_gpu, tag):
     """Per-kernel figures of the dominant conv kernel from the engine's own per-launch event pairs."""
     by = {}
@@ -197,7 +201,8 @@ def roofline_from_stats(stats, spec_macs, ips_per_gpu, tag):
                          "frac_of_mfma_peak": fl / ms / 1e9 / r / pk, "algorithmic_gbs": by / ms / 1e6,
                          "frac_of_hbm_peak": by / ms / 1e6 / HBM_PEAK_GBS,
                          "mfma_busy_pmc": c.get("mfma_busy"), "hbm_bytes_per_launch_pmc": c.get("hbm_bytes_per_launch")})
-    return {
+    FAMILY_TABLES[tag] = families
+    rec = {
         "bound": "mfma", "kernel": f"{dom_kernel} ({insn})",
         "algorithm": {4.0: "winograd F(4x4,3x3)", 2.25: "winograd F(2x2,3x3)"}.get(red, "direct implicit GEMM"),
         # the roofline fraction: FLOPs the matrix pipe EXECUTES per second over its peak (never above 1)
@@ -211,8 +216,15 @@ def roofline_from_stats(stats, spec_macs, ips_per_gpu, tag):
         "avg_launch_gflop": dom_flops / max(1, len(dom)) / 1e9,
         "share_of_device_time": dom_ms / all_ms if all_ms else None,
         "whole_net_algorithmic_tflops": 2.0 * spec_macs * ips_per_gpu / 1e12,
-        "families": families,
     }
+    # the driver keeps only the tail of stdout: the per-family arrays (22-27 numbers each) pushed configs[2]'s value out of
+    # BENCH_r03.json.  They go to gpurun_out/bench_families.json; the line carries them only under --verbose.
+    if VERBOSE:
+        rec["families"] = families
+    else:
+        rec["families_compact"] = {f["kernel"]: [f["launches"], round(f["share_of_device_time"] or 0, 3), round(f["frac_of_mfma_peak"], 3)] for f in families}
+        rec["families_compact_columns"] = ["launches", "share_of_device_time", "executed_frac_of_mfma_peak"]
+    return rec
 
 
 def per_layer_table(stats, steps, wall_ms):
@@ -299,12 +311,20 @@ def run_pipeline(binding, synth, dev_index, nimg=16):
         tiles, masks = tiles.copy(), masks.copy()
         for pa in pins:
             pa.close()
+        # the steady state: 64 images through the same engine (micro-batches of 16), where the first chunk's exposed upload and the
+        # last chunk's exposed postprocess + contours are amortised over four network passes instead of one
+        raws64 = raws + [r.copy() for r in raws * 3]
+        dt64, stages64, (_, masks64, cont64) = timed(raws64)
+        b64_same = bool(all(np.array_equal(masks64[i], masks[i % nimg]) and cont64[i] == cont[i % nimg] for i in range(0, 64, 7)))
+        del raws64
     out["device_one_call"] = {"images_per_s": nimg / dt, "ms_per_image": dt / nimg * 1e3,
                               "contours_first_image": len(cont[0]) if cont[0] is not None else -1, "stages_ms": stages,
                               "what": "mi_unet_segment_raw16, RAW images in ordinary (pageable) host memory"}
     out["device_one_call_pinned"] = {"images_per_s": nimg / dt_p, "ms_per_image": dt_p / nimg * 1e3, "stages_ms": stages_p,
                                      "same_results": pinned_same,
                                      "what": "the same call with the RAW images in page-locked host memory (mi_unet_host_alloc)"}
+    out["device_one_call_b64"] = {"images_per_s": 64 / dt64, "ms_per_image": dt64 / 64 * 1e3, "stages_ms": stages64, "same_results": b64_same,
+                                  "what": "the same call on 64 images (the 16 above four times over), micro-batches of 16"}
     # parity of image 0 against the oracle chain, which is also the all-CPU timing sample
     t0 = time.perf_counter()
     tile0 = orc.preprocess_raw(raws[0])
@@ -386,6 +406,74 @@ def run_pipeline(binding, synth, dev_index, nimg=16):
     return out
 
 
+def run_pipeline_config5(binding, synth, dev_index, nimg=8):
+    """BASELINE configs[4] as BASELINE.json states it -- "1024x1024 3-channel input, 5-level UNet (base=32ch) fp16, fused preprocess
+    + on-device mask2polygon contour extraction" -- as ONE call: nimg images x 3 RAW16 planes 2048x1536 -> mi_unet_segment_raw16
+    on the 1024^2 x 3 fp16 engine -> tiles, masks, polygons.  Gated on exact parity of image 0 against the oracle chain (the
+    structured weights make the label maps exact under fp16 operands; tests/test_gpu_group.py::test_config5_in_one_call_...).
+    Reference seam: src/process.cpp:211-242."""
+    import numpy as np
+    from miunet.spec import UNetSpec, pack_weights
+    orc = oracle()
+    spec = UNetSpec(3, 32, 5, 3)
+    blob = pack_weights(spec, synth.make_threshold_weights(spec))
+    planes = [synth.make_raw16(1536, 2048, seed=300 + k) for k in range(3 * nimg)]
+    out = {"config": "BASELINE.json configs[4] (whole): 1024x1024x3, 5-level base 32, fp16 operands / fp32 accumulate, fused preprocess "
+                     "(three RAW16 planes 2048x1536 per image) + device postprocess + on-device mask2polygon contour extraction, one call",
+           "images": nimg, "dtype": "fp16"}
+    with binding.Engine(1024, 1024, 3, 32, 5, 3, max_batch=nimg, device=dev_index, conv_algo="fp16") as eng:
+        eng.load_weights(blob)
+        prep = eng.segment_raw16_prepare(planes, 1 << 16, 64)
+        for _ in range(2):
+            eng.segment_raw16_run(prep)
+        reps = 5
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            eng.segment_raw16_run(prep)
+        dt = (time.perf_counter() - t0) / reps
+        stages = eng.last_stage_ms()
+        tiles, masks, cont = eng.segment_raw16_decode(prep)
+        tiles, masks = tiles.copy(), masks.copy()
+    out.update({"value": nimg / dt, "unit": "images/s", "ms_per_image": dt / nimg * 1e3, "stages_ms": stages,
+                "what": "mi_unet_segment_raw16 from pageable host memory (PCIe-inclusive: 3 x 6 MB of RAW16 per image go up, a "
+                        "3 MB tile, a 1 MB mask and the contour points come back)"})
+    tile0 = np.stack([orc.preprocess_raw(planes[c], 1024, 1024) for c in range(3)], axis=-1)
+    _, lab0 = orc.unet_forward(blob, tile0[None], want_logits=False, fp16=True)
+    vis0 = orc.mask_to_image(orc.postprocess_mask(lab0[0]))
+    cont0 = orc.find_contours(vis0)
+    out["parity"] = {"tile_equal": bool(np.array_equal(tiles[0], tile0)), "mask_equal": bool(np.array_equal(masks[0], vis0)),
+                     "contours_equal": cont[0] == cont0, "contours_first_image": len(cont0), "mask_nonempty": bool(vis0.max() == 255)}
+    out["parity"]["ok"] = all(bool(v) for v in out["parity"].values())
+    return out
+
+
+def summary_of(out):
+    """the headline figures once more, compact, as the LAST key of the line (the driver keeps the tail of stdout)"""
+    s = {"configs[1]_fp32_images_per_s": round(out["value"], 1), "ms_per_step": round(out["ms_per_step"], 3),
+         "roofline_frac": round(out["roofline"]["frac"], 4), "parity_ok": (out.get("parity") or {}).get("ok")}
+    for c in out.get("configs") or []:
+        if "value" in c:
+            key = "configs[3]_strong" if "configs[3]" in c["config"] else "configs[2]_bf16" if "configs[2]" in c["config"] else "configs[4]_fp16_network"
+            s[key + "_images_per_s"] = round(c["value"], 1)
+            if "roofline" in c:
+                s[key + "_whole_net_tflops"] = round(c["roofline"]["whole_net_algorithmic_tflops"], 1)
+            if "parity" in c:
+                s[key + "_parity_ok"] = c["parity"]["ok"]
+    pc5 = out.get("pipeline_config5") or {}
+    if "value" in pc5:
+        s["configs[4]_whole_one_call_images_per_s"] = round(pc5["value"], 1)
+        s["configs[4]_whole_parity_ok"] = pc5["parity"]["ok"]
+    pl = out.get("pipeline") or {}
+    for k in ("device_one_call", "device_one_call_b64", "facade_device", "facade_single_image"):
+        if k in pl and "images_per_s" in pl[k]:
+            s["pipeline_" + k + "_images_per_s"] = round(pl[k]["images_per_s"], 1)
+    if "parity" in pl:
+        s["pipeline_parity_ok"] = pl["parity"]["ok"]
+    if out.get("cpu_baseline"):
+        s["cpu_baseline_images_per_s"] = round(out["cpu_baseline"]["value"], 3)
+    return s
+
+
 def group_child_main():
     """`bench.py --group-child`: the C++ host's own multi-GPU path (mi_unet_group_*: ONE process, one worker thread per device,
     weights packed once and sent device-to-device, contiguous image shards -- the slot of the reference's sequential file
@@ -437,6 +525,14 @@ def group_child_main():
     sys.stdout.write(json.dumps(rec) + "\n")
     sys.stdout.flush()
     return 0
+
+
+def under_profiler():
+    """rocprofv3 preloads its tool library, which initialises the GPU before Python starts: a fork + exec from here on is an exec
+    from a GPU process (it takes the machine down on this pool)"""
+    env = os.environ
+    return bool(env.get("ROCP_TOOL_LIBRARIES") or env.get("ROCPROFILER_REGISTER_FORCE_LOAD") or any(k.startswith("ROCPROF") for k in env)
+                or "rocprof" in env.get("LD_PRELOAD", "") or "rocprofiler" in env.get("HSA_TOOLS_LIB", ""))
 
 
 def start_group_child():
@@ -497,7 +593,11 @@ def main():
     ap.add_argument("--conv-algo", choices=["auto", "direct", "winograd", "winograd16", "bf16", "fp16"], default="auto")
     ap.add_argument("--no-group", action="store_true", help="skip the `group` record (mi_unet_group_* in one process)")
     ap.add_argument("--group-child", action="store_true", help=argparse.SUPPRESS)
+    ap.add_argument("--verbose", action="store_true", help="keep the per-kernel-family arrays of every roofline record in the JSON line "
+                    "(default: compact form in the line, full arrays in gpurun_out/bench_families.json)")
     args = ap.parse_args()
+    global VERBOSE
+    VERBOSE = args.verbose
 
     if args.group_child:
         raise SystemExit(group_child_main())
@@ -506,6 +606,9 @@ def main():
     # the `group` record's process: started now, while this process has not touched the GPU; it idles until told to run
     default_workload = (args.in_ch, args.base, args.levels, args.size, args.conv_algo, args.global_batch) == (1, 64, 4, 512, "auto", 0)
     want_group = (int(os.environ.get("RANK", "0")) == 0 and not args.no_group and not args.no_extras and default_workload)
+    group_skipped = None
+    if want_group and under_profiler():
+        want_group, group_skipped = False, "a profiler's preloaded library has initialised the GPU: no child process is started from here"
     group_child = start_group_child() if want_group else None
 
     # stdout carries exactly ONE line, the JSON record: everything libraries print while the bench runs (RCCL's version
@@ -664,7 +767,12 @@ def main():
                                   "per rank in micro-batches of 16, RCCL label-map gather to rank 0 inside the timed region",
                         "scaling": "strong", "n_gpus": world, "value": 512 * steps4 / float(d4.item()), "unit": "images/s",
                         "ms_per_step": float(d4.item()) / steps4 * 1e3, "steps": steps4, "warmup": 2, "images_per_rank": B4,
-                        "gathered_label_maps_verified": bool(ok4)}
+                        "micro_batch": min(B4, args.micro_batch), "global_batch": 512,
+                        "gather": "torch.distributed.gather over RCCL (grouped ncclSend / ncclRecv into rank 0), on the engine's stream, "
+                                  "inside the timed region; weights: one RCCL broadcast from rank 0 at start-up",
+                        "gathered_label_maps_verified": bool(ok4),
+                        "measured_on_more_than_one_device": bool(world > 1),
+                        "reference_slot": "the sequential file loop of directory mode, src/main.cpp:148-164"}
             del imgs4, labels4, gathered4
 
     if rank == 0:
@@ -734,16 +842,29 @@ def main():
                 out["pipeline"] = run_pipeline(binding, synth, local_rank)
             except Exception as e:
                 out["pipeline"] = {"error": repr(e)}
+            try:
+                out["pipeline_config5"] = run_pipeline_config5(binding, synth, local_rank)
+            except Exception as e:
+                out["pipeline_config5"] = {"error": repr(e)}
+        if group_skipped:
+            out["group"] = {"skipped": group_skipped}
         if group_child is not None:
             # ---- 6b. the C++ host's own multi-GPU path, one process over every visible device (a child process; see group_child_main)
             try:
                 out["group"] = finish_group_child(group_child, run=True)
             except Exception as e:                                            # an extra record never costs the headline
                 out["group"] = {"error": repr(e)}
-        if not args.no_cpu_baseline and world == 1:
+        if not args.no_cpu_baseline:
+            # N > 1: rank 0 alone, after the process group has ended and the other ranks have left the host's cores
             out["cpu_baseline"] = cpu_baseline(blob, H, W, spec.in_ch, oracle_s)
         else:
             out["cpu_baseline"] = None
+        out["summary"] = summary_of(out)
+        try:
+            os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
+            json.dump(FAMILY_TABLES, open(os.path.join(ROOT, "gpurun_out", "bench_families.json"), "w"), indent=1)
+        except OSError:
+            pass
         sys.stdout.flush()
         os.write(json_fd, (json.dumps(out) + "\n").encode())
         bad = [k for k in ("parity",) if out.get(k) and not out[k]["ok"]]
@@ -753,6 +874,8 @@ def main():
                     print("parity of an extra config outside its tolerance: " + c["config"], file=sys.stderr)
         if extras and isinstance(out.get("pipeline"), dict) and "parity" in out["pipeline"] and not out["pipeline"]["parity"]["ok"]:
             bad.append("pipeline")
+        if extras and isinstance(out.get("pipeline_config5"), dict) and "parity" in out["pipeline_config5"] and not out["pipeline_config5"]["parity"]["ok"]:
+            bad.append("pipeline_config5")
         if bad:
             print("PARITY FAILURE: " + ", ".join(bad), file=sys.stderr)
             rc = 3

@@ -14,9 +14,12 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 CSRC = os.path.join(ROOT, "unet-medical-image-contour-segmentation-cpp_amd", "csrc")
 sys.path.insert(0, os.path.join(ROOT, "tools", "dev"))
 HIPCC = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+# hipcc is part of the build image (the GPU box runs the same one): its absence FAILS these tests instead of skipping them, so a
+# toolchain change cannot silently switch the hazard checks off.  MIUNET_NO_HIPCC_OK=1 restores the skip elsewhere.
+NEEDS_HIPCC = pytest.mark.skipif(not os.path.exists(HIPCC) and os.environ.get("MIUNET_NO_HIPCC_OK") == "1", reason="hipcc not installed")
 
 
-@pytest.mark.skipif(not os.path.exists(HIPCC), reason="hipcc not installed")
+@NEEDS_HIPCC
 @pytest.mark.parametrize("src", sorted(os.path.basename(p) for p in glob.glob(os.path.join(CSRC, "*.hip"))))
 def test_no_wide_store_data_hazard(src, tmp_path):
     import scan_store_hazard
@@ -39,7 +42,7 @@ def test_scanner_sees_the_hazard(tmp_path):
     assert len(hits) == 2 and "v16" in hits[0] and "v6" in hits[1]
 
 
-@pytest.mark.skipif(not os.path.exists(HIPCC), reason="hipcc not installed")
+@NEEDS_HIPCC
 def test_resident_weight_kernels_do_not_spill(tmp_path):
     """conv_lpr.hip counts its own LDS-DMA loads with vmcnt; a register spill adds scratch loads and stores to the same
     counter, and hipcc's waits for THOSE drain the patch ring (measured: the fused-head variant 0.27 -> 0.53 ms with 24 scratch
@@ -56,7 +59,7 @@ def test_resident_weight_kernels_do_not_spill(tmp_path):
 LP_SOURCES = ("conv_lp.hip", "conv_lp2.hip", "conv_lpr.hip", "conv_lprk.hip", "convt_lpr.hip")
 
 
-@pytest.mark.skipif(not os.path.exists(HIPCC), reason="hipcc not installed")
+@NEEDS_HIPCC
 @pytest.mark.parametrize("src", LP_SOURCES)
 def test_inline_asm_mfmas_have_their_wait_states(src, tmp_path):
     """The 16-bit kernels issue v_mfma_f32_16x16x32 through inline asm (in-place accumulation: csrc/lpr_common.h), and hipcc pads
@@ -85,3 +88,12 @@ def test_mfma_scanner_sees_both_hazards(tmp_path):
     ok.write_text("\tv_mfma_f32_16x16x32_bf16 v[4:7], v[8:11], v[12:15], 0\n\tv_mfma_f32_16x16x32_bf16 v[4:7], v[8:11], v[12:15], v[4:7]\n"
                   "\ts_nop 7\n\ts_nop 7\n\tv_add_f32_e32 v0, v5, v1\n\ts_endpgm\n")
     assert scan_mfma_hazard.scan(str(ok)) == []
+    # an MFMA at a loop tail against a VALU read at the loop HEAD (the back-edge), and the same loop with the wait states in place
+    loop = tmp_path / "loop.s"
+    loop.write_text(".LBB0_1:\n\tv_add_f32_e32 v0, v5, v1\n\ts_nop 7\n\ts_nop 7\n\tv_mfma_f32_16x16x32_bf16 v[4:7], v[8:11], v[12:15], v[4:7]\n"
+                    "\ts_cbranch_scc1 .LBB0_1\n\ts_nop 7\n\ts_nop 7\n\ts_endpgm\n")
+    hits = scan_mfma_hazard.scan(str(loop))
+    assert len(hits) == 1 and "v_add_f32" in hits[0]
+    loop.write_text(".LBB0_1:\n\ts_nop 7\n\ts_nop 7\n\tv_add_f32_e32 v0, v5, v1\n\tv_mfma_f32_16x16x32_bf16 v[4:7], v[8:11], v[12:15], v[4:7]\n"
+                    "\ts_cbranch_scc1 .LBB0_1\n\ts_nop 7\n\ts_nop 7\n\ts_endpgm\n")
+    assert scan_mfma_hazard.scan(str(loop)) == []

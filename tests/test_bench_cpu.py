@@ -24,6 +24,9 @@ def _stats():
 def test_roofline_fraction_counts_executed_flops(monkeypatch):
     monkeypatch.setattr(bench, "pmc_summary", lambda tag: (None, "none"))
     r = bench.roofline_from_stats(_stats(), 192.4e9, 900.0, "fp32")
+    assert "families" not in r and r["families_compact"]["conv3x3_wino4"][0] == 4      # the default line stays short
+    monkeypatch.setattr(bench, "VERBOSE", True)
+    r = bench.roofline_from_stats(_stats(), 192.4e9, 900.0, "fp32")
     assert r["kernel"].startswith("conv3x3_wino4 ")                      # the family with the largest share of device time
     assert r["winograd_reduction"] == 4.0 and r["algorithm"] == "winograd F(4x4,3x3)"
     alg = (309e9 + 618e9) / ((0.89 + 1.36) * 1e-3) / 1e12

@@ -41,3 +41,24 @@ def test_raw16_error_paths(engine):
     eng, _ = engine
     with pytest.raises(binding.MiUnetError):
         eng.infer_raw16([np.zeros((0, 5), np.uint16)])
+
+
+def test_bad_image_late_in_a_call_is_rejected_before_anything_runs_and_the_handle_stays_usable(engine):
+    """a bad description in a LATER micro-batch used to be found after the first network was enqueued -- with H2D
+    copies still reading the caller's pinned buffers.  Every description is now validated up front (nothing is enqueued), the
+    message names the image, and the same handle then gives the same results as before."""
+    eng, _ = engine
+    raws = [synth.make_raw16(300 + 8 * i, 400, seed=50 + i) for i in range(9)]           # micro-batches of 4, 4, 1
+    want = eng.segment_raw16(raws)
+    pins = [binding.PinnedArray(r.shape, np.uint16) for r in raws]
+    for pa, r in zip(pins, raws):
+        pa.a[...] = r
+    bad = [pa.a for pa in pins]
+    bad[6] = np.zeros((0, 400), np.uint16)                                                # image 6: second micro-batch
+    with pytest.raises(binding.MiUnetError) as ei:
+        eng.segment_raw16(bad)
+    assert ei.value.code == 1 and "image 6" in str(ei.value)
+    for pa in pins:                                                                       # nothing in flight reads these any more
+        pa.close()
+    got = eng.segment_raw16(raws)
+    assert np.array_equal(got[0], want[0]) and np.array_equal(got[1], want[1]) and got[2] == want[2]

@@ -7,8 +7,9 @@ rule 2): the 16-bit kernels issue v_mfma_f32_16x16x32 through asm statements, so
   * a VALU instruction that wrote one of its source registers just before it (VALU write -> XDL read: 2 wait states)
 
 the required wait states must come from the instruction stream itself.  An MFMA that takes the destination whole as its
-accumulator (the accumulate chain) needs none.  Wait states are counted conservatively in text order across labels: every
-instruction 1, `s_nop N` N + 1; the look-ahead stops at s_endpgm.   usage: scan_mfma_hazard.py file.s"""
+accumulator (the accumulate chain) needs none.  Wait states are counted along EVERY path of the control-flow graph (branch
+targets and loop back-edges included: an MFMA at a loop tail is checked against the loop head): every instruction 1,
+`s_nop N` N + 1; a path ends at s_endpgm.   usage: scan_mfma_hazard.py file.s"""
 import re
 import sys
 
@@ -28,56 +29,92 @@ def _regs(text):
 
 
 def _instructions(path):
-    ins = []
+    """-> (instructions, label -> index of the first instruction behind it)"""
+    ins, labels = [], {}
     for raw in open(path):
         line = raw.split(";")[0].strip() if not raw.lstrip().startswith(";;#") else ""
-        if not line or line.startswith(".") or line.endswith(":") or line.startswith("//"):
+        if not line or line.startswith("//"):
+            continue
+        if line.endswith(":"):
+            labels[line[:-1]] = len(ins)
+            continue
+        if line.startswith("."):
             continue
         ins.append(line)
-    return ins
+    return ins, labels
 
 
-def scan(path):
-    ins = _instructions(path)
+def _successors(ins, labels, j):
+    """indices control can reach right after instruction j (text order + branch targets, back-edges included)"""
+    line = ins[j]
+    if line.startswith("s_endpgm"):
+        return []
+    op = line.split()[0]
+    if op == "s_branch" or op.startswith("s_cbranch"):
+        tgt = labels.get(line.split()[-1])
+        out = [] if tgt is None else [tgt]
+        if op != "s_branch" and j + 1 < len(ins):
+            out.append(j + 1)
+        return out
+    return [j + 1] if j + 1 < len(ins) else []
+
+
+def _states(line):
+    m = re.match(r"s_nop\s+(\d+)", line)
+    return int(m.group(1)) + 1 if m else 1
+
+
+def scan(path, shapes=("v_mfma_f32_16x16x32",)):
+    ins, labels = _instructions(path)
+    preds = {}
+    for j in range(len(ins)):
+        for k in _successors(ins, labels, j):
+            preds.setdefault(k, []).append(j)
     hits = []
     for i, line in enumerate(ins):
-        if not line.startswith("v_mfma_f32_16x16x32"):
+        if not line.startswith(shapes):
             continue
         ops = [o.strip() for o in line.split(None, 1)[1].split(",")]
         dst, srcs = _regs(ops[0]), _regs(ops[1]) | _regs(ops[2])
-        # --- destination hazard
-        states = 0
-        for j in range(i + 1, min(i + 1 + 4 * WAIT_D, len(ins))):
+        # --- destination hazard: every path out of the MFMA (a loop's back-edge continues at the loop head), until WAIT_D states
+        best = {}                                          # instruction index -> fewest states it was reached with
+        work = [(k, 0) for k in _successors(ins, labels, i)]
+        found = None
+        while work and found is None:
+            j, states = work.pop()
+            if states >= WAIT_D or best.get(j, WAIT_D) <= states:
+                continue
+            best[j] = states
             nxt = ins[j]
-            if nxt.startswith("s_endpgm") or states >= WAIT_D:
-                break
             if nxt.startswith("v_mfma"):
                 nops = [o.strip() for o in nxt.split(None, 1)[1].split(",")]
                 touched = (_regs(nops[1]) | _regs(nops[2])) & dst          # as A / B operand: a hazard; whole as C: the chain
                 if touched or (_regs(nops[0]) & dst and _regs(nops[3]) != _regs(nops[0])):
-                    hits.append(f"{path}: `{line}` then after {states} states `{nxt}`")
+                    found = (states, nxt)
                     break
-            elif _regs(nxt) & dst:
-                hits.append(f"{path}: `{line}` then after {states} states `{nxt}`")
+            elif not nxt.startswith("s_") and _regs(nxt) & dst:
+                found = (states, nxt)
                 break
-            m = re.match(r"s_nop\s+(\d+)", nxt)
-            states += int(m.group(1)) + 1 if m else 1
-        # --- source hazard: a VALU write right in front of the MFMA
-        states = 0
-        for j in range(i - 1, max(i - 1 - WAIT_S, -1), -1):
+            for k in _successors(ins, labels, j):
+                work.append((k, states + _states(nxt)))
+        if found:
+            hits.append(f"{path}: `{line}` then after {found[0]} states `{found[1]}`")
+        # --- source hazard: a VALU write right in front of the MFMA, on any path into it
+        work = [(k, 0) for k in preds.get(i, [])]
+        seen = set()
+        while work:
+            j, states = work.pop()
+            if states >= WAIT_S or (j, states) in seen:
+                continue
+            seen.add((j, states))
             prv = ins[j]
-            m = re.match(r"s_nop\s+(\d+)", prv)
-            if m:
-                states += int(m.group(1)) + 1
-            else:
-                if prv.startswith("v_") and not prv.startswith("v_mfma"):
-                    wr = _regs(prv.split(None, 1)[1].split(",")[0]) if " " in prv else set()
-                    if wr & (srcs | (_regs(ops[3]) if len(ops) > 3 else set())):
-                        hits.append(f"{path}: `{prv}` {states} states before `{line}`")
-                        break
-                states += 1
-            if states >= WAIT_S:
-                break
+            if prv.startswith("v_") and not prv.startswith("v_mfma"):
+                wr = _regs(prv.split(None, 1)[1].split(",")[0]) if " " in prv else set()
+                if wr & (srcs | (_regs(ops[3]) if len(ops) > 3 else set())):
+                    hits.append(f"{path}: `{prv}` {states} states before `{line}`")
+                    break
+            for k in preds.get(j, []):
+                work.append((k, states + _states(prv)))
     return hits
 
 

@@ -881,12 +881,13 @@ int engine_adopt_weights(mi_unet_t *h, const HostWeights &hw, bool upload)
 // Numeric guard of the default plan.  F(4x4,3x3) multiplies by transform constants up to 8 and 1/24, so its rounding error
 // relative to the layer's operand range is about five times F(2x2,3x3)'s (measured: 2e-5 against 4e-6 on logits of magnitude
 // 4 with He-initialised weights).  The path's bar is ABSOLUTE (logits within 1e-3 of the fp32 reference), so whether F(4x4)
-// holds it depends on the dynamic range of the weights that were just loaded -- which only the weights can tell.  One probe
-// tile (seeded bytes, the engine's own size, batch 1) goes through the plan twice, every 3x3 layer on F(4x4) and every 3x3
+// holds it depends on the dynamic range of the weights that were just loaded -- which only the weights can tell.  Two probe
+// tiles (seeded bytes and a structured one, the engine's own size, batch 1) go through the plan twice each, every 3x3 layer on F(4x4) and every 3x3
 // layer on F(2x2); if the logits differ by more than half the bar (5e-4), this weight set runs F(2x2) everywhere.  The
 // difference of the two plans overstates F(4x4)'s own error (both errors add: measured 3.7e-4 apart where F(4x4) sat 2.8e-4
 // from the fp32 oracle, tests/test_gpu_numeric_range.py), so a weight set that passes is inside the bar with margin.
-// MIUNET_WINO4_GUARD=0 skips the probe (F(4x4) kept unconditionally), =2 trips it unconditionally (tests).
+// MIUNET_WINO4_GUARD=0 skips the probe (F(4x4) kept unconditionally), =2 trips it unconditionally, =3 probes with the noise
+// tile only (tests).
 int engine_calibrate(mi_unet_t *h)
 {
     if (int rc = check_handle(h, true)) return rc;
@@ -903,42 +904,70 @@ int engine_calibrate(mi_unet_t *h)
     if (mode == 0) { h->guard_text = "numeric guard: skipped (MIUNET_WINO4_GUARD=0), F(4x4,3x3) kept"; return MI_UNET_OK; }
     if (mode == 2) { h->wino4_guard_tripped = true; h->guard_text = "numeric guard: tripped by MIUNET_WINO4_GUARD=2, every 3x3 layer on F(2x2,3x3)"; return MI_UNET_OK; }
     HIP_TRY(hipSetDevice(h->cfg.device));
-    const size_t hw = (size_t)h->cfg.height * h->cfg.width, n_in = hw * h->cfg.in_ch, n_lg = hw * h->cfg.classes;
-    std::vector<uint8_t> probe(n_in);
-    uint32_t x = 0x9E3779B9u;                           // seeded bytes over the whole 0..255 range
-    for (size_t i = 0; i < n_in; ++i) { x = x * 1664525u + 1013904223u; probe[i] = (uint8_t)(x >> 24); }
+    const int PH = h->cfg.height, PW = h->cfg.width, PC = h->cfg.in_ch;
+    const size_t hw = (size_t)PH * PW, n_in = hw * PC, n_lg = hw * h->cfg.classes;
+    // Two probe tiles (round 4).  (a) seeded bytes over the whole 0..255 range: every frequency, but white noise UNDER-drives a
+    // trained network -- a 3x3 sum of independent bytes concentrates around its mean, and on the bench's own weights the probe
+    // saw a logit range of 0.85 where structured images reach 4.  (b) a structured tile: a full-range horizontal ramp under four
+    // soft ellipses of alternating sign plus three bits of noise -- large flat regions at both ends of the range, edges between
+    // them (what miunet/synth.py's "blobs" images and real detector tiles look like).  The decision takes the LARGER difference.
+    std::vector<uint8_t> probes[2] = { std::vector<uint8_t>(n_in), std::vector<uint8_t>(n_in) };
+    uint32_t x = 0x9E3779B9u;
+    for (size_t i = 0; i < n_in; ++i) { x = x * 1664525u + 1013904223u; probes[0][i] = (uint8_t)(x >> 24); }
+    {
+        static const float cx[4] = { 0.30f, 0.72f, 0.38f, 0.80f }, cy[4] = { 0.28f, 0.40f, 0.74f, 0.82f };
+        static const float rx[4] = { 0.22f, 0.16f, 0.25f, 0.12f }, ry[4] = { 0.18f, 0.24f, 0.14f, 0.12f };
+        static const float amp[4] = { 150.f, -170.f, 130.f, -200.f };
+        for (int y = 0; y < PH; ++y)
+            for (int xx = 0; xx < PW; ++xx) {
+                float v = 255.f * (float)xx / (float)(PW > 1 ? PW - 1 : 1);
+                for (int k = 0; k < 4; ++k) {
+                    const float dx = ((float)xx / PW - cx[k]) / rx[k], dy = ((float)y / PH - cy[k]) / ry[k];
+                    const float d = dx * dx + dy * dy;
+                    v += amp[k] / (1.f + d * d * d);
+                }
+                x = x * 1664525u + 1013904223u;
+                v += (float)(x >> 29);
+                const uint8_t b = (uint8_t)(v < 0.f ? 0.f : v > 255.f ? 255.f : v);
+                for (int c = 0; c < PC; ++c) probes[1][((size_t)y * PW + xx) * PC + c] = b;
+            }
+    }
     std::vector<float> lg4(n_lg), lg2(n_lg);
-    HIP_TRY(hipStreamSynchronize(h->stream));
-    HIP_TRY(hipMemcpy(h->d_img, probe.data(), n_in, hipMemcpyHostToDevice));
     const int keep_min = h->wino4_min_wg;
     const bool keep_split = h->wino4_splitk;
-    int rc = 0;
-    h->wino4_min_wg = 0;                                // every packed layer on F(4x4), whatever its grid
-    rc = launch_plan(h, h->d_img, 1, h->d_labels, h->d_logits);
-    if (!rc && hipStreamSynchronize(h->stream) != hipSuccess) rc = fail(MI_UNET_EHIP, "numeric guard: probe pass failed");
-    if (!rc && hipMemcpy(lg4.data(), h->d_logits, sizeof(float) * n_lg, hipMemcpyDeviceToHost) != hipSuccess) rc = fail(MI_UNET_EHIP, "numeric guard: D2H failed");
-    if (!rc) {
-        h->wino4_guard_tripped = true;                  // the same plan with every 3x3 layer on F(2x2)
-        rc = launch_plan(h, h->d_img, 1, h->d_labels, h->d_logits);
-        h->wino4_guard_tripped = false;
-        if (!rc && hipStreamSynchronize(h->stream) != hipSuccess) rc = fail(MI_UNET_EHIP, "numeric guard: probe pass failed");
-        if (!rc && hipMemcpy(lg2.data(), h->d_logits, sizeof(float) * n_lg, hipMemcpyDeviceToHost) != hipSuccess) rc = fail(MI_UNET_EHIP, "numeric guard: D2H failed");
-    }
-    h->wino4_min_wg = keep_min; h->wino4_splitk = keep_split;
-    if (rc) return rc;
-    float diff = 0.f, range = 0.f;
+    float diff = 0.f, range = 0.f, diffs[2] = { 0.f, 0.f };
     bool finite = true;
-    for (size_t i = 0; i < n_lg; ++i) {
-        const float d = std::fabs(lg4[i] - lg2[i]);
-        if (!(d == d) || std::isinf(d)) finite = false;
-        diff = std::max(diff, d);
-        range = std::max(range, std::fabs(lg2[i]));
+    const int n_probes = mode == 3 ? 1 : 2;             // MIUNET_WINO4_GUARD=3: the noise tile alone (round 3's guard; tests)
+    for (int pi = 0; pi < n_probes; ++pi) {
+        HIP_TRY(hipStreamSynchronize(h->stream));
+        HIP_TRY(hipMemcpy(h->d_img, probes[pi].data(), n_in, hipMemcpyHostToDevice));
+        int rc = 0;
+        h->wino4_min_wg = 0;                            // every packed layer on F(4x4), whatever its grid
+        rc = launch_plan(h, h->d_img, 1, h->d_labels, h->d_logits);
+        if (!rc && hipStreamSynchronize(h->stream) != hipSuccess) rc = fail(MI_UNET_EHIP, "numeric guard: probe pass failed");
+        if (!rc && hipMemcpy(lg4.data(), h->d_logits, sizeof(float) * n_lg, hipMemcpyDeviceToHost) != hipSuccess) rc = fail(MI_UNET_EHIP, "numeric guard: D2H failed");
+        if (!rc) {
+            h->wino4_guard_tripped = true;              // the same plan with every 3x3 layer on F(2x2)
+            rc = launch_plan(h, h->d_img, 1, h->d_labels, h->d_logits);
+            h->wino4_guard_tripped = false;
+            if (!rc && hipStreamSynchronize(h->stream) != hipSuccess) rc = fail(MI_UNET_EHIP, "numeric guard: probe pass failed");
+            if (!rc && hipMemcpy(lg2.data(), h->d_logits, sizeof(float) * n_lg, hipMemcpyDeviceToHost) != hipSuccess) rc = fail(MI_UNET_EHIP, "numeric guard: D2H failed");
+        }
+        h->wino4_min_wg = keep_min; h->wino4_splitk = keep_split;
+        if (rc) return rc;
+        for (size_t i = 0; i < n_lg; ++i) {
+            const float d = std::fabs(lg4[i] - lg2[i]);
+            if (!(d == d) || std::isinf(d)) finite = false;
+            diffs[pi] = std::max(diffs[pi], d);
+            range = std::max(range, std::fabs(lg2[i]));
+        }
+        diff = std::max(diff, diffs[pi]);
     }
     h->guard_diff = diff;
     h->wino4_guard_tripped = !finite || diff > h->guard_limit;
-    char buf[256];
-    snprintf(buf, sizeof buf, "numeric guard: probe logits (range %.3g) of the F(4x4,3x3) and F(2x2,3x3) plans differ by %.3g (limit %.3g): %s",
-             range, diff, h->guard_limit, h->wino4_guard_tripped ? "F(2x2,3x3) on every 3x3 layer for this weight set" : "F(4x4,3x3) kept");
+    char buf[384];
+    snprintf(buf, sizeof buf, "numeric guard: probe logits (range %.3g) of the F(4x4,3x3) and F(2x2,3x3) plans differ by %.3g (noise tile %.3g, structured tile %.3g; limit %.3g): %s",
+             range, diff, diffs[0], n_probes > 1 ? diffs[1] : -1.f, h->guard_limit, h->wino4_guard_tripped ? "F(2x2,3x3) on every 3x3 layer for this weight set" : "F(4x4,3x3) kept");
     h->guard_text = buf;
     return MI_UNET_OK;
 }
@@ -1355,6 +1384,11 @@ int run_raw_call(mi_unet *h, const RawCall &c)
     const size_t hw = (size_t)H * W, C = (size_t)h->cfg.in_ch;
     hipStream_t s = h->stream;
     if (c.B <= 0) return MI_UNET_OK;
+    // every image description is checked BEFORE anything is enqueued: a bad width in image k + 1 must not be found after the
+    // network of micro-batch k has started
+    for (size_t i = 0; i < (size_t)c.B * C; ++i)
+        if (!c.raws[i] || c.widths[i] <= 0 || c.heights[i] <= 0)
+            return fail(MI_UNET_EARG, "RAW16 input: bad image description (image " + std::to_string(i / C) + ", plane " + std::to_string(i % C) + ")");
     // micro-batches: chunks of max_batch images -- and the FIRST chunk is cut once more when it is large (a quarter, at least
     // four images, then the rest), so that the network starts as soon as a few images have been uploaded and preprocessed
     // and the upload of the rest hides under it.
@@ -1499,25 +1533,40 @@ int run_raw_call(mi_unet *h, const RawCall &c)
             h->tail_ws_bytes = need;
         }
     }
-    HIP_TRY(hipStreamSynchronize(s));                  // an external stream may still be reading the tile buffers
-    mark("stage begin", 0);
-    if (int rc = stage(0)) return rc;
-    mark("stage end", 0);
-    for (int k = 0; k < n_mb; ++k) {
-        if (int rc = enqueue(k)) return rc;
-        mark("enqueued", k);
-        if (k + 1 < n_mb) {                            // the host's staging copies of k + 1 run while the device works on k
-            if (int rc = stage(k + 1)) return rc;
-            mark("stage end", k + 1);
+    // Once the first micro-batch is enqueued, H2D copies read the caller's (possibly page-locked) RAW buffers directly and the tail
+    // writes the handle's pinned mirrors: an error return with work still in flight would let the caller free buffers under the
+    // DMA engine.  Every failure path below therefore drains ALL four streams before the call returns.
+    auto pipeline = [&]() -> int {
+        HIP_TRY(hipStreamSynchronize(s));                  // an external stream may still be reading the tile buffers
+        mark("stage begin", 0);
+        if (int rc = stage(0)) return rc;
+        mark("stage end", 0);
+        for (int k = 0; k < n_mb; ++k) {
+            if (int rc = enqueue(k)) return rc;
+            mark("enqueued", k);
+            if (k + 1 < n_mb) {                            // the host's staging copies of k + 1 run while the device works on k
+                if (int rc = stage(k + 1)) return rc;
+                mark("stage end", k + 1);
+            }
+            if (k >= 1) {
+                if (int rc = finalize(k - 1)) return rc;   // ... and so does the copy-out of k - 1
+                mark("finalized", k - 1);
+            }
         }
-        if (k >= 1) {
-            if (int rc = finalize(k - 1)) return rc;   // ... and so does the copy-out of k - 1
-            mark("finalized", k - 1);
-        }
+        if (int rc = finalize(n_mb - 1)) return rc;
+        mark("finalized", n_mb - 1);
+        HIP_TRY(hipStreamSynchronize(s));                  // D2H copies into the caller's own (pageable) logits included
+        return MI_UNET_OK;
+    };
+    const int rc = pipeline();
+    if (rc != MI_UNET_OK) {
+        const std::string keep = g_err;
+        for (hipStream_t q : { h->pre_stream, s, h->tail_stream, h->dl_stream })
+            if (q) (void)hipStreamSynchronize(q);
+        for (int i = 0; i < mi_unet::RAW_RING; ++i) h->raw_busy[i] = false;
+        g_err = keep;
+        return rc;
     }
-    if (int rc = finalize(n_mb - 1)) return rc;
-    mark("finalized", n_mb - 1);
-    HIP_TRY(hipStreamSynchronize(s));                  // D2H copies into the caller's own (pageable) logits included
     mark("done", 0);
     return MI_UNET_OK;
 }
