@@ -1,0 +1,927 @@
+#!/usr/bin/env python3
+"""gen_wino4_asm.py -- emits the gfx950 assembly of the persistent two-block Winograd F(4x4,3x3) kernel (conv3x3_wino4a).
+
+Why assembly (profiles/r04_fp32_mfma_filler_probe.txt): next to v_mfma_f32_16x16x4_f32 with one wave per SIMD,
+ANY vector-ALU instruction costs 6-13 cycles of matrix-pipe time (a packed-f32 one the same as a plain one), while SALU, s_waitcnt,
+s_nop and ds_read cost nothing.  hipcc's K loop of conv3x3_wino4_f32<2> carries ~190 VALU per 288 MFMAs (96 of them the transform
+itself, the rest address arithmetic, parity selects and register copies) and pays ~25 k cycles per tile outside the loop.  Here:
+
+  * the K loop holds exactly the transform's packed operations (96 / 48 per wave and chunk) in a few large groups, every address is
+    a loop-invariant register plus an immediate, buffer parities are unrolled, every wait count is exact;
+  * the workgroup is PERSISTENT (one per CU): the opening loads of tile T+1 (its first two raw chunks by LDS-DMA, its U ring) are
+    issued inside the last two chunks of tile T, its first transform runs before the epilogue of T, so a tile costs its chunks plus
+    an epilogue -- no launch, no cold loads;
+  * same data layouts as csrc/conv_wino4.hip (U = [Cin/16][36][CoutPad][16], V / raw-patch LDS images of csrc/wino4_common.h), so
+    the weights are shared and the hipcc kernel remains the fallback for shapes this one does not take.
+
+Shape contract (checked by the launcher, csrc/wino4_asm.cpp): H % 16 == 0, W % 16 == 0, Cin % 32 == 0 and Cin >= 64, Cout % 128 == 0,
+CoutPad == Cout, no fused head, no split-K.  Optional fused 2x2 max pooling, ReLU by a lower bound.
+
+usage: gen_wino4_asm.py out.s [UD]
+"""
+import sys
+
+UD = 9                       # U ring depth in positions (36 % UD == 0)
+VPOS_B = 1024                # bytes per position of a V buffer (16 tiles x 64 B)
+VBUF_B = 36 * VPOS_B         # 36864
+RAW_ROW = 20
+RAW_LOADS = 24               # wave-wide LDS-DMA loads per chunk (23 live + 1 so that every wave issues six)
+RAWBUF_B = RAW_LOADS * 1024  # 24576
+LDS_V0, LDS_V1 = 0, VBUF_B
+LDS_R0 = 2 * VBUF_B          # 73728
+LDS_R1 = LDS_R0 + RAWBUF_B
+LDS_BYTES = LDS_R1 + RAWBUF_B   # 122880
+
+# ---------------------------------------------------------------------------------------------------------------- registers
+# SGPRs
+S_KARG = 0          # s[0:1]
+S_WG = 2
+S_T0, S_T1, S_T2, S_T3, S_T4 = 3, 4, 5, 6, 7          # temporaries
+A_IN, A_U, A_BIAS, A_OUT, A_POOL = 8, 10, 12, 14, 16   # pointers (pairs)
+A_H, A_W, A_PIXIN, A_NCH, A_TX, A_TY, A_MT, A_NWG = 18, 19, 20, 21, 22, 23, 24, 25
+A_MAGM, A_MAGX, A_MAGY, A_UPOS, A_UBYTES, A_IMGIN = 26, 27, 28, 29, 30, 31
+A_PIXOUT, A_COOFF, A_IMGOUT, A_PIXPOOL, A_IMGPOOL, A_RELU, A_GRID, A_FLAGS = 32, 33, 34, 35, 36, 37, 38, 39
+R_IN, R_U, R_OUT, R_POOL = 40, 44, 48, 52             # buffer descriptors (quads)
+N_OUTB, N_POOLB = 56, 58                              # next tile: base address pairs of its out / pool descriptors
+N_TOUT, N_TPOOL, N_UBASE, N_HAS = 60, 61, 62, 63      # next tile: scalar byte offsets, U base, "there is a next tile"
+L_TT, L_TCOUNT, L_TSTART, L_SLOTS = 64, 65, 66, 67
+L_UOFF, L_DMAOFF, L_PAIRS, L_WAVE = 68, 69, 70, 71
+K_4, K_M5, K_2, K_M2, K_ALPHA, K_BETA, K_MBETA, K_M4, K_8 = 72, 74, 76, 78, 80, 82, 84, 86, 88   # packed-f32 constant pairs
+C_TOUT, C_TPOOL = 90, 91                              # current tile: scalar byte offsets of its outputs
+L_M0BASE = 92                                         # LDS address of this wave's first raw-patch load in buffer 0
+L_BY0M1, L_BX0M1, L_BASEPIX = 93, 94, 95
+S_ROW = 96                                            # s[96:99] per-row scalar offsets in the epilogue; s[100:101] pooled rows
+S_PROW = 100
+
+# VGPRs
+U0 = 0
+AV0 = 8 * UD                 # 72
+PX0 = AV0 + 8                # 80: two banks of 16
+CR0 = PX0 + 32               # 112: [2 rows][6 cols][4]
+E0 = CR0 + 48                # 160
+TV0 = E0 + 16                # 176: 3 quads
+V_VRD0, V_VRD1, V_UVOFF, V_PRD, V_VWR = 188, 189, 190, 191, 192
+V_REL0 = 193                 # 6
+V_VOFF0 = 199                # 6
+V_PYPX0 = 205                # 6
+V_OUTOFF, V_POOLOFF = 211, 212
+V_BIAS0, V_BIAS1, V_CHAN4 = 213, 214, 215
+V_T0 = 216                   # 216..223: eight temporaries (set-up code only)
+ACCV = 224                   # accumulators of positions 32..35
+assert V_PYPX0 + 6 <= V_OUTOFF and V_T0 + 8 <= ACCV and TV0 + 12 <= V_VRD0
+
+# epilogue temporaries (alias the transform's registers; none is live across the K loop)
+EP_M = PX0                   # 6 pairs
+EP_S = PX0 + 12              # 4 pairs
+EP_Y = PX0 + 20              # 4 pairs
+EP_C = PX0 + 28              # 2 pairs (pooling carries)
+EP_T = CR0                   # [4][6] pairs = 48
+EP_VX = E0                   # 16 per-x voffsets
+EP_VXP = TV0                 # 8 per-x pooled voffsets
+assert EP_VXP + 8 <= V_VRD0
+
+
+def v(n, cnt=1):
+    return f"v{n}" if cnt == 1 else f"v[{n}:{n + cnt - 1}]"
+
+
+def a(n, cnt=1):
+    return f"a{n}" if cnt == 1 else f"a[{n}:{n + cnt - 1}]"
+
+
+def s(n, cnt=1):
+    return f"s{n}" if cnt == 1 else f"s[{n}:{n + cnt - 1}]"
+
+
+DUMP = ""                    # bring-up: at the checkpoint, workgroup 0 writes "lds" | "vgpr" | "agpr" to the OUTPUT buffer instead of going on
+STOP_AT = 0                  # bring-up: leave the kernel at checkpoint N (0 = run everything); gen_wino4_asm.py out.s --stop N
+
+
+class Emitter:
+    def __init__(self):
+        self.lines = []
+        self.uid = 0
+        self.stats = {}
+
+    def checkpoint(self, n, what):
+        self.c(f"checkpoint {n}: {what}")
+        if STOP_AT == n:
+            if DUMP:
+                emit_dump(self, DUMP)
+            self.i("s_branch .Lend_program")
+
+    def i(self, text):
+        self.lines.append("\t" + text)
+        op = text.split()[0]
+        self.stats[op] = self.stats.get(op, 0) + 1
+
+    def label(self, name):
+        self.lines.append(name + ":")
+
+    def c(self, text):
+        self.lines.append("\t// " + text)
+
+    def new(self, stem):
+        self.uid += 1
+        return f".L{stem}_{self.uid}"
+
+
+def emit_dump(E, what):
+    """bring-up only: workgroup 0 copies its LDS image (linear), or registers ([register][thread]), into the output tensor"""
+    E.i(f"s_cmp_lg_u32 {s(S_WG)}, 0")
+    E.i("s_cbranch_scc1 .Lend_program")
+    E.i("s_waitcnt vmcnt(0) lgkmcnt(0)")
+    E.i("s_barrier")
+    E.i(f"s_mov_b32 {s(S_ROW)}, {s(A_OUT)}")
+    E.i(f"s_and_b32 {s(S_ROW + 1)}, {s(A_OUT + 1)}, 0xffff")
+    E.i(f"s_mov_b32 {s(S_ROW + 2)}, 0x7ffffff0")
+    E.i(f"s_mov_b32 {s(S_ROW + 3)}, 0x00020000")
+    t, o = V_T0, V_T0 + 1
+    E.i(f"v_mbcnt_lo_u32_b32 {v(t)}, -1, 0")
+    E.i(f"v_mbcnt_hi_u32_b32 {v(t)}, -1, {v(t)}")
+    E.i(f"s_lshl_b32 {s(S_T0)}, {s(L_WAVE)}, 6")
+    E.i(f"v_add_u32 {v(t)}, {s(S_T0)}, {v(t)}")                              # thread index
+    if what == "lds":
+        E.i(f"v_lshlrev_b32 {v(o)}, 4, {v(t)}")
+        E.i(f"v_add_u32 {v(t)}, 61440, {v(o)}")
+        for i in range(LDS_BYTES // 4096):
+            base, off = (o, i * 4096) if i < 15 else (t, (i - 15) * 4096)
+            E.i(f"ds_read_b128 {v(V_T0 + 4, 4)}, {v(base)} offset:{off}")
+            E.i("s_waitcnt lgkmcnt(0)")
+            E.i(f"s_mov_b32 {s(S_T1)}, {i * 4096}")
+            E.i(f"buffer_store_dwordx4 {v(V_T0 + 4, 4)}, {v(o)}, {s(S_ROW, 4)}, {s(S_T1)} offen")
+            E.i("s_waitcnt vmcnt(0)")
+    else:
+        E.i(f"v_lshlrev_b32 {v(o)}, 2, {v(t)}")
+        for r in range(256):
+            if r in (V_T0, V_T0 + 1, V_T0 + 2):
+                continue
+            E.i(f"s_mov_b32 {s(S_T1)}, {r * 1024}")
+            if what == "agpr":
+                E.i(f"v_accvgpr_read_b32 {v(V_T0 + 2)}, {a(r)}")
+                E.i("s_nop 1")
+                E.i(f"buffer_store_dword {v(V_T0 + 2)}, {v(o)}, {s(S_ROW, 4)}, {s(S_T1)} offen")
+            else:
+                E.i(f"buffer_store_dword {v(r)}, {v(o)}, {s(S_ROW, 4)}, {s(S_T1)} offen")
+    E.i("s_waitcnt vmcnt(0)")
+
+
+def acc_reg(p, blk, r=0, cnt=4):
+    """accumulator registers of position p, channel block blk: AGPRs for p < 32, VGPRs for the last four positions"""
+    if p < 32:
+        return a(8 * p + 4 * blk + r, cnt)
+    return v(ACCV + 8 * (p - 32) + 4 * blk + r, cnt)
+
+
+# ------------------------------------------------------------------------------------------------------------ LDS wait model
+class LdsQueue:
+    """LDS operations of a wave complete in order; lgkmcnt(k) = at most k outstanding.  Tracks issue order inside one body
+    (every body starts after lgkmcnt(0)) and gives the exact count for "everything up to this tag has completed"."""
+
+    def __init__(self):
+        self.q = []
+
+    def issue(self, tag):
+        self.q.append(tag)
+
+    def wait_count(self, tag):
+        """count that guarantees completion of the LAST op carrying `tag`; None if nothing with that tag is outstanding"""
+        idx = None
+        for n, t in enumerate(self.q):
+            if t == tag:
+                idx = n
+        if idx is None:
+            return None
+        k = len(self.q) - 1 - idx
+        self.q = self.q[idx + 1:]
+        return k
+
+
+def waitcnt(E, vm=None, lgkm=None):
+    parts = []
+    if vm is not None:
+        assert 0 <= vm <= 63, vm
+        parts.append(f"vmcnt({vm})")
+    if lgkm is not None:
+        assert 0 <= lgkm <= 15, lgkm
+        parts.append(f"lgkmcnt({lgkm})")
+    if parts:
+        E.i("s_waitcnt " + " ".join(parts))
+
+
+# ---------------------------------------------------------------------------------------------------------- packed helpers
+def pk_fma(E, dst, k_sgpr, x, y):
+    """dst(quad) = K * x + y on four floats: two v_pk_fma_f32 (constant pair in SGPRs: one constant-bus read)"""
+    for h in (0, 2):
+        E.i(f"v_pk_fma_f32 {v(dst + h, 2)}, {s(k_sgpr, 2)}, {v(x + h, 2)}, {v(y + h, 2)}")
+
+
+def pk_add(E, dst, x, y):
+    for h in (0, 2):
+        E.i(f"v_pk_add_f32 {v(dst + h, 2)}, {v(x + h, 2)}, {v(y + h, 2)}")
+
+
+def pk_sub(E, dst, x, y):
+    for h in (0, 2):
+        E.i(f"v_pk_add_f32 {v(dst + h, 2)}, {v(x + h, 2)}, {v(y + h, 2)} neg_lo:[0,1] neg_hi:[0,1]")
+
+
+# -------------------------------------------------------------------------------------------------------------- transform
+# V = B^T d B of one 16-channel chunk, cut by rows of B^T over the waves (csrc/conv_wino4.hip):
+#   role A (waves 0, 1): patch rows 1..4 -> xi rows (1,2) resp. (3,4): ta = d4 + alpha d2, tb = d3 + alpha d1, ta +- beta tb
+#   role B (waves 2, 3): patch rows (0,2,4) resp. (1,3,5) -> xi 0 resp. 5: 4 d0 - 5 d1 + d2
+# lane = (tile, channel quad).  The pieces: L(k) patch column k into a PX bank, C(k) column pass, P(row) / S(row, nus) row pass.
+def px_bank(k):
+    return PX0 + 16 * (k & 1)
+
+
+def cr(row, k):
+    return CR0 + 4 * (6 * row + k)
+
+
+def tr_load(E, role, k, rbuf, lq):
+    rows = 4 if role == "A" else 3
+    rstep = 1 if role == "A" else 2
+    for i in range(rows):
+        off = ((k & 3) * 5 + (k >> 2)) * 64 + i * rstep * RAW_ROW * 64 + rbuf * RAWBUF_B
+        E.i(f"ds_read_b128 {v(px_bank(k) + 4 * i, 4)}, {v(V_PRD)} offset:{off}")
+        lq.issue(("L", k))
+
+
+def tr_col(E, role, k):
+    d = [px_bank(k) + 4 * i for i in range(4)]
+    if role == "A":
+        ta, tb = TV0, TV0 + 4
+        pk_fma(E, ta, K_ALPHA, d[1], d[3])
+        pk_fma(E, tb, K_ALPHA, d[0], d[2])
+        pk_fma(E, cr(0, k), K_BETA, tb, ta)
+        pk_fma(E, cr(1, k), K_MBETA, tb, ta)
+    else:
+        t = TV0
+        pk_fma(E, t, K_4, d[0], d[2])
+        pk_fma(E, cr(0, k), K_M5, d[1], t)
+
+
+def tr_prep(E, row):
+    c = [cr(row, k) for k in range(6)]
+    pk_fma(E, E0, K_M4, c[2], c[4])
+    pk_fma(E, E0 + 4, K_M4, c[1], c[3])
+    pk_sub(E, E0 + 8, c[4], c[2])
+    pk_sub(E, E0 + 12, c[3], c[1])
+
+
+def tr_store_calc(E, row, nu, dst):
+    c = [cr(row, k) for k in range(6)]
+    if nu == 0:
+        pk_fma(E, dst, K_4, c[0], c[4])
+        pk_fma(E, dst, K_M5, c[2], dst)
+    elif nu == 1:
+        pk_add(E, dst, E0, E0 + 4)
+    elif nu == 2:
+        pk_sub(E, dst, E0, E0 + 4)
+    elif nu == 3:
+        pk_fma(E, dst, K_2, E0 + 12, E0 + 8)
+    elif nu == 4:
+        pk_fma(E, dst, K_M2, E0 + 12, E0 + 8)
+    else:
+        pk_fma(E, dst, K_4, c[1], c[5])
+        pk_fma(E, dst, K_M5, c[3], dst)
+
+
+def tr_write(E, row, nu, src, wbuf, lq):
+    off = nu * VPOS_B + row * 6 * VPOS_B + wbuf * VBUF_B
+    E.i(f"ds_write_b128 {v(V_VWR)}, {v(src, 4)} offset:{off}")
+    lq.issue(("W", row, nu))
+
+
+def transform_schedule(role):
+    """position -> (valu actions, lds actions after them).  Actions are tuples understood by emit_body."""
+    sch = {}
+    if role == "A":
+        sch[1] = ([], [("L", 0), ("L", 1)])
+        sch[3] = ([("waitL", 1), ("C", 0), ("C", 1)], [("L", 2), ("L", 3)])
+        sch[6] = ([("waitL", 3), ("C", 2), ("C", 3)], [("L", 4), ("L", 5)])
+        sch[9] = ([("waitL", 5), ("C", 4), ("C", 5)], [])
+        sch[12] = ([("P", 0), ("S", 0, (0, 1, 2))], [])
+        sch[14] = ([("S", 0, (3, 4, 5)), ("P", 1)], [])
+        sch[16] = ([("S", 1, (0, 1, 2))], [])
+        sch[18] = ([("S", 1, (3, 4, 5))], [])
+    else:
+        sch[1] = ([], [("L", 0), ("L", 1)])
+        sch[3] = ([("waitL", 1), ("C", 0), ("C", 1)], [("L", 2), ("L", 3)])
+        sch[6] = ([("waitL", 3), ("C", 2), ("C", 3)], [("L", 4), ("L", 5)])
+        sch[9] = ([("waitL", 5), ("C", 4), ("C", 5)], [])
+        sch[12] = ([("P", 0), ("S", 0, (0, 1, 2))], [])
+        sch[14] = ([("S", 0, (3, 4, 5))], [])
+    return sch
+
+
+def emit_transform_alone(E, role, rbuf, wbuf):
+    """the whole transform of one chunk with nothing beside it (a tile's first chunk)"""
+    lq = LdsQueue()
+    E.c(f"first transform, role {role}: Raw{rbuf} -> V{wbuf}")
+    tr_load(E, role, 0, rbuf, lq)
+    tr_load(E, role, 1, rbuf, lq)
+    for k in range(6):
+        waitcnt(E, lgkm=lq.wait_count(("L", k)))
+        tr_col(E, role, k)
+        if k + 2 < 6:
+            tr_load(E, role, k + 2, rbuf, lq)
+    for row in range(2 if role == "A" else 1):
+        tr_prep(E, row)
+        for grp in ((0, 1, 2), (3, 4, 5)):
+            for n, nu in enumerate(grp):
+                tr_store_calc(E, row, nu, TV0 + 4 * n)
+            for n, nu in enumerate(grp):
+                tr_write(E, row, nu, TV0 + 4 * n, wbuf, lq)
+            E.i("s_nop 1")       # the three TV quads are rewritten by the next group: the ds_writes read them as they issue
+
+
+# ------------------------------------------------------------------------------------------------------------- chunk body
+def vm_wait_for_position(p):
+    """vmcnt that guarantees the U fragments of position p: they were issued at the end of position p - UD; younger than them are
+    the refills of positions p-UD+1 .. p-1 (two each) and the LDS-DMA loads issued in positions p-UD+1 .. p-1 of this body"""
+    dmas = sum(1 for q in range(max(0, p - UD + 1), p) if q % 4 == 0 and q < 24)
+    return 2 * (UD - 1) + dmas
+
+
+def emit_body(E, role, par, kind):
+    """One K chunk: 288 MFMAs on V[par] and the U ring; beside them the V fragment reads, the U refills, the LDS-DMA of the raw
+    patch two chunks ahead into Raw[par], and (kind != last) the transform Raw[par^1] -> V[par^1] of the next chunk."""
+    assert kind in ("first", "mid", "last")
+    lq = LdsQueue()
+    sch = transform_schedule(role) if kind != "last" else {}
+    vrd = V_VRD0 if par == 0 else V_VRD1
+    rbuf = wbuf = par ^ 1
+    E.c(f"---- chunk body: role {role}, V{par}, {kind}")
+    E.i(f"ds_read_b128 {v(AV0, 4)}, {v(vrd)} offset:0")
+    lq.issue(("AV", 0))
+    pending_writes = []          # (row, nu, src) ds_writes to spread over the next MFMA gaps
+    for p in range(36):
+        av = AV0 + 4 * (p & 1)
+        slot = p % UD
+        vm = None if (kind == "first" and p < UD) else vm_wait_for_position(p)
+        waitcnt(E, vm=vm, lgkm=lq.wait_count(("AV", p)))
+        valu, ldsops = sch.get(p, ([], []))
+        dma = (p % 4 == 0 and p < 24)
+        for m in range(8):
+            st, blk = m >> 1, m & 1
+            acc = acc_reg(p, blk)
+            csrc = "0" if (kind == "first" and p != 7 and st == 0) else acc      # a tile's first MFMA of a chain starts from the literal 0
+            if dma and m == 1:
+                E.i(f"s_add_u32 m0, {s(L_M0BASE)}, {par * RAWBUF_B + 4096 * (p // 4)}")
+            E.i(f"v_mfma_f32_16x16x4_f32 {acc}, {v(av + st)}, {v(U0 + 8 * slot + 4 * blk + st)}, {csrc}")
+            if m == 0 and p + 1 < 36:
+                E.i(f"ds_read_b128 {v(AV0 + 4 * ((p + 1) & 1), 4)}, {v(vrd)} offset:{(p + 1) * VPOS_B}")
+                lq.issue(("AV", p + 1))
+            if dma and m == 1:
+                E.i(f"buffer_load_dwordx4 {v(V_VOFF0 + p // 4)}, {s(R_IN, 4)}, {s(L_DMAOFF)} offen lds")
+            if m == 3:
+                for act in valu:
+                    if act[0] == "waitL":
+                        waitcnt(E, lgkm=lq.wait_count(("L", act[1])))
+                    elif act[0] == "C":
+                        tr_col(E, role, act[1])
+                    elif act[0] == "P":
+                        tr_prep(E, act[1])
+                    elif act[0] == "S":
+                        for n, nu in enumerate(act[2]):
+                            tr_store_calc(E, act[1], nu, TV0 + 4 * n)
+                            pending_writes.append((act[1], nu, TV0 + 4 * n))
+                for act in ldsops:
+                    tr_load(E, role, act[1], rbuf, lq)
+            if m >= 4 and pending_writes and m - 4 < 3:
+                row, nu, src = pending_writes.pop(0)
+                tr_write(E, row, nu, src, wbuf, lq)
+            if m == 6 or m == 7:
+                if kind == "last" and p == 36 - UD and m == 6:
+                    E.i(f"s_mov_b32 {s(L_UOFF)}, {s(N_UBASE)}")        # the ring now fills with the NEXT tile's first positions
+                E.i(f"buffer_load_dwordx4 {v(U0 + 8 * slot + 4 * blk, 4)}, {v(V_UVOFF)}, {s(R_U, 4)}, {s(L_UOFF)} offen" +
+                    (" offset:1024" if blk else ""))
+        assert not pending_writes
+        E.i(f"s_add_u32 {s(L_UOFF)}, {s(L_UOFF)}, {s(A_UPOS)}")
+        if p == 20:
+            E.i(f"s_add_u32 {s(L_DMAOFF)}, {s(L_DMAOFF)}, 64")
+    # every LDS-DMA of this body landed (the 32 refills of positions 20..35 are younger), every V write done; then the barrier.
+    # The last body waits for everything: the next tile's ring and both of its raw chunks are complete before the epilogue's stores
+    # enter the queue (vmcnt counts loads and stores together, in order).
+    waitcnt(E, vm=0 if kind == "last" else 32, lgkm=0)
+    E.i("s_barrier")
+
+
+# ----------------------------------------------------------------------------------------------------------------- set-up
+def mul64_add(E, dst_pair, base_pair, a_s, b_s):
+    """s[dst:dst+1] = s[base:base+1] + a * b (unsigned 32 x 32 -> 64)"""
+    E.i(f"s_mul_i32 {s(S_T3)}, {s(a_s)}, {s(b_s)}")
+    E.i(f"s_mul_hi_u32 {s(S_T4)}, {s(a_s)}, {s(b_s)}")
+    E.i(f"s_add_u32 {s(dst_pair)}, {s(base_pair)}, {s(S_T3)}")
+    E.i(f"s_addc_u32 {s(dst_pair + 1)}, {s(base_pair + 1)}, {s(S_T4)}")
+
+
+def udiv_magic(E, q, n, magic):
+    """q = n / d with magic = ceil(2^32 / d) (exact while n * d < 2^32); magic == 0 encodes d == 1"""
+    E.i(f"s_mul_hi_u32 {s(q)}, {s(n)}, {s(magic)}")
+    E.i(f"s_cmp_eq_u32 {s(magic)}, 0")
+    E.i(f"s_cselect_b32 {s(q)}, {s(n)}, {s(q)}")
+
+
+def emit_setup_tile(E):
+    """Decode the logical tile index in s[S_T0] and make it the NEXT tile: LDS-DMA descriptor and per-lane offsets (what the raw
+    loads use from now on), U base, output bases / offsets for its epilogue, its bias values.  Uses s3..s7, v216..v223, vcc."""
+    nt, tx, ty, b = S_T1, S_T2, S_T3, S_T4      # re-used below once consumed
+    # n_tile = L / m_tiles, m = L % m_tiles
+    udiv_magic(E, S_T1, S_T0, A_MAGM)
+    E.i(f"s_mul_i32 {s(S_T2)}, {s(S_T1)}, {s(A_MT)}")
+    E.i(f"s_sub_u32 {s(S_T0)}, {s(S_T0)}, {s(S_T2)}")                       # m
+    E.i(f"s_lshl_b32 {s(N_UBASE)}, {s(S_T1)}, 13")                           # n_tile * 128 channels * 64 bytes
+    E.i(f"s_lshl_b32 {s(N_TOUT)}, {s(S_T1)}, 9")                             # n_tile * 128 channels * 4 bytes (outputs)
+    E.i(f"s_mov_b32 {s(N_TPOOL)}, {s(N_TOUT)}")
+    # bias of this channel group: issued now, consumed at the start of the tile
+    E.i(f"v_add_u32 {v(V_T0)}, {s(N_TOUT)}, {v(V_CHAN4)}")
+    E.i(f"global_load_dword {v(V_BIAS0)}, {v(V_T0)}, {s(A_BIAS, 2)}")
+    E.i(f"global_load_dword {v(V_BIAS1)}, {v(V_T0)}, {s(A_BIAS, 2)} offset:64")
+    # q1 = m / tiles_x, tx = m % tiles_x; b = q1 / tiles_y, ty = q1 % tiles_y
+    udiv_magic(E, S_T1, S_T0, A_MAGX)
+    E.i(f"s_mul_i32 {s(S_T2)}, {s(S_T1)}, {s(A_TX)}")
+    E.i(f"s_sub_u32 {s(S_T2)}, {s(S_T0)}, {s(S_T2)}")                       # tx
+    udiv_magic(E, S_T4, S_T1, A_MAGY)                                          # b
+    E.i(f"s_mul_i32 {s(S_T3)}, {s(S_T4)}, {s(A_TY)}")
+    E.i(f"s_sub_u32 {s(S_T3)}, {s(S_T1)}, {s(S_T3)}")                       # ty
+    # descriptors: in (LDS-DMA), next out, next pool -- base + b * image bytes
+    E.i(f"s_mov_b32 {s(S_T0)}, {s(S_T4)}")                                   # b (mul64_add clobbers T3/T4)
+    E.i(f"s_lshl_b32 {s(S_T1)}, {s(S_T3)}, 4")                               # by0
+    E.i(f"s_lshl_b32 {s(S_T2)}, {s(S_T2)}, 4")                               # bx0
+    mul64_add(E, R_IN, A_IN, S_T0, A_IMGIN)
+    E.i(f"s_and_b32 {s(R_IN + 1)}, {s(R_IN + 1)}, 0xffff")
+    mul64_add(E, N_OUTB, A_OUT, S_T0, A_IMGOUT)
+    E.i(f"s_and_b32 {s(N_OUTB + 1)}, {s(N_OUTB + 1)}, 0xffff")
+    mul64_add(E, N_POOLB, A_POOL, S_T0, A_IMGPOOL)
+    E.i(f"s_and_b32 {s(N_POOLB + 1)}, {s(N_POOLB + 1)}, 0xffff")
+    # pixel offsets
+    E.i(f"s_mul_i32 {s(S_T3)}, {s(S_T1)}, {s(A_W)}")
+    E.i(f"s_add_u32 {s(S_T3)}, {s(S_T3)}, {s(S_T2)}")                       # by0 * W + bx0
+    E.i(f"s_mul_i32 {s(L_BASEPIX)}, {s(S_T3)}, {s(A_PIXIN)}")
+    E.i(f"s_mul_i32 {s(S_T4)}, {s(S_T3)}, {s(A_PIXOUT)}")
+    E.i(f"s_add_u32 {s(N_TOUT)}, {s(N_TOUT)}, {s(S_T4)}")
+    E.i(f"s_lshr_b32 {s(S_T3)}, {s(S_T1)}, 1")                               # by0 / 2
+    E.i(f"s_lshr_b32 {s(S_T4)}, {s(A_W)}, 1")                                # Wp
+    E.i(f"s_mul_i32 {s(S_T3)}, {s(S_T3)}, {s(S_T4)}")
+    E.i(f"s_lshr_b32 {s(S_T4)}, {s(S_T2)}, 1")                               # bx0 / 2
+    E.i(f"s_add_u32 {s(S_T3)}, {s(S_T3)}, {s(S_T4)}")
+    E.i(f"s_mul_i32 {s(S_T3)}, {s(S_T3)}, {s(A_PIXPOOL)}")
+    E.i(f"s_add_u32 {s(N_TPOOL)}, {s(N_TPOOL)}, {s(S_T3)}")
+    E.i(f"s_sub_u32 {s(L_BY0M1)}, {s(S_T1)}, 1")
+    E.i(f"s_sub_u32 {s(L_BX0M1)}, {s(S_T2)}, 1")
+    # per-lane LDS-DMA offsets: zero padding by the buffer range check (voffset 0xFFFFFFFF reads zeros)
+    for j in range(6):
+        E.i(f"v_and_b32 {v(V_T0)}, 0xffff, {v(V_PYPX0 + j)}")
+        E.i(f"v_lshrrev_b32 {v(V_T0 + 1)}, 16, {v(V_PYPX0 + j)}")
+        E.i(f"v_add_u32 {v(V_T0)}, {s(L_BY0M1)}, {v(V_T0)}")
+        E.i(f"v_add_u32 {v(V_T0 + 1)}, {s(L_BX0M1)}, {v(V_T0 + 1)}")
+        E.i(f"v_cmp_gt_u32 vcc, {s(A_H)}, {v(V_T0)}")
+        E.i(f"v_cmp_gt_u32 {s(S_T3, 2)}, {s(A_W)}, {v(V_T0 + 1)}")
+        E.i(f"s_and_b64 vcc, vcc, {s(S_T3, 2)}")
+        E.i(f"v_add_u32 {v(V_T0)}, {s(L_BASEPIX)}, {v(V_REL0 + j)}")
+        E.i(f"v_cndmask_b32 {v(V_VOFF0 + j)}, -1, {v(V_T0)}, vcc")
+
+
+def emit_dma_chunk(E, buf, sidx_range=range(6)):
+    for j in sidx_range:
+        E.i(f"s_add_u32 m0, {s(L_M0BASE)}, {buf * RAWBUF_B + 4096 * j}")
+        E.i("s_nop 0")
+        E.i(f"buffer_load_dwordx4 {v(V_VOFF0 + j)}, {s(R_IN, 4)}, {s(L_DMAOFF)} offen lds")
+
+
+def emit_u_ring_fill(E):
+    for j in range(UD):
+        for blk in range(2):
+            E.i(f"buffer_load_dwordx4 {v(U0 + 8 * j + 4 * blk, 4)}, {v(V_UVOFF)}, {s(R_U, 4)}, {s(L_UOFF)} offen" + (" offset:1024" if blk else ""))
+        E.i(f"s_add_u32 {s(L_UOFF)}, {s(L_UOFF)}, {s(A_UPOS)}")
+
+
+# --------------------------------------------------------------------------------------------------------------- epilogue
+def emit_epilogue(E, pool):
+    """Y = A^T M A in-lane (lane = channel, accumulator register r = tile column, kq = tile row), ReLU by a lower bound, 4x4 stores
+    per tile (+ the 2x2 pooled maxima).  Unit = (channel block, pair of tile columns): packed arithmetic on the register pair."""
+    E.c("epilogue" + (" + pooling" if pool else ""))
+    # per-x voffsets (x = pixel column 0..15 of the block) and per-row scalar offsets
+    E.i(f"v_mov_b32 {v(EP_VX)}, {v(V_OUTOFF)}")
+    for x in range(1, 16):
+        E.i(f"v_add_u32 {v(EP_VX + x)}, {s(A_PIXOUT)}, {v(EP_VX + x - 1)}")
+    E.i(f"s_mul_i32 {s(S_T0)}, {s(A_W)}, {s(A_PIXOUT)}")                     # bytes per image row
+    E.i(f"s_mov_b32 {s(S_ROW)}, {s(C_TOUT)}")
+    for i in range(1, 4):
+        E.i(f"s_add_u32 {s(S_ROW + i)}, {s(S_ROW + i - 1)}, {s(S_T0)}")
+    if pool:
+        E.i(f"v_mov_b32 {v(EP_VXP)}, {v(V_POOLOFF)}")
+        for x in range(1, 8):
+            E.i(f"v_add_u32 {v(EP_VXP + x)}, {s(A_PIXPOOL)}, {v(EP_VXP + x - 1)}")
+        E.i(f"s_lshr_b32 {s(S_T0)}, {s(A_W)}, 1")
+        E.i(f"s_mul_i32 {s(S_T0)}, {s(S_T0)}, {s(A_PIXPOOL)}")               # bytes per pooled row
+        E.i(f"s_mov_b32 {s(S_PROW)}, {s(C_TPOOL)}")
+        E.i(f"s_add_u32 {s(S_PROW + 1)}, {s(S_PROW)}, {s(S_T0)}")
+
+    def pair(reg):
+        return v(reg, 2)
+
+    def first_pass(src6, dst_t, nu_or_i, stride):
+        """src6: six register pairs m0..m5; writes t0..t3 at dst_t + stride * {0,1,2,3} (pairs)"""
+        m = src6
+        s12, d12, s34, d34 = EP_S, EP_S + 2, EP_S + 4, EP_S + 6
+        E.i(f"v_pk_add_f32 {pair(s12)}, {pair(m[1])}, {pair(m[2])}")
+        E.i(f"v_pk_add_f32 {pair(d12)}, {pair(m[1])}, {pair(m[2])} neg_lo:[0,1] neg_hi:[0,1]")
+        E.i(f"v_pk_add_f32 {pair(s34)}, {pair(m[3])}, {pair(m[4])}")
+        E.i(f"v_pk_add_f32 {pair(d34)}, {pair(m[3])}, {pair(m[4])} neg_lo:[0,1] neg_hi:[0,1]")
+        t = [dst_t + stride * i for i in range(4)]
+        E.i(f"v_pk_add_f32 {pair(t[0])}, {pair(m[0])}, {pair(s12)}")
+        E.i(f"v_pk_add_f32 {pair(t[0])}, {pair(t[0])}, {pair(s34)}")
+        E.i(f"v_pk_fma_f32 {pair(t[1])}, {s(K_2, 2)}, {pair(d34)}, {pair(d12)}")
+        E.i(f"v_pk_fma_f32 {pair(t[2])}, {s(K_4, 2)}, {pair(s34)}, {pair(s12)}")
+        E.i(f"v_pk_fma_f32 {pair(t[3])}, {s(K_8, 2)}, {pair(d34)}, {pair(d12)}")
+        E.i(f"v_pk_add_f32 {pair(t[3])}, {pair(t[3])}, {pair(m[5])}")
+
+    for blk in range(2):
+        for h2 in range(2):
+            r0 = 2 * h2
+            # ---- first pass: for every nu, the six xi rows -> t[i][nu] (pairs at EP_T + 2 * (6 * i + nu))
+            for nu in range(6):
+                m = []
+                for xi in range(6):
+                    p = 6 * xi + nu
+                    if p < 32:
+                        dst = EP_M + 2 * xi
+                        E.i(f"v_accvgpr_read_b32 {v(dst)}, {a(8 * p + 4 * blk + r0)}")
+                        E.i(f"v_accvgpr_read_b32 {v(dst + 1)}, {a(8 * p + 4 * blk + r0 + 1)}")
+                        m.append(dst)
+                    else:
+                        m.append(ACCV + 8 * (p - 32) + 4 * blk + r0)
+                first_pass(m, EP_T + 2 * nu, nu, 12)
+            # ---- second pass per output row i
+            for i in range(4):
+                t = [EP_T + 2 * (6 * i + nu) for nu in range(6)]
+                first_pass(t, EP_Y, i, 2)                                    # y[k] pairs at EP_Y + 2 k
+                for k in range(4):
+                    for rr in range(2):
+                        E.i(f"v_max_f32 {v(EP_Y + 2 * k + rr)}, {s(A_RELU)}, {v(EP_Y + 2 * k + rr)}")
+                for k in range(4):
+                    for rr in range(2):
+                        x = 4 * (r0 + rr) + k
+                        E.i(f"buffer_store_dword {v(EP_Y + 2 * k + rr)}, {v(EP_VX + x)}, {s(R_OUT, 4)}, {s(S_ROW + i)} offen" +
+                            (" offset:64" if blk else ""))
+                if pool:
+                    if i % 2 == 0:
+                        for rr in range(2):
+                            E.i(f"v_max_f32 {v(EP_C + rr)}, {v(EP_Y + rr)}, {v(EP_Y + 2 + rr)}")
+                            E.i(f"v_max_f32 {v(EP_C + 2 + rr)}, {v(EP_Y + 4 + rr)}, {v(EP_Y + 6 + rr)}")
+                    else:
+                        for rr in range(2):
+                            E.i(f"v_max3_f32 {v(EP_C + rr)}, {v(EP_Y + rr)}, {v(EP_Y + 2 + rr)}, {v(EP_C + rr)}")
+                            E.i(f"v_max3_f32 {v(EP_C + 2 + rr)}, {v(EP_Y + 4 + rr)}, {v(EP_Y + 6 + rr)}, {v(EP_C + 2 + rr)}")
+                        for rr in range(2):
+                            for j in range(2):
+                                xp = 2 * (r0 + rr) + j
+                                E.i(f"buffer_store_dword {v(EP_C + 2 * j + rr)}, {v(EP_VXP + xp)}, {s(R_POOL, 4)}, {s(S_PROW + (i >> 1))} offen" +
+                                    (" offset:64" if blk else ""))
+
+
+# ----------------------------------------------------------------------------------------------------------------- kernel
+def emit_kernel(E, name):
+    E.lines += [
+        '\t.amdgcn_target "amdgcn-amd-amdhsa--gfx950"',
+        "\t.amdhsa_code_object_version 6",
+        "\t.text",
+        f"\t.protected\t{name}",
+        f"\t.globl\t{name}",
+        "\t.p2align\t8",
+        f"\t.type\t{name},@function",
+        f"{name}:",
+    ]
+    TID, LANE, J16, KQ, TT, TQ, TMPA, TMPB = V_T0, V_T0 + 1, V_T0 + 2, V_T0 + 3, V_T0 + 4, V_T0 + 5, V_T0 + 6, V_T0 + 7
+    E.i(f"s_load_dwordx16 {s(8, 16)}, {s(S_KARG, 2)}, 0x0")
+    E.i(f"s_load_dwordx16 {s(24, 16)}, {s(S_KARG, 2)}, 0x40")
+    E.i(f"v_and_b32 {v(TID)}, 0x3ff, v0")
+    E.i(f"v_lshrrev_b32 {v(TMPA)}, 6, {v(TID)}")
+    # gfx940+: a VALU write of a VGPR needs one wait state before v_readfirstlane reads it (the assembler pads nothing; without it the
+    # wave number was whatever the register held before -- tools/dev/asm_probes/probe_ids.s); a VALU-written SGPR needs two before
+    # another VALU reads it (none does here: every such SGPR goes through SALU first)
+    E.i("s_nop 1")
+    E.i(f"v_readfirstlane_b32 {s(L_WAVE)}, {v(TMPA)}")
+    E.i("s_nop 1")
+    E.i(f"v_and_b32 {v(LANE)}, 63, {v(TID)}")
+    E.i(f"v_and_b32 {v(J16)}, 15, {v(LANE)}")
+    E.i(f"v_lshrrev_b32 {v(KQ)}, 4, {v(LANE)}")
+    E.i(f"v_lshrrev_b32 {v(TT)}, 2, {v(LANE)}")                              # transform tile
+    E.i(f"v_and_b32 {v(TQ)}, 3, {v(LANE)}")                                  # transform channel quad
+    # ---- MFMA-role lane constants
+    E.i(f"v_lshrrev_b32 {v(TMPA)}, 1, {v(J16)}")
+    E.i(f"v_and_b32 {v(TMPA)}, 2, {v(TMPA)}")                                # swz(j16)
+    E.i(f"v_xor_b32 {v(TMPA)}, {v(TMPA)}, {v(KQ)}")
+    E.i(f"v_lshlrev_b32 {v(TMPA)}, 4, {v(TMPA)}")
+    E.i(f"v_lshl_or_b32 {v(V_VRD0)}, {v(J16)}, 6, {v(TMPA)}")
+    E.i(f"v_add_u32 {v(V_VRD1)}, {VBUF_B}, {v(V_VRD0)}")
+    E.i(f"s_lshl_b32 {s(S_T0)}, {s(L_WAVE)}, 11")                            # wave * 32 channels * 64 bytes
+    E.i(f"v_lshlrev_b32 {v(TMPA)}, 4, {v(KQ)}")
+    E.i(f"v_lshl_or_b32 {v(TMPA)}, {v(J16)}, 6, {v(TMPA)}")
+    E.i(f"v_add_u32 {v(V_UVOFF)}, {s(S_T0)}, {v(TMPA)}")
+    E.i(f"s_lshl_b32 {s(S_T0)}, {s(L_WAVE)}, 7")                             # wave * 32 channels * 4 bytes
+    E.i(f"v_lshlrev_b32 {v(TMPA)}, 2, {v(J16)}")
+    E.i(f"v_add_u32 {v(V_CHAN4)}, {s(S_T0)}, {v(TMPA)}")
+    # ---- transform-role lane constants: row0 = 1 (waves 0, 1), wave - 2 (waves 2, 3); xi_a = 1, 3, 0, 5
+    E.i(f"s_sub_u32 {s(S_T0)}, {s(L_WAVE)}, 2")
+    E.i(f"s_cmp_lt_u32 {s(L_WAVE)}, 2")
+    E.i(f"s_cselect_b32 {s(S_T0)}, 1, {s(S_T0)}")                            # row0
+    E.i(f"s_mul_i32 {s(S_T0)}, {s(S_T0)}, {RAW_ROW * 64}")
+    E.i(f"s_add_u32 {s(S_T0)}, {s(S_T0)}, {LDS_R0}")
+    E.i(f"v_lshrrev_b32 {v(TMPA)}, 2, {v(TT)}")                              # ty
+    E.i(f"v_and_b32 {v(TMPB)}, 3, {v(TT)}")                                  # tx
+    E.i(f"v_mul_u32_u24 {v(V_PRD)}, {4 * RAW_ROW * 64}, {v(TMPA)}")
+    E.i(f"v_lshl_add_u32 {v(V_PRD)}, {v(TMPB)}, 6, {v(V_PRD)}")
+    E.i(f"v_lshl_add_u32 {v(V_PRD)}, {v(TQ)}, 4, {v(V_PRD)}")
+    E.i(f"v_add_u32 {v(V_PRD)}, {s(S_T0)}, {v(V_PRD)}")
+    E.i(f"s_cmp_eq_u32 {s(L_WAVE)}, 0")
+    E.i(f"s_cselect_b32 {s(S_T0)}, 1, 3")
+    E.i(f"s_cmp_eq_u32 {s(L_WAVE)}, 2")
+    E.i(f"s_cselect_b32 {s(S_T0)}, 0, {s(S_T0)}")
+    E.i(f"s_cmp_eq_u32 {s(L_WAVE)}, 3")
+    E.i(f"s_cselect_b32 {s(S_T0)}, 5, {s(S_T0)}")                            # xi_a
+    E.i(f"s_mul_i32 {s(S_T0)}, {s(S_T0)}, {6 * VPOS_B}")
+    E.i(f"v_and_b32 {v(TMPA)}, 1, {v(TMPA)}")                                # ty & 1
+    E.i(f"v_lshlrev_b32 {v(TMPA)}, 1, {v(TMPA)}")                            # swz(tile)
+    E.i(f"v_xor_b32 {v(TMPA)}, {v(TMPA)}, {v(TQ)}")
+    E.i(f"v_lshlrev_b32 {v(TMPA)}, 4, {v(TMPA)}")
+    E.i(f"v_lshl_or_b32 {v(TMPA)}, {v(TT)}, 6, {v(TMPA)}")
+    E.i(f"v_add_u32 {v(V_VWR)}, {s(S_T0)}, {v(TMPA)}")
+    # ---- packed constants
+    def kpair(reg, value):
+        E.i(f"s_mov_b32 {s(reg)}, {value}")
+        E.i(f"s_mov_b32 {s(reg + 1)}, {value}")
+    kpair(K_4, "4.0"); kpair(K_M5, "0xc0a00000"); kpair(K_2, "2.0"); kpair(K_M2, "-2.0"); kpair(K_M4, "-4.0"); kpair(K_8, "0x41000000")
+    E.i(f"s_cmp_eq_u32 {s(L_WAVE)}, 0")
+    for reg, v0_, v1_ in ((K_ALPHA, "-4.0", "-1.0"), (K_BETA, "1.0", "2.0"), (K_MBETA, "-1.0", "-2.0")):
+        E.i(f"s_cselect_b32 {s(reg)}, {v0_}, {v1_}")
+        E.i(f"s_mov_b32 {s(reg + 1)}, {s(reg)}")
+    E.i("s_waitcnt lgkmcnt(0)")
+    E.checkpoint(1, "arguments loaded, lane constants of the two roles computed; no vector memory access so far")
+    # ---- LDS-DMA lane constants (need W and the pixel stride)
+    E.i(f"s_lshl_b32 {s(S_T0)}, {s(L_WAVE)}, 10")
+    E.i(f"s_add_u32 {s(L_M0BASE)}, {s(S_T0)}, {LDS_R0}")
+    E.i(f"s_mov_b32 {s(S_T2)}, 3277")
+    for j in range(6):
+        g, py, sl, a5, px = TMPA, TMPB, V_PYPX0 + j, V_REL0 + j, V_VOFF0 + j      # scratch in registers that are defined below
+        E.i(f"s_lshl_b32 {s(S_T0)}, {s(L_WAVE)}, 4")
+        E.i(f"s_add_u32 {s(S_T0)}, {s(S_T0)}, {64 * j}")                     # (wave + 4 j) * 16
+        E.i(f"v_add_u32 {v(g)}, {s(S_T0)}, {v(TT)}")                         # slot index
+        E.i(f"v_mul_lo_u32 {v(py)}, {v(g)}, {s(S_T2)}")
+        E.i(f"v_lshrrev_b32 {v(py)}, 16, {v(py)}")                           # g / 20
+        E.i(f"v_mul_u32_u24 {v(sl)}, 20, {v(py)}")
+        E.i(f"v_sub_u32 {v(sl)}, {v(g)}, {v(sl)}")                           # g % 20
+        E.i(f"v_mul_u32_u24 {v(a5)}, 13, {v(sl)}")
+        E.i(f"v_lshrrev_b32 {v(a5)}, 6, {v(a5)}")                            # sl / 5
+        E.i(f"v_mul_u32_u24 {v(px)}, 5, {v(a5)}")
+        E.i(f"v_sub_u32 {v(px)}, {v(sl)}, {v(px)}")                          # sl % 5
+        E.i(f"v_lshl_add_u32 {v(px)}, {v(px)}, 2, {v(a5)}")                  # pixel column 4 c + a
+        # live = g < 360 && px < 18
+        E.i(f"v_cmp_gt_u32 vcc, 360, {v(g)}")
+        E.i(f"v_cmp_gt_u32 {s(S_T3, 2)}, 18, {v(px)}")
+        E.i(f"s_and_b64 vcc, vcc, {s(S_T3, 2)}")
+        # rel = ((py - 1) * W + (px - 1)) * pixel bytes + 16 * quad
+        E.i(f"v_add_u32 {v(g)}, -1, {v(py)}")
+        E.i(f"v_mul_lo_u32 {v(g)}, {v(g)}, {s(A_W)}")
+        E.i(f"v_add_u32 {v(g)}, {v(g)}, {v(px)}")
+        E.i(f"v_add_u32 {v(g)}, -1, {v(g)}")
+        E.i(f"v_mul_lo_u32 {v(g)}, {v(g)}, {s(A_PIXIN)}")
+        E.i(f"v_lshl_add_u32 {v(V_REL0 + j)}, {v(TQ)}, 4, {v(g)}")
+        # pypx = py | px << 16; dead slots get row 0x7fff (never inside an image)
+        E.i(f"v_lshl_or_b32 {v(py)}, {v(px)}, 16, {v(py)}")
+        E.i(f"v_mov_b32 {v(g)}, 0x7fff")
+        E.i(f"v_cndmask_b32 {v(V_PYPX0 + j)}, {v(g)}, {v(py)}, vcc")
+    # ---- output lane constants
+    E.i(f"s_lshl_b32 {s(S_T0)}, {s(A_W)}, 2")
+    E.i(f"s_mul_i32 {s(S_T0)}, {s(S_T0)}, {s(A_PIXOUT)}")                    # 4 rows of pixels
+    E.i(f"v_mul_lo_u32 {v(TMPA)}, {v(KQ)}, {s(S_T0)}")
+    E.i(f"v_add_u32 {v(TMPA)}, {v(TMPA)}, {v(V_CHAN4)}")
+    E.i(f"v_add_u32 {v(V_OUTOFF)}, {s(A_COOFF)}, {v(TMPA)}")
+    E.i(f"s_mul_i32 {s(S_T0)}, {s(A_W)}, {s(A_PIXPOOL)}")                    # 2 pooled rows = W/2 * 2 pixels
+    E.i(f"v_mul_lo_u32 {v(TMPA)}, {v(KQ)}, {s(S_T0)}")
+    E.i(f"v_add_u32 {v(V_POOLOFF)}, {v(TMPA)}, {v(V_CHAN4)}")
+    # ---- descriptors that never change
+    E.i(f"s_mov_b32 {s(R_U)}, {s(A_U)}")
+    E.i(f"s_and_b32 {s(R_U + 1)}, {s(A_U + 1)}, 0xffff")
+    E.i(f"s_mov_b32 {s(R_U + 2)}, {s(A_UBYTES)}")
+    E.i(f"s_mov_b32 {s(R_U + 3)}, 0x00020000")
+    E.i(f"s_mov_b32 {s(R_IN + 2)}, {s(A_IMGIN)}")
+    E.i(f"s_mov_b32 {s(R_IN + 3)}, 0x00020000")
+    E.i(f"s_mov_b32 {s(R_OUT + 2)}, {s(A_IMGOUT)}")
+    E.i(f"s_mov_b32 {s(R_OUT + 3)}, 0x00020000")
+    E.i(f"s_mov_b32 {s(R_POOL + 2)}, {s(A_IMGPOOL)}")
+    E.i(f"s_mov_b32 {s(R_POOL + 3)}, 0x00020000")
+    # ---- this workgroup's share of its XCD's logical tile range (csrc/kernel_common.h: blocks b and b + 8 share an XCD)
+    E.i(f"s_and_b32 {s(S_T0)}, {s(S_WG)}, 7")                                # xcd
+    E.i(f"s_lshr_b32 {s(L_TT)}, {s(S_WG)}, 3")                               # slot
+    E.i(f"s_lshr_b32 {s(L_SLOTS)}, {s(A_GRID)}, 3")
+    E.i(f"s_and_b32 {s(S_T1)}, {s(A_GRID)}, 7")
+    E.i(f"s_cmp_lt_u32 {s(S_T0)}, {s(S_T1)}")
+    E.i(f"s_addc_u32 {s(L_SLOTS)}, {s(L_SLOTS)}, 0")                         # + (xcd < G & 7)
+    E.i(f"s_lshr_b32 {s(S_T1)}, {s(A_NWG)}, 3")                              # q
+    E.i(f"s_and_b32 {s(S_T2)}, {s(A_NWG)}, 7")                               # r
+    E.i(f"s_min_u32 {s(S_T3)}, {s(S_T0)}, {s(S_T2)}")                        # min(xcd, r)
+    E.i(f"s_mul_i32 {s(L_TSTART)}, {s(S_T0)}, {s(S_T1)}")
+    E.i(f"s_add_u32 {s(L_TSTART)}, {s(L_TSTART)}, {s(S_T3)}")                # xcd * q + min(xcd, r)
+    E.i(f"s_cmp_lt_u32 {s(S_T0)}, {s(S_T2)}")
+    E.i(f"s_addc_u32 {s(L_TCOUNT)}, {s(S_T1)}, 0")                           # q + (xcd < r)
+    E.i(f"s_cmp_ge_u32 {s(L_TT)}, {s(L_TCOUNT)}")
+    E.i("s_cbranch_scc1 .Lend_program")
+    # ---- first tile: set up, open its loads
+    E.i(f"s_add_u32 {s(S_T0)}, {s(L_TSTART)}, {s(L_TT)}")
+    E.checkpoint(2, "tile range of this workgroup known")
+    emit_setup_tile(E)
+    E.checkpoint(3, "first tile decoded, its two bias loads issued")
+    E.i(f"s_mov_b32 {s(N_HAS)}, 1")
+    E.i(f"s_mov_b32 {s(L_UOFF)}, {s(N_UBASE)}")
+    E.i(f"s_mov_b32 {s(L_DMAOFF)}, 0")
+    emit_dma_chunk(E, 0)
+    E.i(f"s_mov_b32 {s(L_DMAOFF)}, 64")
+    emit_dma_chunk(E, 1)
+    E.i(f"s_mov_b32 {s(L_DMAOFF)}, 128")
+    E.checkpoint(4, "LDS-DMA of the first two raw chunks issued")
+    emit_u_ring_fill(E)
+    E.checkpoint(5, "U ring filled")
+    E.i("s_waitcnt vmcnt(0)")
+    E.i("s_barrier")
+    E.i(f"s_cmp_lt_u32 {s(L_WAVE)}, 2")
+    E.i("s_cbranch_scc0 .Lrole_B")
+    for role in ("A", "B"):
+        R = role
+        E.label(f".Lrole_{R}")
+        emit_transform_alone(E, role, 0, 0)
+        E.checkpoint(6, "first transform done")
+        E.i(f"s_branch .Ljoin_{R}")
+        # ================================================================================================ tile loop
+        E.label(f".Ltile_{R}")
+        E.checkpoint(7, "joined: bias in the accumulators, V0 complete")
+        emit_body(E, role, 0, "first")
+        E.checkpoint(8, "first chunk done")
+        E.label(f".Lloop_{R}")
+        emit_body(E, role, 1, "mid")
+        E.i(f"s_cmp_eq_u32 {s(L_PAIRS)}, 1")
+        E.i(f"s_cbranch_scc0 .Lnosetup_{R}")
+        # ---- the next tile: from here on the LDS-DMA loads fetch ITS first two chunks
+        E.i(f"s_add_u32 {s(S_T0)}, {s(L_TT)}, {s(L_SLOTS)}")
+        E.i(f"s_mov_b32 {s(L_DMAOFF)}, 0")
+        E.i(f"s_mov_b32 {s(N_HAS)}, 0")
+        E.i(f"s_cmp_lt_u32 {s(S_T0)}, {s(L_TCOUNT)}")
+        E.i(f"s_cbranch_scc0 .Lnosetup_{R}")
+        E.i(f"s_mov_b32 {s(N_HAS)}, 1")
+        E.i(f"s_add_u32 {s(S_T0)}, {s(S_T0)}, {s(L_TSTART)}")
+        emit_setup_tile(E)
+        E.label(f".Lnosetup_{R}")
+        emit_body(E, role, 0, "mid")
+        E.i(f"s_sub_u32 {s(L_PAIRS)}, {s(L_PAIRS)}, 1")
+        E.i(f"s_cmp_lg_u32 {s(L_PAIRS)}, 0")
+        E.i(f"s_cbranch_scc1 .Lloop_{R}")
+        emit_body(E, role, 1, "last")
+        E.checkpoint(9, "every chunk of the tile done; epilogue next")
+        # ---- the next tile's first transform (its chunk 0 is in Raw0), then this tile's epilogue
+        E.i(f"s_cmp_eq_u32 {s(N_HAS)}, 0")
+        E.i(f"s_cbranch_scc1 .Lepi_{R}")
+        emit_transform_alone(E, role, 0, 0)
+        E.label(f".Lepi_{R}")
+        E.i("s_nop 7")
+        E.i("s_nop 7")
+        E.i("s_branch .Lepilogue")                                          # one copy for both roles; it returns by wave number
+        E.label(f".Lepi_done_{R}")
+        E.i(f"s_cmp_eq_u32 {s(N_HAS)}, 0")
+        E.i("s_cbranch_scc1 .Lend_program")
+        E.i(f"s_add_u32 {s(L_TT)}, {s(L_TT)}, {s(L_SLOTS)}")
+        # ---- join: the next tile becomes the current one
+        E.label(f".Ljoin_{R}")
+        E.i(f"s_mov_b32 {s(R_OUT)}, {s(N_OUTB)}")
+        E.i(f"s_mov_b32 {s(R_OUT + 1)}, {s(N_OUTB + 1)}")
+        E.i(f"s_mov_b32 {s(R_POOL)}, {s(N_POOLB)}")
+        E.i(f"s_mov_b32 {s(R_POOL + 1)}, {s(N_POOLB + 1)}")
+        E.i(f"s_mov_b32 {s(C_TOUT)}, {s(N_TOUT)}")
+        E.i(f"s_mov_b32 {s(C_TPOOL)}, {s(N_TPOOL)}")
+        E.i(f"s_lshr_b32 {s(L_PAIRS)}, {s(A_NCH)}, 1")
+        E.i(f"s_sub_u32 {s(L_PAIRS)}, {s(L_PAIRS)}, 1")
+        # bias = the initial value of position (xi, nu) = (1, 1): A^T e1 e1^T A is the all-ones tile
+        for blk in range(2):
+            for r in range(4):
+                E.i(f"v_accvgpr_write_b32 {a(8 * 7 + 4 * blk + r)}, {v(V_BIAS0 + blk)}")
+        E.i("s_waitcnt lgkmcnt(0)")
+        E.i("s_barrier")
+        E.i(f"s_branch .Ltile_{R}")
+    # ---- the epilogue (shared by both roles: it only touches accumulators, lane constants of the MFMA role and scalars)
+    E.label(".Lepilogue")
+    E.i(f"s_bitcmp1_b32 {s(A_FLAGS)}, 0")
+    E.i("s_cbranch_scc0 .Lepi_nopool")
+    emit_epilogue(E, True)
+    E.i("s_branch .Lepi_return")
+    E.label(".Lepi_nopool")
+    emit_epilogue(E, False)
+    E.label(".Lepi_return")
+    E.i(f"s_cmp_lt_u32 {s(L_WAVE)}, 2")
+    E.i("s_cbranch_scc1 .Lepi_done_A")
+    E.i("s_branch .Lepi_done_B")
+    E.label(".Lend_program")
+    E.i("s_waitcnt vmcnt(0) lgkmcnt(0)")
+    E.i("s_endpgm")
+    # the instruction prefetcher runs past s_endpgm: without this pad of s_code_end words (what hipcc emits behind every kernel) the
+    # fetch can leave the code object's mapping -- a "memory access fault" that comes and goes with the allocation layout
+    E.lines += ["\t.p2alignl 6, 3212836864", "\t.fill 256, 4, 3212836864"]
+    E.lines += [
+        "\t.section\t.rodata,\"a\",@progbits",
+        "\t.p2align\t6, 0x0",
+        f"\t.amdhsa_kernel {name}",
+        f"\t\t.amdhsa_group_segment_fixed_size {LDS_BYTES}",
+        "\t\t.amdhsa_private_segment_fixed_size 0",
+        "\t\t.amdhsa_kernarg_size 128",
+        "\t\t.amdhsa_user_sgpr_count 2",
+        "\t\t.amdhsa_user_sgpr_dispatch_ptr 0",
+        "\t\t.amdhsa_user_sgpr_queue_ptr 0",
+        "\t\t.amdhsa_user_sgpr_kernarg_segment_ptr 1",
+        "\t\t.amdhsa_user_sgpr_dispatch_id 0",
+        "\t\t.amdhsa_user_sgpr_kernarg_preload_length 0",
+        "\t\t.amdhsa_user_sgpr_kernarg_preload_offset 0",
+        "\t\t.amdhsa_user_sgpr_private_segment_size 0",
+        "\t\t.amdhsa_uses_dynamic_stack 0",
+        "\t\t.amdhsa_enable_private_segment 0",
+        "\t\t.amdhsa_system_sgpr_workgroup_id_x 1",
+        "\t\t.amdhsa_system_sgpr_workgroup_id_y 0",
+        "\t\t.amdhsa_system_sgpr_workgroup_id_z 0",
+        "\t\t.amdhsa_system_sgpr_workgroup_info 0",
+        "\t\t.amdhsa_system_vgpr_workitem_id 0",
+        "\t\t.amdhsa_next_free_vgpr 512",
+        "\t\t.amdhsa_next_free_sgpr 102",
+        "\t\t.amdhsa_accum_offset 256",
+        "\t\t.amdhsa_reserve_vcc 1",
+        "\t\t.amdhsa_float_round_mode_32 0",
+        "\t\t.amdhsa_float_round_mode_16_64 0",
+        "\t\t.amdhsa_float_denorm_mode_32 3",
+        "\t\t.amdhsa_float_denorm_mode_16_64 3",
+        "\t\t.amdhsa_dx10_clamp 1",
+        "\t\t.amdhsa_ieee_mode 1",
+        "\t\t.amdhsa_fp16_overflow 0",
+        "\t\t.amdhsa_tg_split 0",
+        "\t\t.amdhsa_exception_fp_ieee_invalid_op 0",
+        "\t\t.amdhsa_exception_fp_denorm_src 0",
+        "\t\t.amdhsa_exception_fp_ieee_div_zero 0",
+        "\t\t.amdhsa_exception_fp_ieee_overflow 0",
+        "\t\t.amdhsa_exception_fp_ieee_underflow 0",
+        "\t\t.amdhsa_exception_fp_ieee_inexact 0",
+        "\t\t.amdhsa_exception_int_div_zero 0",
+        "\t.end_amdhsa_kernel",
+        "\t.text",
+        "\t.amdgpu_metadata",
+        "---",
+        "amdhsa.kernels:",
+        "  - .agpr_count:     256",
+        "    .args:",
+        "      - .offset:         0",
+        "        .size:           128",
+        "        .value_kind:     by_value",
+        f"    .group_segment_fixed_size: {LDS_BYTES}",
+        "    .kernarg_segment_align: 8",
+        "    .kernarg_segment_size: 128",
+        "    .max_flat_workgroup_size: 256",
+        f"    .name:           {name}",
+        "    .private_segment_fixed_size: 0",
+        "    .sgpr_count:     108",
+        "    .sgpr_spill_count: 0",
+        f"    .symbol:         {name}.kd",
+        "    .uniform_work_group_size: 1",
+        "    .uses_dynamic_stack: false",
+        "    .vgpr_count:     512",
+        "    .vgpr_spill_count: 0",
+        "    .wavefront_size: 64",
+        "amdhsa.target:   amdgcn-amd-amdhsa--gfx950",
+        "amdhsa.version:",
+        "  - 1",
+        "  - 2",
+        "...",
+        "",
+        "\t.end_amdgpu_metadata",
+    ]
+
+
+def main():
+    global UD, AV0
+    global STOP_AT, DUMP
+    out = sys.argv[1] if len(sys.argv) > 1 else "wino4a_gfx950.s"
+    if "--dump" in sys.argv:
+        DUMP = sys.argv[sys.argv.index("--dump") + 1]
+    if "--stop" in sys.argv:
+        STOP_AT = int(sys.argv[sys.argv.index("--stop") + 1])
+    for g in range(384):
+        assert (g * 3277) >> 16 == g // 20
+    for sl in range(20):
+        assert (sl * 13) >> 6 == sl // 5
+    assert 36 % UD == 0
+    E = Emitter()
+    emit_kernel(E, "conv3x3_wino4a_f32")
+    open(out, "w").write("\n".join(E.lines) + "\n")
+    top = sorted(E.stats.items(), key=lambda kv: -kv[1])[:12]
+    print(f"{out}: {sum(E.stats.values())} instructions; " + ", ".join(f"{k} {n}" for k, n in top), file=sys.stderr)
+
+
+if __name__ == "__main__":
+    main()

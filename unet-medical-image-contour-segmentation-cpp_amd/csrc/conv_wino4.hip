@@ -559,6 +559,16 @@ bool conv3x3_wino4_runs_staged(const ConvArgs &a)
     return one_block && (staged == 2 || (staged == 1 && (wg1 >= 2 * rt.cus || a.ksplit_ws == nullptr)));
 }
 
+// the hand-scheduled persistent form of the two-block kernel (csrc/wino4_asm.cpp) takes the layer when its shape fits the assembly's
+// contract and the grid is not one the launcher below would split K for (single images, deep levels: those keep the hipcc kernel)
+bool conv3x3_wino4_runs_asm(const ConvArgs &a)
+{
+    if (routing_of(a).wino4_asm == 0 || !conv3x3_wino4a_shape_ok(a) || conv3x3_wino4_runs_staged(a)) return false;
+    const long long nwg = (long long)(a.W / 16) * (a.H / 16) * a.B * (a.Cout / 128);
+    const bool split_k = a.ksplit_ws != nullptr && nwg <= 128 && a.Cin / WINO4_KC >= 8;
+    return !split_k;
+}
+
 hipError_t launch_conv3x3_wino4(const ConvArgs &a, hipStream_t s)
 {
     if (a.wpk4 == nullptr || a.Cin % 4 || a.ldc % 4 || a.CoutPad % NPAD) return hipErrorInvalidValue;
@@ -570,6 +580,7 @@ hipError_t launch_conv3x3_wino4(const ConvArgs &a, hipStream_t s)
             return hipErrorInvalidValue;
         return launch_wino4_cfg<1, true>(a, s);
     }
+    if (conv3x3_wino4_runs_asm(a)) return launch_conv3x3_wino4a(a, s);
     if (a.Cout >= 128 && (rem == 0 || rem > 64)) return launch_wino4_cfg<2, false>(a, s);
     return launch_wino4_cfg<1, false>(a, s);
 }

@@ -23,6 +23,7 @@ struct Routing {
     int lprk = 1;             // MIUNET_LPRK: the 128 -> 64 K-split resident-weight kernel (conv_lprk.hip), as lpr
     int convt_lpr = 1;        // MIUNET_CONVT_LPR: as lpr
     int wino4s = 1;           // MIUNET_WINO4S: 0 never, 1 grids that fill the chip twice over, 2 every one-block case
+    int wino4_asm = 1;        // MIUNET_WINO4_ASM: 0 never, 1 the hand-scheduled persistent two-block kernel for the shapes it takes
     bool convt_small = true;  // MIUNET_CONVT_SMALL=0: the per-tap transposed conv never shrinks its tile
     bool first_mfma = true;   // MIUNET_FIRST_MFMA=0: the 16-bit pipelines' first layer stays on the VALU kernel
     static Routing from_env();            // reads the environment and the current device's properties (engine.cpp)
@@ -90,6 +91,12 @@ hipError_t launch_conv3x3_wino4(const ConvArgs &a, hipStream_t s);
 // routes its one-block cases here unless MIUNET_WINO4S=0.
 hipError_t launch_conv3x3_wino4s(const ConvArgs &a, hipStream_t s);
 bool conv3x3_wino4_runs_staged(const ConvArgs &a);   // the routing decision of launch_conv3x3_wino4 (for the launch log)
+// The two-block kernel hand-scheduled in gfx950 assembly and persistent (csrc/asm/gen_wino4_asm.py, csrc/wino4_asm.cpp): same
+// packing (a.wpk4), same tensors.  shape_ok = the contract of the assembly (whole 16x16 blocks, Cin % 32 == 0 and >= 64, Cout % 128
+// == 0, fp32, no fused head); runs_asm = what launch_conv3x3_wino4 decides (shape, MIUNET_WINO4_ASM, not a split-K grid).
+bool conv3x3_wino4a_shape_ok(const ConvArgs &a);
+bool conv3x3_wino4_runs_asm(const ConvArgs &a);
+hipError_t launch_conv3x3_wino4a(const ConvArgs &a, hipStream_t s);
 hipError_t launch_wino_splitk_reduce(const ConvArgs &a, hipStream_t s);   // sums a.ksplit slabs of a.ksplit_ws into a.out
 hipError_t launch_convT2x2_mfma(const ConvArgs &a, hipStream_t s);
 // The transposed conv as four per-tap GEMMs sharing one A operand (convt_taps.hip): a.wpk4 holds the weights packed
