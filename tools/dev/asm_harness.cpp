@@ -29,6 +29,7 @@ int main(int argc, char **argv)
     if (argc < 7) { std::printf("usage: asm_harness file.hsaco B H W Cin Cout [pool]\n"); return 2; }
     const int B = atoi(argv[2]), H = atoi(argv[3]), W = atoi(argv[4]), Cin = atoi(argv[5]), Cout = atoi(argv[6]);
     const bool pool = argc > 7 && std::string(argv[7]) == "pool";
+    const bool stamps = argc > 7 && std::string(argv[7]) == "stamps";   // a --stamps build: the POOL pointer receives [wg][wave][8] cycle sums
     const char *dump_dir = argc > 8 ? argv[8] : nullptr;          // writes in.bin, u.bin, bias.bin, out.bin there
     std::vector<char> blob;
     if (FILE *f = fopen(argv[1], "rb")) { fseek(f, 0, SEEK_END); blob.resize(ftell(f)); fseek(f, 0, SEEK_SET); if (fread(blob.data(), 1, blob.size(), f) != blob.size()) return 2; fclose(f); }
@@ -46,6 +47,7 @@ int main(int argc, char **argv)
     float *d_in, *d_u, *d_b, *d_out, *d_pool = nullptr;
     CK(hipMalloc(&d_in, in_n * 4)); CK(hipMalloc(&d_u, u_n * 4)); CK(hipMalloc(&d_b, Cout * 4)); CK(hipMalloc(&d_out, out_n * 4));
     if (pool) { CK(hipMalloc(&d_pool, out_n)); CK(hipMemset(d_pool, 0xFF, out_n)); }
+    if (stamps) { CK(hipMalloc(&d_pool, 1 << 20)); CK(hipMemset(d_pool, 0, 1 << 20)); }
     CK(hipMemcpy(d_in, h_in.data(), in_n * 4, hipMemcpyHostToDevice));
     CK(hipMemcpy(d_u, h_u.data(), u_n * 4, hipMemcpyHostToDevice));
     CK(hipMemcpy(d_b, h_b.data(), Cout * 4, hipMemcpyHostToDevice));
@@ -62,6 +64,7 @@ int main(int argc, char **argv)
     k.relu_lo = 0.f;
     hipDeviceProp_t p; CK(hipGetDeviceProperties(&p, 0));
     k.grid = k.nwg < p.multiProcessorCount ? k.nwg : p.multiProcessorCount;
+    if (const char *g = getenv("ASM_GRID")) k.grid = atoi(g) < k.grid ? atoi(g) : k.grid;      // fewer workgroups than CUs: what the chip-wide bursts cost
     k.flags = pool ? 1 : 0;
     size_t size = sizeof k;
     void *extra[] = { HIP_LAUNCH_PARAM_BUFFER_POINTER, &k, HIP_LAUNCH_PARAM_BUFFER_SIZE, &size, HIP_LAUNCH_PARAM_END };
@@ -71,6 +74,34 @@ int main(int argc, char **argv)
     CK(hipEventRecord(e1));
     CK(hipDeviceSynchronize());
     float ms = 0; CK(hipEventElapsedTime(&ms, e0, e1));
+    if (stamps) {
+        for (int rep = 0; rep < 3; ++rep) {          // warm clocks and caches, then the measured launch
+            CK(hipMemset(d_pool, 0, 1 << 20));
+            CK(hipEventRecord(e0));
+            CK(hipModuleLaunchKernel(fn, k.grid, 1, 1, 256, 1, 1, 0, nullptr, nullptr, extra));
+            CK(hipEventRecord(e1));
+            CK(hipDeviceSynchronize());
+            CK(hipEventElapsedTime(&ms, e0, e1));
+        }
+        std::vector<uint32_t> st((size_t)k.grid * 4 * 8);
+        CK(hipMemcpy(st.data(), d_pool, st.size() * 4, hipMemcpyDeviceToHost));
+        const char *names[6] = { "first body", "mid bodies", "last body", "first transform (next tile)", "epilogue", "join" };
+        const double tiles = (double)k.nwg / k.grid;
+        std::printf("stamps, %d tiles over %d workgroups (%.2f per workgroup), K = %d chunks, launch %.3f ms; cycles per TILE, mean over workgroups:\n", k.nwg, k.grid, tiles, k.nchunks, ms);
+        for (int w = 0; w < 4; w += 2) {
+            double tot = 0;
+            std::printf("  wave %d (%s):", w, w == 0 ? "two-row role" : "one-row role");
+            for (int ph = 0; ph < 6; ++ph) {
+                double sum = 0;
+                for (int g = 0; g < k.grid; ++g) sum += st[((size_t)g * 4 + w) * 8 + ph];
+                sum /= k.grid * tiles;
+                tot += sum;
+                std::printf(" %s %.0f%s", names[ph], sum, ph == 1 && k.nchunks > 2 ? (std::string(" (") + std::to_string((int)(sum / (k.nchunks - 2))) + " per chunk)").c_str() : "");
+                std::printf(";");
+            }
+            std::printf(" total %.0f\n", tot);
+        }
+    }
     std::vector<float> h_out(out_n);
     CK(hipMemcpy(h_out.data(), d_out, out_n * 4, hipMemcpyDeviceToHost));
     size_t nan = 0; double sum = 0;

@@ -93,6 +93,9 @@ def s(n, cnt=1):
     return f"s{n}" if cnt == 1 else f"s[{n}:{n + cnt - 1}]"
 
 
+DMA_POS = (0, 4, 8, 12, 16, 20)   # positions of a chunk body at which the six LDS-DMA loads of the raw patch are issued (tuning: --dma-pos)
+TIMING_ONLY = ""             # tuning builds with WRONG results: "notransform" | "nodma"
+STAMPS = False               # bring-up / tuning: s_memtime stamps at the phase boundaries of a tile, summed per wave, written to the POOL pointer
 DUMP = ""                    # bring-up: at the checkpoint, workgroup 0 writes "lds" | "vgpr" | "agpr" to the OUTPUT buffer instead of going on
 STOP_AT = 0                  # bring-up: leave the kernel at checkpoint N (0 = run everything); gen_wino4_asm.py out.s --stop N
 
@@ -124,6 +127,21 @@ class Emitter:
     def new(self, stem):
         self.uid += 1
         return f".L{stem}_{self.uid}"
+
+
+V_ST = V_T0 + 2              # six per-wave phase sums (stamp builds only; v216 / v217 stay the set-up code's temporaries)
+S_PREV = S_PROW + 1
+
+
+def stamp(E, k):
+    """tuning builds: add the cycles since the previous stamp to phase k (only at points where lgkmcnt is 0 and s3..s7 are dead)"""
+    if not STAMPS:
+        return
+    E.i(f"s_memtime {s(S_T3, 2)}")
+    E.i("s_waitcnt lgkmcnt(0)")
+    E.i(f"s_sub_u32 {s(S_T2)}, {s(S_T3)}, {s(S_PREV)}")
+    E.i(f"v_add_u32 {v(V_ST + k)}, {s(S_T2)}, {v(V_ST + k)}")
+    E.i(f"s_mov_b32 {s(S_PREV)}, {s(S_T3)}")
 
 
 def emit_dump(E, what):
@@ -341,7 +359,7 @@ def emit_transform_alone(E, role, rbuf, wbuf):
 def vm_wait_for_position(p):
     """vmcnt that guarantees the U fragments of position p: they were issued at the end of position p - UD; younger than them are
     the refills of positions p-UD+1 .. p-1 (two each) and the LDS-DMA loads issued in positions p-UD+1 .. p-1 of this body"""
-    dmas = sum(1 for q in range(max(0, p - UD + 1), p) if q % 4 == 0 and q < 24)
+    dmas = sum(1 for q in DMA_POS if max(0, p - UD + 1) <= q < p)
     return 2 * (UD - 1) + dmas
 
 
@@ -350,7 +368,7 @@ def emit_body(E, role, par, kind):
     patch two chunks ahead into Raw[par], and (kind != last) the transform Raw[par^1] -> V[par^1] of the next chunk."""
     assert kind in ("first", "mid", "last")
     lq = LdsQueue()
-    sch = transform_schedule(role) if kind != "last" else {}
+    sch = transform_schedule(role) if (kind != "last" and TIMING_ONLY != "notransform") else {}
     vrd = V_VRD0 if par == 0 else V_VRD1
     rbuf = wbuf = par ^ 1
     E.c(f"---- chunk body: role {role}, V{par}, {kind}")
@@ -363,19 +381,21 @@ def emit_body(E, role, par, kind):
         vm = None if (kind == "first" and p < UD) else vm_wait_for_position(p)
         waitcnt(E, vm=vm, lgkm=lq.wait_count(("AV", p)))
         valu, ldsops = sch.get(p, ([], []))
-        dma = (p % 4 == 0 and p < 24)
+        dma_idx = [j for j, q in enumerate(DMA_POS) if q == p] if TIMING_ONLY != "nodma" else []      # (at most two per position)
         for m in range(8):
             st, blk = m >> 1, m & 1
             acc = acc_reg(p, blk)
             csrc = "0" if (kind == "first" and p != 7 and st == 0) else acc      # a tile's first MFMA of a chain starts from the literal 0
-            if dma and m == 1:
-                E.i(f"s_add_u32 m0, {s(L_M0BASE)}, {par * RAWBUF_B + 4096 * (p // 4)}")
+            for n, j in enumerate(dma_idx):
+                if m == 1 + 2 * n:
+                    E.i(f"s_add_u32 m0, {s(L_M0BASE)}, {par * RAWBUF_B + 4096 * j}")
             E.i(f"v_mfma_f32_16x16x4_f32 {acc}, {v(av + st)}, {v(U0 + 8 * slot + 4 * blk + st)}, {csrc}")
             if m == 0 and p + 1 < 36:
                 E.i(f"ds_read_b128 {v(AV0 + 4 * ((p + 1) & 1), 4)}, {v(vrd)} offset:{(p + 1) * VPOS_B}")
                 lq.issue(("AV", p + 1))
-            if dma and m == 1:
-                E.i(f"buffer_load_dwordx4 {v(V_VOFF0 + p // 4)}, {s(R_IN, 4)}, {s(L_DMAOFF)} offen lds")
+            for n, j in enumerate(dma_idx):
+                if m == 1 + 2 * n:
+                    E.i(f"buffer_load_dwordx4 {v(V_VOFF0 + j)}, {s(R_IN, 4)}, {s(L_DMAOFF)} offen lds")
             if m == 3:
                 for act in valu:
                     if act[0] == "waitL":
@@ -400,12 +420,16 @@ def emit_body(E, role, par, kind):
                     (" offset:1024" if blk else ""))
         assert not pending_writes
         E.i(f"s_add_u32 {s(L_UOFF)}, {s(L_UOFF)}, {s(A_UPOS)}")
-        if p == 20:
+        if p == max(DMA_POS):
             E.i(f"s_add_u32 {s(L_DMAOFF)}, {s(L_DMAOFF)}, 64")
-    # every LDS-DMA of this body landed (the 32 refills of positions 20..35 are younger), every V write done; then the barrier.
+    # every LDS-DMA of this body landed (the refills of the positions from the last DMA on are younger), every V write done; then the barrier.
     # The last body waits for everything: the next tile's ring and both of its raw chunks are complete before the epilogue's stores
     # enter the queue (vmcnt counts loads and stores together, in order).
-    waitcnt(E, vm=0 if kind == "last" else 32, lgkm=0)
+    vm_end = 2 * (36 - max(DMA_POS))
+    if vm_end > 63:              # the U waits of positions >= max(DMA_POS) + UD + 1 already cover every LDS-DMA of this body
+        assert max(DMA_POS) + UD + 1 <= 35
+        vm_end = None
+    waitcnt(E, vm=0 if kind == "last" else vm_end, lgkm=0)
     E.i("s_barrier")
 
 
@@ -748,6 +772,12 @@ def emit_kernel(E, name):
     E.checkpoint(5, "U ring filled")
     E.i("s_waitcnt vmcnt(0)")
     E.i("s_barrier")
+    if STAMPS:
+        for k in range(6):
+            E.i(f"v_mov_b32 {v(V_ST + k)}, 0")
+        E.i(f"s_memtime {s(S_T3, 2)}")
+        E.i("s_waitcnt lgkmcnt(0)")
+        E.i(f"s_mov_b32 {s(S_PREV)}, {s(S_T3)}")
     E.i(f"s_cmp_lt_u32 {s(L_WAVE)}, 2")
     E.i("s_cbranch_scc0 .Lrole_B")
     for role in ("A", "B"):
@@ -759,7 +789,9 @@ def emit_kernel(E, name):
         # ================================================================================================ tile loop
         E.label(f".Ltile_{R}")
         E.checkpoint(7, "joined: bias in the accumulators, V0 complete")
+        stamp(E, 5)
         emit_body(E, role, 0, "first")
+        stamp(E, 0)
         E.checkpoint(8, "first chunk done")
         E.label(f".Lloop_{R}")
         emit_body(E, role, 1, "mid")
@@ -779,7 +811,9 @@ def emit_kernel(E, name):
         E.i(f"s_sub_u32 {s(L_PAIRS)}, {s(L_PAIRS)}, 1")
         E.i(f"s_cmp_lg_u32 {s(L_PAIRS)}, 0")
         E.i(f"s_cbranch_scc1 .Lloop_{R}")
+        stamp(E, 1)
         emit_body(E, role, 1, "last")
+        stamp(E, 2)
         E.checkpoint(9, "every chunk of the tile done; epilogue next")
         # ---- the next tile's first transform (its chunk 0 is in Raw0), then this tile's epilogue
         E.i(f"s_cmp_eq_u32 {s(N_HAS)}, 0")
@@ -788,8 +822,10 @@ def emit_kernel(E, name):
         E.label(f".Lepi_{R}")
         E.i("s_nop 7")
         E.i("s_nop 7")
+        stamp(E, 3)
         E.i("s_branch .Lepilogue")                                          # one copy for both roles; it returns by wave number
         E.label(f".Lepi_done_{R}")
+        stamp(E, 4)
         E.i(f"s_cmp_eq_u32 {s(N_HAS)}, 0")
         E.i("s_cbranch_scc1 .Lend_program")
         E.i(f"s_add_u32 {s(L_TT)}, {s(L_TT)}, {s(L_SLOTS)}")
@@ -823,6 +859,13 @@ def emit_kernel(E, name):
     E.i("s_cbranch_scc1 .Lepi_done_A")
     E.i("s_branch .Lepi_done_B")
     E.label(".Lend_program")
+    if STAMPS:
+        E.i(f"s_lshl_b32 {s(S_T0)}, {s(S_WG)}, 2")
+        E.i(f"s_add_u32 {s(S_T0)}, {s(S_T0)}, {s(L_WAVE)}")
+        E.i(f"s_lshl_b32 {s(S_T0)}, {s(S_T0)}, 5")
+        E.i(f"v_mov_b32 {v(V_T0)}, {s(S_T0)}")
+        for k in range(6):
+            E.i(f"global_store_dword {v(V_T0)}, {v(V_ST + k)}, {s(A_POOL, 2)} offset:{4 * k}")
     E.i("s_waitcnt vmcnt(0) lgkmcnt(0)")
     E.i("s_endpgm")
     # the instruction prefetcher runs past s_endpgm: without this pad of s_code_end words (what hipcc emits behind every kernel) the
@@ -905,7 +948,13 @@ def emit_kernel(E, name):
 
 def main():
     global UD, AV0
-    global STOP_AT, DUMP
+    global STOP_AT, DUMP, STAMPS, DMA_POS, TIMING_ONLY
+    if "--dma-pos" in sys.argv:
+        DMA_POS = tuple(int(x) for x in sys.argv[sys.argv.index("--dma-pos") + 1].split(","))
+        assert len(DMA_POS) == 6 and all(DMA_POS.count(q) <= 2 for q in DMA_POS) and max(DMA_POS) < 36 - UD
+    if "--timing-only" in sys.argv:
+        TIMING_ONLY = sys.argv[sys.argv.index("--timing-only") + 1]
+    STAMPS = "--stamps" in sys.argv
     out = sys.argv[1] if len(sys.argv) > 1 else "wino4a_gfx950.s"
     if "--dump" in sys.argv:
         DUMP = sys.argv[sys.argv.index("--dump") + 1]
