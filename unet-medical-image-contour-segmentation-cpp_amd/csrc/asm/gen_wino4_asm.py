@@ -28,13 +28,13 @@ RAW_ROW = 20
 RAW_LOADS = 24               # wave-wide LDS-DMA loads per chunk (23 live + 1 so that every wave issues six)
 RAWBUF_B = RAW_LOADS * 1024  # 24576
 LDS_V0, LDS_V1 = 0, VBUF_B
-LDS_R0 = 2 * VBUF_B          # 73728
-LDS_R1 = LDS_R0 + RAWBUF_B
-LDS_BYTES = LDS_R1 + RAWBUF_B   # 122880
+LDS_R0 = 2 * VBUF_B          # 73728: three raw-patch buffers (chunk G lives in buffer G % 3, G counted across tiles)
+LDS_BYTES = LDS_R0 + 3 * RAWBUF_B   # 147456
 
 # ---------------------------------------------------------------------------------------------------------------- registers
 # SGPRs
-S_KARG = 0          # s[0:1]
+S_KARG = 0          # s[0:1]: the argument pointer; dead once the arguments are loaded, then:
+L_RIDX, L_M0CUR = 0, 1   # raw-buffer index of the current body's chunk (G % 3); LDS address this wave's LDS-DMA loads of the body start at
 S_WG = 2
 S_T0, S_T1, S_T2, S_T3, S_T4 = 3, 4, 5, 6, 7          # temporaries
 A_IN, A_U, A_BIAS, A_OUT, A_POOL = 8, 10, 12, 14, 16   # pointers (pairs)
@@ -93,8 +93,21 @@ def s(n, cnt=1):
     return f"s{n}" if cnt == 1 else f"s[{n}:{n + cnt - 1}]"
 
 
-DMA_POS = (0, 4, 8, 12, 16, 20)   # positions of a chunk body at which the six LDS-DMA loads of the raw patch are issued (tuning: --dma-pos)
-TIMING_ONLY = ""             # tuning builds with WRONG results: "notransform" | "nodma"
+DMA_POS = (0, 2, 4, 6, 8, 10)     # positions of a chunk body at which the six LDS-DMA loads of the raw patch are issued (tuning: --dma-pos;
+                                  # same-card sweep, profiles/r04_ab_asm_dma_positions.txt: early positions 1.6 % faster than every fourth)
+DMA_POS_FIRST = (22, 23, 24, 25, 26, 27)   # ... of a tile's FIRST body: late, once the chip-wide store burst of the epilogues has drained
+                                  # (profiles/r04_asm_stamps.txt: LDS-DMA issued into that burst made the first body 5.8 k cycles longer)
+
+
+def dma_positions(kind):
+    return DMA_POS_FIRST if kind == "first" else DMA_POS
+
+
+def prev_kind(kind):
+    """the body that ran before a body of this kind in steady state (for the LDS-DMA loads still counted by its early U waits)"""
+    return {"first": "last", "mid": "mid", "last": "mid"}[kind]
+U_POLICY = ""                # cache-policy modifier of the U loads (tuning: --u-policy "nt" | "sc0" | "sc1" | "sc0 sc1")
+TIMING_ONLY = ""             # tuning builds with WRONG results: "notransform" | "nodma" | "nouload" | "novread" (comma-separated)
 STAMPS = False               # bring-up / tuning: s_memtime stamps at the phase boundaries of a tile, summed per wave, written to the POOL pointer
 DUMP = ""                    # bring-up: at the checkpoint, workgroup 0 writes "lds" | "vgpr" | "agpr" to the OUTPUT buffer instead of going on
 STOP_AT = 0                  # bring-up: leave the kernel at checkpoint N (0 = run everything); gen_wino4_asm.py out.s --stop N
@@ -162,12 +175,13 @@ def emit_dump(E, what):
     if what == "lds":
         E.i(f"v_lshlrev_b32 {v(o)}, 4, {v(t)}")
         E.i(f"v_add_u32 {v(t)}, 61440, {v(o)}")
+        E.i(f"v_add_u32 {v(V_T0 + 3)}, 122880, {v(o)}")
         for i in range(LDS_BYTES // 4096):
-            base, off = (o, i * 4096) if i < 15 else (t, (i - 15) * 4096)
-            E.i(f"ds_read_b128 {v(V_T0 + 4, 4)}, {v(base)} offset:{off}")
+            base, off = (o, i * 4096) if i < 15 else (t, (i - 15) * 4096) if i < 30 else (V_T0 + 3, (i - 30) * 4096)
+            E.i(f"ds_read_b128 {v(PX0, 4)}, {v(base)} offset:{off}")
             E.i("s_waitcnt lgkmcnt(0)")
             E.i(f"s_mov_b32 {s(S_T1)}, {i * 4096}")
-            E.i(f"buffer_store_dwordx4 {v(V_T0 + 4, 4)}, {v(o)}, {s(S_ROW, 4)}, {s(S_T1)} offen")
+            E.i(f"buffer_store_dwordx4 {v(PX0, 4)}, {v(o)}, {s(S_ROW, 4)}, {s(S_T1)} offen")
             E.i("s_waitcnt vmcnt(0)")
     else:
         E.i(f"v_lshlrev_b32 {v(o)}, 2, {v(t)}")
@@ -261,7 +275,7 @@ def tr_load(E, role, k, rbuf, lq):
     rows = 4 if role == "A" else 3
     rstep = 1 if role == "A" else 2
     for i in range(rows):
-        off = ((k & 3) * 5 + (k >> 2)) * 64 + i * rstep * RAW_ROW * 64 + rbuf * RAWBUF_B
+        off = ((k & 3) * 5 + (k >> 2)) * 64 + i * rstep * RAW_ROW * 64      # (the buffer is in V_PRD: emit_rotate)
         E.i(f"ds_read_b128 {v(px_bank(k) + 4 * i, 4)}, {v(V_PRD)} offset:{off}")
         lq.issue(("L", k))
 
@@ -356,11 +370,17 @@ def emit_transform_alone(E, role, rbuf, wbuf):
 
 
 # ------------------------------------------------------------------------------------------------------------- chunk body
-def vm_wait_for_position(p):
+def vm_wait_for_position(p, kind):
     """vmcnt that guarantees the U fragments of position p: they were issued at the end of position p - UD; younger than them are
-    the refills of positions p-UD+1 .. p-1 (two each) and the LDS-DMA loads issued in positions p-UD+1 .. p-1 of this body"""
-    dmas = sum(1 for q in DMA_POS if max(0, p - UD + 1) <= q < p)
-    return 2 * (UD - 1) + dmas
+    the refills of positions p-UD+1 .. p-1 (two each) and the LDS-DMA loads issued in those positions (of this body, or of the tail
+    of the body before it).  A count that is too SMALL only waits longer, so the previous body is taken as whichever kind issues
+    the fewest loads there -- except that a mid body may follow a first body, whose loads come late: counted exactly for both."""
+    lo, hi = p - UD + 1, p - 1                       # positions whose loads are younger (negative = previous body)
+    here = sum(1 for q in dma_positions(kind) if max(0, lo) <= q <= hi)
+    def tail(k):
+        return sum(1 for q in dma_positions(k) if lo <= q - 36 <= hi)
+    prevs = {"first": ("last",), "mid": ("mid", "first"), "last": ("mid",)}[kind]
+    return 2 * (UD - 1) + here + min(tail(k) for k in prevs)
 
 
 def emit_body(E, role, par, kind):
@@ -368,29 +388,31 @@ def emit_body(E, role, par, kind):
     patch two chunks ahead into Raw[par], and (kind != last) the transform Raw[par^1] -> V[par^1] of the next chunk."""
     assert kind in ("first", "mid", "last")
     lq = LdsQueue()
-    sch = transform_schedule(role) if (kind != "last" and TIMING_ONLY != "notransform") else {}
+    sch = transform_schedule(role) if (kind != "last" and "notransform" not in TIMING_ONLY) else {}
     vrd = V_VRD0 if par == 0 else V_VRD1
     rbuf = wbuf = par ^ 1
     E.c(f"---- chunk body: role {role}, V{par}, {kind}")
+    emit_rotate(E)
+    DMA_HERE = dma_positions(kind)
     E.i(f"ds_read_b128 {v(AV0, 4)}, {v(vrd)} offset:0")
     lq.issue(("AV", 0))
     pending_writes = []          # (row, nu, src) ds_writes to spread over the next MFMA gaps
     for p in range(36):
         av = AV0 + 4 * (p & 1)
         slot = p % UD
-        vm = None if (kind == "first" and p < UD) else vm_wait_for_position(p)
+        vm = None if ((kind == "first" and p < UD) or "nouload" in TIMING_ONLY) else vm_wait_for_position(p, kind)
         waitcnt(E, vm=vm, lgkm=lq.wait_count(("AV", p)))
         valu, ldsops = sch.get(p, ([], []))
-        dma_idx = [j for j, q in enumerate(DMA_POS) if q == p] if TIMING_ONLY != "nodma" else []      # (at most two per position)
+        dma_idx = [j for j, q in enumerate(DMA_HERE) if q == p] if "nodma" not in TIMING_ONLY else []      # (at most two per position)
         for m in range(8):
             st, blk = m >> 1, m & 1
             acc = acc_reg(p, blk)
             csrc = "0" if (kind == "first" and p != 7 and st == 0) else acc      # a tile's first MFMA of a chain starts from the literal 0
             for n, j in enumerate(dma_idx):
                 if m == 1 + 2 * n:
-                    E.i(f"s_add_u32 m0, {s(L_M0BASE)}, {par * RAWBUF_B + 4096 * j}")
+                    E.i(f"s_add_u32 m0, {s(L_M0CUR)}, {4096 * j}")
             E.i(f"v_mfma_f32_16x16x4_f32 {acc}, {v(av + st)}, {v(U0 + 8 * slot + 4 * blk + st)}, {csrc}")
-            if m == 0 and p + 1 < 36:
+            if m == 0 and p + 1 < 36 and "novread" not in TIMING_ONLY:
                 E.i(f"ds_read_b128 {v(AV0 + 4 * ((p + 1) & 1), 4)}, {v(vrd)} offset:{(p + 1) * VPOS_B}")
                 lq.issue(("AV", p + 1))
             for n, j in enumerate(dma_idx):
@@ -413,24 +435,35 @@ def emit_body(E, role, par, kind):
             if m >= 4 and pending_writes and m - 4 < 3:
                 row, nu, src = pending_writes.pop(0)
                 tr_write(E, row, nu, src, wbuf, lq)
-            if m == 6 or m == 7:
+            if (m == 6 or m == 7) and "nouload" not in TIMING_ONLY:
                 if kind == "last" and p == 36 - UD and m == 6:
                     E.i(f"s_mov_b32 {s(L_UOFF)}, {s(N_UBASE)}")        # the ring now fills with the NEXT tile's first positions
                 E.i(f"buffer_load_dwordx4 {v(U0 + 8 * slot + 4 * blk, 4)}, {v(V_UVOFF)}, {s(R_U, 4)}, {s(L_UOFF)} offen" +
-                    (" offset:1024" if blk else ""))
+                    (" offset:1024" if blk else "") + (" " + U_POLICY if U_POLICY else ""))
         assert not pending_writes
         E.i(f"s_add_u32 {s(L_UOFF)}, {s(L_UOFF)}, {s(A_UPOS)}")
-        if p == max(DMA_POS):
+        if p == max(DMA_HERE):
             E.i(f"s_add_u32 {s(L_DMAOFF)}, {s(L_DMAOFF)}, 64")
-    # every LDS-DMA of this body landed (the refills of the positions from the last DMA on are younger), every V write done; then the barrier.
-    # The last body waits for everything: the next tile's ring and both of its raw chunks are complete before the epilogue's stores
-    # enter the queue (vmcnt counts loads and stores together, in order).
-    vm_end = 2 * (36 - max(DMA_POS))
-    if vm_end > 63:              # the U waits of positions >= max(DMA_POS) + UD + 1 already cover every LDS-DMA of this body
-        assert max(DMA_POS) + UD + 1 <= 35
-        vm_end = None
-    waitcnt(E, vm=0 if kind == "last" else vm_end, lgkm=0)
-    E.i("s_barrier")
+    # No vmcnt wait here: the raw chunk these LDS-DMA loads fetch is three chunks ahead and is first read two bodies on; every U wait
+    # of the NEXT body (at most 19 + a few loads may be outstanding there) already implies that they landed, and that body's closing
+    # barrier publishes them to the other waves.  The last body of a tile neither transforms nor writes V: no barrier behind it.
+    if kind != "last":
+        waitcnt(E, lgkm=0)
+        E.i("s_barrier")
+
+
+def emit_rotate(E):
+    """start of every chunk body: the chunk index G advances; r = G % 3 is the raw buffer this body's LDS-DMA fills (chunk G + 3),
+    (r + 1) % 3 the one its transform reads (chunk G + 1) -- V_PRD follows by +1 buffer or -2 buffers, m0's base by SALU"""
+    E.i(f"s_add_u32 {s(L_RIDX)}, {s(L_RIDX)}, 1")
+    E.i(f"s_cmp_eq_u32 {s(L_RIDX)}, 3")
+    E.i(f"s_cselect_b32 {s(L_RIDX)}, 0, {s(L_RIDX)}")
+    E.i(f"s_mul_i32 {s(S_T0)}, {s(L_RIDX)}, {RAWBUF_B}")
+    E.i(f"s_add_u32 {s(L_M0CUR)}, {s(L_M0BASE)}, {s(S_T0)}")
+    E.i(f"s_mov_b32 {s(S_T0)}, {RAWBUF_B}")
+    E.i(f"s_cmp_eq_u32 {s(L_RIDX)}, 2")                                       # then the read buffer wraps from 2 to 0
+    E.i(f"s_cselect_b32 {s(S_T0)}, {-2 * RAWBUF_B & 0xffffffff}, {s(S_T0)}")
+    E.i(f"v_add_u32 {v(V_PRD)}, {s(S_T0)}, {v(V_PRD)}")
 
 
 # ----------------------------------------------------------------------------------------------------------------- set-up
@@ -767,7 +800,10 @@ def emit_kernel(E, name):
     E.i(f"s_mov_b32 {s(L_DMAOFF)}, 64")
     emit_dma_chunk(E, 1)
     E.i(f"s_mov_b32 {s(L_DMAOFF)}, 128")
-    E.checkpoint(4, "LDS-DMA of the first two raw chunks issued")
+    emit_dma_chunk(E, 2)
+    E.i(f"s_mov_b32 {s(L_DMAOFF)}, 192")
+    E.i(f"s_mov_b32 {s(L_RIDX)}, 2")                                         # the first body's rotation makes it 0 (chunk G = 0)
+    E.checkpoint(4, "LDS-DMA of the first three raw chunks issued")
     emit_u_ring_fill(E)
     E.checkpoint(5, "U ring filled")
     E.i("s_waitcnt vmcnt(0)")
@@ -794,10 +830,9 @@ def emit_kernel(E, name):
         stamp(E, 0)
         E.checkpoint(8, "first chunk done")
         E.label(f".Lloop_{R}")
-        emit_body(E, role, 1, "mid")
         E.i(f"s_cmp_eq_u32 {s(L_PAIRS)}, 1")
         E.i(f"s_cbranch_scc0 .Lnosetup_{R}")
-        # ---- the next tile: from here on the LDS-DMA loads fetch ITS first two chunks
+        # ---- the final pair of middle bodies is next: from here on the LDS-DMA loads fetch the NEXT tile's first three chunks
         E.i(f"s_add_u32 {s(S_T0)}, {s(L_TT)}, {s(L_SLOTS)}")
         E.i(f"s_mov_b32 {s(L_DMAOFF)}, 0")
         E.i(f"s_mov_b32 {s(N_HAS)}, 0")
@@ -807,6 +842,7 @@ def emit_kernel(E, name):
         E.i(f"s_add_u32 {s(S_T0)}, {s(S_T0)}, {s(L_TSTART)}")
         emit_setup_tile(E)
         E.label(f".Lnosetup_{R}")
+        emit_body(E, role, 1, "mid")
         emit_body(E, role, 0, "mid")
         E.i(f"s_sub_u32 {s(L_PAIRS)}, {s(L_PAIRS)}, 1")
         E.i(f"s_cmp_lg_u32 {s(L_PAIRS)}, 0")
@@ -815,11 +851,13 @@ def emit_kernel(E, name):
         emit_body(E, role, 1, "last")
         stamp(E, 2)
         E.checkpoint(9, "every chunk of the tile done; epilogue next")
-        # ---- the next tile's first transform (its chunk 0 is in Raw0), then this tile's epilogue
+        # ---- the next tile's first transform (its chunk 0 landed two bodies ago; V0 is free: the last body read V1), then every
+        # load that opens the next tile (U ring, raw chunks 1 and 2, bias) must be home BEFORE the epilogue's stores join the queue
         E.i(f"s_cmp_eq_u32 {s(N_HAS)}, 0")
         E.i(f"s_cbranch_scc1 .Lepi_{R}")
         emit_transform_alone(E, role, 0, 0)
         E.label(f".Lepi_{R}")
+        E.i("s_waitcnt vmcnt(0)")
         E.i("s_nop 7")
         E.i("s_nop 7")
         stamp(E, 3)
@@ -948,10 +986,14 @@ def emit_kernel(E, name):
 
 def main():
     global UD, AV0
-    global STOP_AT, DUMP, STAMPS, DMA_POS, TIMING_ONLY
+    global STOP_AT, DUMP, STAMPS, DMA_POS, TIMING_ONLY, U_POLICY, DMA_POS_FIRST
+    if "--u-policy" in sys.argv:
+        U_POLICY = sys.argv[sys.argv.index("--u-policy") + 1]
+    if "--dma-pos-first" in sys.argv:
+        DMA_POS_FIRST = tuple(int(x) for x in sys.argv[sys.argv.index("--dma-pos-first") + 1].split(","))
     if "--dma-pos" in sys.argv:
         DMA_POS = tuple(int(x) for x in sys.argv[sys.argv.index("--dma-pos") + 1].split(","))
-        assert len(DMA_POS) == 6 and all(DMA_POS.count(q) <= 2 for q in DMA_POS) and max(DMA_POS) < 36 - UD
+        assert len(DMA_POS) == 6 and all(DMA_POS.count(q) <= 2 for q in DMA_POS)
     if "--timing-only" in sys.argv:
         TIMING_ONLY = sys.argv[sys.argv.index("--timing-only") + 1]
     STAMPS = "--stamps" in sys.argv

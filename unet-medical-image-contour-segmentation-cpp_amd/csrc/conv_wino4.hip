@@ -554,7 +554,10 @@ bool conv3x3_wino4_runs_staged(const ConvArgs &a)
     const long long wg1 = (long long)((a.W + 15) / 16) * ((a.H + 15) / 16) * a.B * ((a.Cout + 63) / 64);
     // ... and wider layers whose K loop is at most four chunks (down1.c1, 64 -> 128: 0.521 -> 0.488 ms); with eight chunks and
     // more the two-block kernel's shared forward transform wins (measured on every such layer: 7-20 % slower staged)
-    const bool one_block = a.head_w != nullptr || !(a.Cout >= 128 && (rem == 0 || rem > 64)) || a.Cin <= 64;
+    // ... unless the assembly kernel can take the layer (down1.c1, 64 -> 128: 0.459 -> 0.415 ms same card, profiles/r04_ab_asm_routing.txt;
+    // MIUNET_WINO4_ASM = 3 keeps such a layer on the staged kernel -- A/B switch)
+    const bool asm_takes_k4 = rt.wino4_asm != 0 && rt.wino4_asm != 3 && a.Cin == 64 && conv3x3_wino4a_shape_ok(a);
+    const bool one_block = a.head_w != nullptr || !(a.Cout >= 128 && (rem == 0 || rem > 64)) || (a.Cin <= 64 && !asm_takes_k4);
     // a.ksplit_ws == nullptr is the batch-invariant mode (MIUNET_SPLITK=0): there the choice must not depend on the batch
     return one_block && (staged == 2 || (staged == 1 && (wg1 >= 2 * rt.cus || a.ksplit_ws == nullptr)));
 }

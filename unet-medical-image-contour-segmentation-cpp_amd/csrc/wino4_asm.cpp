@@ -6,8 +6,11 @@
 
 #include <atomic>
 #include <cstdint>
+#include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <mutex>
+#include <vector>
 
 #include "kernels.h"
 
@@ -50,7 +53,18 @@ hipError_t function_for_current_device(hipFunction_t *fn)
     if (hipFunction_t f = d.fn.load(std::memory_order_acquire)) { *fn = f; return hipSuccess; }
     if (d.tried) return d.err;
     d.tried = true;
-    d.err = hipModuleLoadData(&d.mod, miunet_wino4a_hsaco);
+    const void *image = miunet_wino4a_hsaco;
+#ifdef MIUNET_EXPERIMENTS                              // lab build only: a code object FILE instead of the embedded one (same-card A/Bs of kernel variants)
+    static std::vector<char> file_image;
+    if (const char *path = getenv("MIUNET_WINO4A_HSACO")) {
+        if (FILE *f = fopen(path, "rb")) {
+            fseek(f, 0, SEEK_END); file_image.resize((size_t)ftell(f)); fseek(f, 0, SEEK_SET);
+            if (fread(file_image.data(), 1, file_image.size(), f) == file_image.size()) image = file_image.data();
+            fclose(f);
+        }
+    }
+#endif
+    d.err = hipModuleLoadData(&d.mod, image);
     hipFunction_t f = nullptr;
     if (d.err == hipSuccess) d.err = hipModuleGetFunction(&f, d.mod, "conv3x3_wino4a_f32");
     if (d.err != hipSuccess) return d.err;
