@@ -97,3 +97,55 @@ def test_mfma_scanner_sees_both_hazards(tmp_path):
     loop.write_text(".LBB0_1:\n\ts_nop 7\n\ts_nop 7\n\tv_add_f32_e32 v0, v5, v1\n\tv_mfma_f32_16x16x32_bf16 v[4:7], v[8:11], v[12:15], v[4:7]\n"
                     "\ts_cbranch_scc1 .LBB0_1\n\ts_nop 7\n\ts_nop 7\n\ts_endpgm\n")
     assert scan_mfma_hazard.scan(str(loop)) == []
+
+
+# ------------------------------------------------------------------------------------------ the generated assembly kernel
+GEN = os.path.join(CSRC, "asm", "gen_wino4_asm.py")
+LLVM_BIN = "/opt/rocm/lib/llvm/bin"
+
+
+def test_assembly_kernel_scanner_sees_each_hazard(tmp_path):
+    """the assembler pads nothing: tools/dev/scan_asm_kernel.py must flag each wait state LLVM's hazard recognizer would have inserted"""
+    import scan_asm_kernel
+    cases = {
+        "readfirstlane": "\tv_lshrrev_b32 v2, 6, v1\n\tv_readfirstlane_b32 s71, v2\n\ts_endpgm\n",
+        "sgpr_valu": "\tv_cmp_gt_u32 vcc, s18, v216\n\ts_nop 0\n\tv_cndmask_b32 v199, -1, v216, vcc\n\ts_endpgm\n",
+        "sgpr_vmem": "\tv_readfirstlane_b32 s68, v2\n\ts_nop 2\n\tbuffer_load_dwordx4 v[0:3], v190, s[44:47], s68 offen\n\ts_endpgm\n",
+        "m0": "\ts_add_u32 m0, s1, 4096\n\tbuffer_load_dwordx4 v199, s[40:43], s69 offen lds\n\ts_endpgm\n",
+        "mfma": "\tv_mfma_f32_16x16x4_f32 a[0:3], v72, v0, a[0:3]\n\ts_nop 7\n\tv_accvgpr_read_b32 v80, a1\n\ts_endpgm\n",
+        "loop": ".Lhead:\n\tv_accvgpr_read_b32 v80, a1\n\ts_nop 7\n\ts_nop 7\n\tv_mfma_f32_16x16x4_f32 a[0:3], v72, v0, a[0:3]\n\ts_cbranch_scc1 .Lhead\n\ts_endpgm\n",
+    }
+    for name, text in cases.items():
+        p = tmp_path / (name + ".s")
+        p.write_text(text)
+        assert len(scan_asm_kernel.scan(str(p))) == 1, name
+    ok = tmp_path / "ok.s"
+    ok.write_text("\tv_lshrrev_b32 v2, 6, v1\n\ts_nop 0\n\tv_readfirstlane_b32 s71, v2\n\ts_nop 1\n\tv_add_u32 v3, s71, v2\n"
+                  "\ts_add_u32 m0, s1, 4096\n\ts_nop 0\n\tbuffer_load_dwordx4 v199, s[40:43], s69 offen lds\n"
+                  "\tv_mfma_f32_16x16x4_f32 a[0:3], v72, v0, 0\n\tv_mfma_f32_16x16x4_f32 a[0:3], v73, v1, a[0:3]\n\ts_nop 7\n\ts_nop 3\n\tv_accvgpr_read_b32 v80, a1\n\ts_endpgm\n")
+    assert scan_asm_kernel.scan(str(ok)) == []
+
+
+@NEEDS_HIPCC
+def test_generated_assembly_kernel_assembles_and_has_its_wait_states(tmp_path):
+    """csrc/asm/gen_wino4_asm.py -> gfx950 assembly: assembles with the ROCm clang, carries every wait state the assembler does not
+    insert, is padded behind s_endpgm (the instruction prefetcher runs past it), and declares the LDS / registers it uses."""
+    import scan_asm_kernel
+    asm = tmp_path / "wino4a.s"
+    subprocess.run([sys.executable, GEN, str(asm)], check=True, capture_output=True, timeout=300)
+    text = asm.read_text()
+    assert text.count("v_mfma_f32_16x16x4_f32") == 2 * 4 * 288          # two roles x (first, two middle, last) chunk bodies
+    assert ".amdhsa_group_segment_fixed_size 147456" in text and ".amdhsa_next_free_vgpr 512" in text and ".amdhsa_accum_offset 256" in text
+    tail = text[text.rindex("s_endpgm"):]
+    assert ".fill 256, 4, 3212836864" in tail                            # s_nop pad behind the end of the program
+    assert scan_asm_kernel.scan(str(asm)) == []
+    obj = tmp_path / "wino4a.o"
+    subprocess.run([os.path.join(LLVM_BIN, "clang"), "-x", "assembler", "-target", "amdgcn-amd-amdhsa", "-mcpu=gfx950", "-c", str(asm), "-o", str(obj)],
+                   check=True, capture_output=True, timeout=300)
+    assert obj.stat().st_size > 40000
+    # every timing-only / dump / stamp variant of the generator still assembles (they are bring-up tools, never shipped)
+    for flags in (["--stamps"], ["--stop", "5", "--dump", "lds"], ["--timing-only", "nouload,novread,notransform,nodma"], ["--dma-pos", "0,4,8,12,16,20"]):
+        v = tmp_path / "variant.s"
+        subprocess.run([sys.executable, GEN, str(v)] + flags, check=True, capture_output=True, timeout=300)
+        subprocess.run([os.path.join(LLVM_BIN, "clang"), "-x", "assembler", "-target", "amdgcn-amd-amdhsa", "-mcpu=gfx950", "-c", str(v), "-o", str(obj)],
+                       check=True, capture_output=True, timeout=300)

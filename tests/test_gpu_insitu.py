@@ -121,7 +121,7 @@ def test_fp32_plan_every_layer_at_512_batch_16():
     rep = _check_layers("winograd", UNetSpec(), 512, 16, 1234, img=5)
     _show("fp32 512^2 x16", rep)
     kernels = {k for _, k, _, _ in rep}
-    assert {"conv3x3_first", "conv3x3_wino4", "conv3x3_wino4s", "convT2x2_taps"} <= kernels and any(k.endswith("+head") for k in kernels)
+    assert {"conv3x3_first", "conv3x3_wino4a", "conv3x3_wino4s", "convT2x2_taps"} <= kernels and any(k.endswith("+head") for k in kernels)
 
 
 def test_bf16_plan_every_layer_at_512_batch_16():

