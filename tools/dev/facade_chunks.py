@@ -1,0 +1,39 @@
+#!/usr/bin/env python3
+"""facade process_image_batch on 16 and 64 files for several pipeline piece sizes (MEDSEG_PIPELINE_CHUNK), and process_single_image"""
+import os, sys, tempfile, time
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.join(ROOT, "unet-medical-image-contour-segmentation-cpp_amd"))
+import numpy as np
+from miunet import hostlib, synth
+from miunet.spec import UNetSpec, pack_weights
+spec = UNetSpec()
+blob = pack_weights(spec, synth.make_threshold_weights(spec))
+raws = [synth.make_raw16(1536, 2048, seed=100 + i) for i in range(16)]
+with tempfile.TemporaryDirectory() as d:
+    os.makedirs(os.path.join(d, "engine")); wp = os.path.join(d, "engine", "unet.miw"); open(wp, "wb").write(blob)
+    paths = []
+    for i in range(64):
+        p = os.path.join(d, f"img{i:03d}.raw"); raws[i % 16].tofile(p); paths.append(p)
+    os.environ["MEDSEG_DEVICES"] = "1"
+    devnull = os.open(os.devnull, os.O_WRONLY); saved = os.dup(1)
+    res = []
+    for chunk in ("16", "8", "4", "0"):
+        os.environ["MEDSEG_PIPELINE_CHUNK"] = chunk
+        od = os.path.join(d, "out" + chunk); os.makedirs(od)
+        sys.stdout.flush(); os.dup2(devnull, 1)
+        assert hostlib.initialize_engine(wp, os.path.join(d, "log" + chunk))
+        for n in (16, 64):
+            hostlib.process_image_batch(paths[:n], [2048] * n, [1536] * n, od)
+            t0 = time.perf_counter(); ok = hostlib.process_image_batch(paths[:n], [2048] * n, [1536] * n, od); dt = time.perf_counter() - t0
+            res.append(f"MEDSEG_PIPELINE_CHUNK={chunk} (0 = default) {n} files: {n / dt:.1f} images/s ({dt / n * 1e3:.2f} ms/image), {ok} ok")
+        if chunk == "0":
+            for p in paths[:3]: hostlib.process_single_image(p, 2048, 1536, od)
+            t0 = time.perf_counter()
+            for p in paths[:16]: hostlib.process_single_image(p, 2048, 1536, od)
+            dt = time.perf_counter() - t0
+            res.append(f"process_single_image: {dt / 16 * 1e3:.2f} ms/image")
+            log = open(hostlib.get_log_path()).read().splitlines()
+            res += [l for l in log if "Stage times" in l][-2:]
+        hostlib.cleanup_resources()
+        os.dup2(saved, 1)
+    print("\n".join(res))

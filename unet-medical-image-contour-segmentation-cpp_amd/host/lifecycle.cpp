@@ -510,8 +510,14 @@ int process_batch_pipelined(const std::vector<std::string> &paths, const std::ve
             if (g_lane2) { lanes[1] = g_lane2; n_lanes = 2; }
         }
     }
-    // a chunk = one micro-batch on every device of the group
-    const size_t n = paths.size(), step = (size_t)std::max(1, g_cfg.max_batch) * (size_t)std::max(1, mi_unet_group_size(lanes[0]));
+    // a chunk = one micro-batch on every device of the group ... unless the whole call fits into one: then it is cut into two
+    // pieces (at least eight images each), so that reading piece k + 1, the device work of k and the artefacts of k - 1 overlap
+    // inside a 16-file call too (same card, 16 files: one piece 568, two 596, four 534 images/s -- smaller network batches cost
+    // more than the overlap returns, profiles/r04_facade_chunks.txt; MEDSEG_PIPELINE_CHUNK overrides the piece size)
+    const size_t n = paths.size(), full = (size_t)std::max(1, g_cfg.max_batch) * (size_t)std::max(1, mi_unet_group_size(lanes[0]));
+    size_t step = full;
+    if (n <= full) step = std::max<size_t>(8, (n + 1) / 2);
+    if (const int forced = env_int("MEDSEG_PIPELINE_CHUNK", 0); forced > 0) step = std::min<size_t>(full, (size_t)forced);
     int ok = 0;
     auto emit = [&](const ChunkIn &in, const ChunkOut &out, const ChunkText &tx) {
         for (size_t k = 0; k < tx.con.size(); ++k) {

@@ -215,7 +215,11 @@ void write_polygon_outputs(const std::vector<Contour> &contours, const Image8 &n
         }
         console << "Extracted " << contours.size() << " Contours" << std::endl;
         const std::string overlay_path = output_dir + "/" + base_name + "_contour_overlay.png";
-        if (!medseg::write_png(overlay_path, draw_overlay(normalized_tile, contours), /*level0=*/false))
+        // stored blocks, like the two PNGs the reference itself writes with IMWRITE_PNG_COMPRESSION 0 (src/preprocess.cpp:116,
+        // src/process.cpp:233): the pixels are the contract, and deflating the 786 KB overlay was the longest artefact of the
+        // device route (1.1 ms of the 3.9 ms per image); create_overlay_image above -- the reference's own
+        // stand-alone mask2polygon entry point -- keeps cv::imwrite's default level 1
+        if (!medseg::write_png(overlay_path, draw_overlay(normalized_tile, contours), /*level0=*/true))
             throw std::runtime_error("Fail to Save Overlay PNG: " + overlay_path);
         console << "Overlay Image Saved to: " << overlay_path << std::endl;
         const double scale_x = static_cast<double>(original_width) / normalized_tile.cols;

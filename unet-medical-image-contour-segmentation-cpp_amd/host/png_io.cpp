@@ -3,10 +3,13 @@
 #include <zlib.h>
 
 #include <algorithm>
+#include <condition_variable>
 #include <cstdio>
 #include <cstring>
+#include <deque>
 #include <fstream>
 #include <functional>
+#include <mutex>
 #include <thread>
 #include <vector>
 
@@ -75,6 +78,82 @@ void deflate_band(const Image8 &img, Band &bd, int level, int strategy, bool las
     bd.crc = crc32(crc32(0L, Z_NULL, 0), bd.out.data(), (uInt)bd.out.size());
 }
 
+// A few persistent helper threads for the bands of one image.  Round 3 started (and joined) up to fifteen std::threads per PNG:
+// for the 786 KB overlay of a 512 x 512 tile that start-up was most of the 1.1 ms the file took.  The pool
+// is created on first use and lives as long as the library; a caller that is itself one of several parallel writers (directory
+// mode: one image per OpenMP thread) still asks for one band and never touches it.
+class BandPool {
+public:
+    static BandPool &get()
+    {
+        static BandPool pool;
+        return pool;
+    }
+    // run fn(0) .. fn(n - 1): the caller takes job 0, the helpers the rest; returns when all are done
+    void run(int n, const std::function<void(int)> &fn)
+    {
+        if (n <= 1) { if (n == 1) fn(0); return; }
+        Batch b;
+        b.fn = &fn;
+        b.left = n - 1;
+        {
+            std::lock_guard<std::mutex> lk(m_);
+            for (int i = 1; i < n; ++i) q_.push_back({ &b, i });
+        }
+        cv_.notify_all();
+        fn(0);
+        std::unique_lock<std::mutex> lk(m_);
+        for (;;) {                                     // help with whatever is still queued (also other callers' bands), then wait
+            if (b.left == 0) break;
+            if (!q_.empty()) {
+                Job j = q_.front();
+                q_.pop_front();
+                lk.unlock();
+                (*j.b->fn)(j.i);
+                lk.lock();
+                if (--j.b->left == 0) done_.notify_all();
+                continue;
+            }
+            done_.wait(lk);
+        }
+    }
+
+private:
+    struct Batch { const std::function<void(int)> *fn = nullptr; int left = 0; };
+    struct Job { Batch *b; int i; };
+    BandPool()
+    {
+        unsigned hw = std::thread::hardware_concurrency();
+        const int n = (int)std::max(2u, std::min(12u, hw ? hw / 4 : 4u));
+        for (int i = 0; i < n; ++i) th_.emplace_back([this] { loop(); });
+    }
+    ~BandPool()
+    {
+        { std::lock_guard<std::mutex> lk(m_); stop_ = true; }
+        cv_.notify_all();
+        for (std::thread &t : th_) t.join();
+    }
+    void loop()
+    {
+        std::unique_lock<std::mutex> lk(m_);
+        for (;;) {
+            cv_.wait(lk, [this] { return stop_ || !q_.empty(); });
+            if (stop_) return;
+            Job j = q_.front();
+            q_.pop_front();
+            lk.unlock();
+            (*j.b->fn)(j.i);
+            lk.lock();
+            if (--j.b->left == 0) done_.notify_all();
+        }
+    }
+    std::mutex m_;
+    std::condition_variable cv_, done_;
+    std::deque<Job> q_;
+    std::vector<std::thread> th_;
+    bool stop_ = false;
+};
+
 }  // namespace
 
 static thread_local int t_png_threads = 16;
@@ -92,17 +171,15 @@ bool write_png(const std::string &path, const Image8 &img, bool level0)
     // level 1 with the run-length strategy -- fast, and the compressed bytes are not part of any contract (the pixels are)
     const int level = level0 ? 0 : 1, strategy = level0 ? Z_DEFAULT_STRATEGY : Z_RLE;
     const size_t total = ((size_t)img.cols * img.channels + 1) * img.rows;
-    int nb = level0 ? 1 : (int)std::min<size_t>((size_t)t_png_threads, std::max<size_t>(1, total / (48u << 10)));   // bands of >= 48 KB
+    // bands of >= 48 KB (level 1) / >= 96 KB (stored: only the copy and the two checksums are left to share)
+    int nb = (int)std::min<size_t>((size_t)t_png_threads, std::max<size_t>(1, total / ((level0 ? 96u : 48u) << 10)));
     nb = std::max(1, std::min(nb, img.rows));
     std::vector<Band> bands(nb);
     for (int b = 0; b < nb; ++b) {
         bands[b].r0 = (int)((long long)img.rows * b / nb);
         bands[b].r1 = (int)((long long)img.rows * (b + 1) / nb);
     }
-    std::vector<std::thread> workers;
-    for (int b = 1; b < nb; ++b) workers.emplace_back(deflate_band, std::cref(img), std::ref(bands[b]), level, strategy, b == nb - 1);
-    deflate_band(img, bands[0], level, strategy, nb == 1);
-    for (std::thread &w : workers) w.join();
+    BandPool::get().run(nb, [&](int b) { deflate_band(img, bands[b], level, strategy, b == nb - 1); });
     size_t zlen = 2 + 4;
     for (const Band &bd : bands) { if (!bd.ok) return false; zlen += bd.out.size(); }
     // the IDAT chunk, written in place: length, type, zlib header, bands, Adler-32, CRC-32 (combined from the pieces)
