@@ -206,7 +206,8 @@ typedef struct mi_unet_layer_info {
     int in_bits, out_bits; /* 8 = u8 image, 16 = bf16 / fp16 (per conv_algo), 32 = fp32: storage type in HBM (capture only) */
     int pooled;            /* the step also stored the 2x2 max-pooled tensor */
     int fused_head;        /* the step ran the 1x1 head + argmax in its epilogue; its own activations never reached HBM */
-    int skipped;           /* not launched at this batch size: fused into its producer */
+    int skipped;           /* not launched at this batch size: fused into its producer (pooling, head) or its consumer (first layer) */
+    int fused_first;       /* the step computed the network's first layer in its loader: `in` of the capture is the u8 image */
 } mi_unet_layer_info;
 int mi_unet_debug_layer_count(const mi_unet_t *h);
 int mi_unet_debug_layer_info(const mi_unet_t *h, int layer, mi_unet_layer_info *info);

@@ -64,6 +64,13 @@ def _check_layers(algo, spec, size, batch, seed, img):
                 assert np.array_equal(x[0], imgs[img].astype(np.float32))
                 wf, shift = _fold(tensors, name[:-3], 1, spec.bn_eps)
                 ref = np.maximum(orc.conv3x3(orc.normalize_u8(imgs[img][None]), wf) + shift, 0.0)[0]      # fp32 arithmetic in every plan
+            elif kind == "conv3x3" and d["fused_first"]:
+                # the first layer ran in this launch's loader: what it READ is the u8 image, what it stored is conv2(relu(conv1(image / 255)))
+                assert name == "inc.c2" and d["in_bits"] == 8 and np.array_equal(x[0], imgs[img].astype(np.float32)) and not lp
+                w1, s1 = _fold(tensors, "inc", 1, spec.bn_eps)
+                mid = np.maximum(orc.conv3x3(orc.normalize_u8(imgs[img][None]), w1) + s1, 0.0)
+                wf, shift = _fold(tensors, "inc", 2, spec.bn_eps)
+                ref = np.maximum(orc.conv3x3(mid, wf) + shift, 0.0)[0]
             elif kind == "conv3x3":
                 wf, shift = _fold(tensors, name[:-3], int(name[-1]), spec.bn_eps)
                 if lp:
@@ -121,7 +128,8 @@ def test_fp32_plan_every_layer_at_512_batch_16():
     rep = _check_layers("winograd", UNetSpec(), 512, 16, 1234, img=5)
     _show("fp32 512^2 x16", rep)
     kernels = {k for _, k, _, _ in rep}
-    assert {"conv3x3_first", "conv3x3_wino4a", "conv3x3_wino4s", "convT2x2_taps"} <= kernels and any(k.endswith("+head") for k in kernels)
+    assert {"conv3x3_wino4s+first", "conv3x3_wino4a", "conv3x3_wino4s", "convT2x2_taps"} <= kernels and any(k.endswith("+head") for k in kernels)
+    assert "conv3x3_first" not in kernels and len(rep) == 21          # inc.c1 runs inside inc.c2's loader: one launch and 1 GiB of traffic less
 
 
 def test_bf16_plan_every_layer_at_512_batch_16():

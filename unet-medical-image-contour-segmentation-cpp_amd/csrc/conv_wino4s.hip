@@ -33,6 +33,9 @@ struct W4S {
     static constexpr int HEAD_ROW = 64 + 4;                 // floats per pixel of the head's LDS tile (conflict-free b128 rows)
     static constexpr size_t LDS_BYTES = sizeof(float) * (W4::VBUF + W4::RAW_FLOATS);          // 60,416
     static constexpr size_t LDS_BYTES_HEAD = sizeof(float) * (256 * HEAD_ROW + 4 * 64);       // the head tile (larger than V + raw) + its weights
+    static constexpr int FIRST_WIN = 20;                    // fused first layer: the normalised (16 + 4)^2 window of the image behind V + raw
+    static constexpr int FIRST_WMAX = 64;                   // ... and the first layer's weights [9][Cin] + shift [Cin] (Cin <= 64: no long-lived registers)
+    static constexpr size_t LDS_BYTES_FIRST = LDS_BYTES + sizeof(float) * (FIRST_WIN * FIRST_WIN + 10 * FIRST_WMAX);
     static_assert(LDS_BYTES <= sizeof(float) * 256 * HEAD_ROW, "the head launch's allocation must cover the K loop's V + raw images");
 };
 
@@ -52,7 +55,11 @@ struct W4S {
 // the first on: a wave's vmcnt is in order, so every U fragment younger than a patch request waits for HBM with it; requested late,
 // the patch's latency falls into the wait in front of the next transform, which the co-resident workgroup's MFMAs cover
 // (inc.c2 -2 %, up4.c1 -2.8 %, the others unchanged: profiles/r03_ab_wino4s_k_loop.txt).
-template <bool HEAD, int UD, int EXP = 0, bool LATE = true>
+// FIRST: the layer's input is the network's FIRST layer, computed here (ConvArgs::first_img): instead of the LDS-DMA of a raw chunk,
+// every thread builds its 16-byte piece of the patch image -- the same (slot, channel quad) piece the DMA would have written --
+// from a 20x20 window of the u8 image that the workgroup normalises once: acc = sum over the nine taps (raster order, fma chain from
+// 0), + shift, ReLU: bit for bit what conv3x3_first_kernel stores, zero where the patch leaves the image (this layer's padding).
+template <bool HEAD, int UD, int EXP = 0, bool LATE = true, bool FIRST = false>
 __global__ __launch_bounds__(256, 2) void conv3x3_wino4s_f32(const ConvArgs a, const int tiles_x, const int tiles_y,
                                                              const int m_tiles, const int nwg)
 {
@@ -62,6 +69,8 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wino4s_f32(const ConvArgs a, c
     extern __shared__ __attribute__((aligned(16))) float lds[];
     float *const Vs = lds;                    // [36][16][VROW]
     float *const Raw = lds + W4::VBUF;        // [18 rows][20 slots][16]
+    float *const Win = Raw + W4::RAW_FLOATS;  // FIRST: [20][20] normalised image window, origin (by0 - 2, bx0 - 2)
+    float *const Wf = Win + W4S::FIRST_WIN * W4S::FIRST_WIN;      // FIRST: [9][Cin] weights, then [Cin] shifts
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -93,6 +102,29 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wino4s_f32(const ConvArgs a, c
         const bool inb = g < W4::RAW_SLOTS && px < 18 && gy >= 0 && gy < a.H && gx >= 0 && gx < a.W;
         raw_voff[s] = inb ? (unsigned)(((gy * a.W + gx) * a.ldc + 4 * (lane & 3)) * 4) : 0xFFFFFFFFu;
     }
+    auto first_patch = [&](int chunk) {                        // FIRST: this thread's pieces of a chunk's patch, computed
+        const int cq = chunk * WINO4_KC + 4 * (lane & 3);
+        const float *wq = Wf + cq;                             // tap t: wq[t * Cin .. + 3]; the shifts behind the ninth tap
+#pragma unroll 1                                               // a real loop: unrolled, hipcc hoists 6 x 18 LDS reads and spills accumulators
+        for (int s = 0; s < W4::RAW_ITERS; ++s) {
+            if (wave + 4 * s >= W4::RAW_LOADS) break;
+            const int g = (wave + 4 * s) * 16 + (lane >> 2);
+            const int py = g / W4::RAW_ROW, sl = g - py * W4::RAW_ROW;
+            const int px = 4 * (sl % 5) + sl / 5;
+            const int gy = by0 - 1 + py, gx = bx0 - 1 + px;
+            const bool inb = g < W4::RAW_SLOTS && px < 18 && gy >= 0 && gy < a.H && gx >= 0 && gx < a.W;
+            f32x4 r = f32x4{ 0.f, 0.f, 0.f, 0.f };
+            if (inb) {
+                f32x4 acc = f32x4{ 0.f, 0.f, 0.f, 0.f };
+                const float *wp = Win + py * W4S::FIRST_WIN + px;      // tap (dy, dx) of patch pixel (py, px): window (py + dy, px + dx)
+#pragma unroll
+                for (int t = 0; t < 9; ++t) acc += wp[(t / 3) * W4S::FIRST_WIN + t % 3] * *reinterpret_cast<const f32x4 *>(wq + t * a.Cin);
+                const f32x4 a4 = acc + *reinterpret_cast<const f32x4 *>(wq + 9 * a.Cin);
+                r.x = a4.x > 0.f ? a4.x : 0.f; r.y = a4.y > 0.f ? a4.y : 0.f; r.z = a4.z > 0.f ? a4.z : 0.f; r.w = a4.w > 0.f ? a4.w : 0.f;
+            }
+            *reinterpret_cast<f32x4 *>(Raw + (size_t)g * WINO4_KC + 4 * (lane & 3)) = r;
+        }
+    };
     typedef __attribute__((address_space(3))) void *lds_ptr;
     auto raw_dma_one = [&](int chunk, int s) {                 // the wave's s-th load of a chunk's patch
         const int c0 = chunk * WINO4_KC;
@@ -163,8 +195,17 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wino4s_f32(const ConvArgs a, c
     const float *const v_rd = Vs + j16 * VROW + 4 * (kq ^ v_swz(j16));                       // + pos*VPOS
 
     // the loads that open the tile: the raw patch of chunk 0 straight into LDS, then the U ring
+    if constexpr (FIRST) {
+        const uint8_t *imgb = a.first_img + (size_t)b * a.H * a.W;
+        for (int i = tid; i < W4S::FIRST_WIN * W4S::FIRST_WIN; i += 256) {
+            const int y = i / W4S::FIRST_WIN, x = i - y * W4S::FIRST_WIN, gy = by0 - 2 + y, gx = bx0 - 2 + x;
+            Win[i] = (gy >= 0 && gy < a.H && gx >= 0 && gx < a.W) ? a.first_lut[imgb[(size_t)gy * a.W + gx]] : 0.f;
+        }
+        for (int i = tid; i < 10 * a.Cin; i += 256) Wf[i] = i < 9 * a.Cin ? a.first_w[i] : a.first_shift[i - 9 * a.Cin];
+    } else {
 #pragma unroll
-    for (int s = 0; s < W4::RAW_ITERS; ++s) raw_dma_one(0, s);
+        for (int s = 0; s < W4::RAW_ITERS; ++s) raw_dma_one(0, s);
+    }
     f32x4 u[UD];
 #pragma unroll
     for (int p = 0; p < UD; ++p) u[p] = u_load(0, p);
@@ -182,7 +223,12 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wino4s_f32(const ConvArgs a, c
     do {
         // the patch DMA of this chunk is older than the UD youngest loads (the U ring): wait for everything but those
         constexpr int LEFT = LATE ? 0 : UD;           // (late patch requests interleave with the ring's refills: wait for everything)
-        __builtin_amdgcn_s_waitcnt(0x0F70 | (LEFT & 15) | ((LEFT >> 4) << 14));
+        if constexpr (FIRST) {
+            if (chunk == 0) __syncthreads();  // the image window is complete
+            first_patch(chunk);               // (the raw image is free: its last reader, the transform, is behind a barrier)
+        } else {
+            __builtin_amdgcn_s_waitcnt(0x0F70 | (LEFT & 15) | ((LEFT >> 4) << 14));
+        }
         __syncthreads();                      // every wave's part of the patch has landed; nobody reads V any more
         transform();
         __syncthreads();                      // V complete, the raw image is free again
@@ -194,7 +240,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wino4s_f32(const ConvArgs a, c
             f32x4 avn = av;
             if (p + 1 < 36) avn = *reinterpret_cast<const f32x4 *>(v_rd + (p + 1) * VPOS);   // V fragment one position ahead
             // one DMA load every fourth position, not a burst: 16 line misses at a time keep the VMEM queue moving
-            if (more && !(EXP & 2)) {             // one DMA load per position (16 line misses at a time keep the VMEM queue moving)
+            if (!FIRST && more && !(EXP & 2)) {   // one DMA load per position (16 line misses at a time keep the VMEM queue moving)
                 if (!LATE && p % 4 == 0 && p / 4 < W4::RAW_ITERS) raw_dma_one(chunk + 1, p / 4);
                 if (LATE && p >= 36 - W4::RAW_ITERS) raw_dma_one(chunk + 1, p - (36 - W4::RAW_ITERS));
             }
@@ -351,6 +397,11 @@ static hipError_t launch_wino4s_cfg(const ConvArgs &a, hipStream_t s)
     const int n_tiles = (a.Cout + 63) / 64;
     const int nwg = m_tiles * n_tiles;
     size_t lds_bytes = HEAD ? W4S::LDS_BYTES_HEAD : W4S::LDS_BYTES;
+    const bool first = a.first_img != nullptr;
+    if (first) {
+        if (HEAD || !conv3x3_wino4s_can_fuse_first(a, 1)) return hipErrorInvalidValue;
+        lds_bytes = W4S::LDS_BYTES_FIRST;
+    }
     // experiment switch: MIUNET_WINO4S_ONE_WG=1 asks for more than half a CU's LDS, so only ONE workgroup is
     // resident per CU -- the same kernel, same instructions, without its co-resident partner.  What that costs is what any
     // one-workgroup-per-CU re-tiling of these layers (a 32-tile block on v_mfma_f32_32x32x2_f32 needs 56 % of the register
@@ -373,13 +424,20 @@ static hipError_t launch_wino4s_cfg(const ConvArgs &a, hipStream_t s)
     if (ud == 3) return launch(conv3x3_wino4s_f32<HEAD, 3, 0, false>);
     if (ud == 60) return launch(conv3x3_wino4s_f32<HEAD, 6, 0, false>);
 #endif
+    if constexpr (!HEAD) { if (first) return launch(conv3x3_wino4s_f32<false, 6, 0, true, true>); }
     return launch(conv3x3_wino4s_f32<HEAD, 6>);
+}
+
+// the fused first layer: one input channel, whole 16-channel chunks of its output (= this layer's input), no fused head
+bool conv3x3_wino4s_can_fuse_first(const ConvArgs &a, int first_cin)
+{
+    return first_cin == 1 && a.Cin % WINO4_KC == 0 && a.Cin >= WINO4_KC && a.Cin <= W4S::FIRST_WMAX && a.head_w == nullptr && a.wpk4 != nullptr;
 }
 
 // Same contract as the one-block variant of launch_conv3x3_wino4 (a.wpk4 = U packed [Cin/16][36][CoutPad][16]); no split-K.
 hipError_t launch_conv3x3_wino4s(const ConvArgs &a, hipStream_t s)
 {
-    if (a.wpk4 == nullptr || a.Cin % 4 || a.ldc % 4 || a.CoutPad % NPAD) return hipErrorInvalidValue;
+    if (a.wpk4 == nullptr || a.Cin % 4 || (a.first_img == nullptr && a.ldc % 4) || a.CoutPad % NPAD) return hipErrorInvalidValue;
     if (a.head_w != nullptr) {
         if (a.Cout > 64 || a.head_classes < 1 || a.head_classes > 4 || a.pool_out != nullptr || a.head_labels == nullptr)
             return hipErrorInvalidValue;

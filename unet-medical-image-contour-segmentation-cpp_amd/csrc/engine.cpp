@@ -608,10 +608,21 @@ int launch_plan(mi_unet *h, const uint8_t *d_imgs, int B, uint8_t *d_labels, flo
     const int lp_kind = h->algo == MI_UNET_CONV_BF16 ? 1 : h->algo == MI_UNET_CONV_FP16 ? 2 : 0;
     bool head_done = false;
     int step_index = -1;
+    // The first layer can run inside its consumer (conv_wino4s.hip, FIRST): when the default fp32 plan sends inc.c2 to the staged
+    // F(4x4) kernel at this batch size, one input channel.  Decided per launch, like every routing choice that depends on the grid.
+    const Step *fused_first = nullptr;
+    if (h->plan.size() >= 2 && h->plan[0].kind == Step::FIRST && h->plan[1].kind == Step::CONV && lp_kind == 0 && h->routing.fuse_first &&
+        h->algo == MI_UNET_CONV_WINOGRAD && !h->wino4_guard_tripped && h->plan[1].a.wpk4 != nullptr && h->plan[1].head_step < 0) {
+        ConvArgs a = h->plan[1].a; a.B = B; a.rt = h->routing;
+        a.ksplit_ws = h->d_ksplit; a.ksplit_ws_bytes = h->ksplit_bytes;
+        const long long wg4 = (long long)((a.W + 15) / 16) * ((a.H + 15) / 16) * B * ((a.Cout + 127) / 128);
+        if ((wg4 >= h->wino4_min_wg || h->d_ksplit == nullptr) && conv3x3_wino4_runs_staged(a) && conv3x3_wino4s_can_fuse_first(a, h->plan[0].C))
+            fused_first = &h->plan[0];
+    }
     for (Step &st : h->plan) {
         ++step_index;
         const bool tapped = h->tap.layer == step_index;
-        if (st.fused_away || (st.kind == Step::HEAD && head_done)) {
+        if (st.fused_away || (st.kind == Step::HEAD && head_done) || (&st == fused_first)) {
             if (tapped) { h->tap.info->skipped = 1; h->tap.hit = true; return 0; }
             continue;
         }
@@ -624,6 +635,12 @@ int launch_plan(mi_unet *h, const uint8_t *d_imgs, int B, uint8_t *d_labels, flo
             if (st.kind == Step::FIRST) {
                 h->tap.info->in_bits = 8;
                 rc = download_tensor(s, d_imgs + im * st.H * st.W * st.C, 8, 0, (size_t)st.H * st.W, st.C, st.C, h->tap.in);
+            } else if (st.kind == Step::CONV && fused_first != nullptr && step_index == 1) {
+                // the step reads the u8 image: the first layer runs inside it (what the caller's `in` buffer receives is the image)
+                h->tap.info->in_bits = 8;
+                h->tap.info->fused_first = 1;
+                rc = download_tensor(s, d_imgs + im * fused_first->H * fused_first->W * fused_first->C, 8, 0, (size_t)fused_first->H * fused_first->W,
+                                     fused_first->C, fused_first->C, h->tap.in);
             } else if (st.kind == Step::CONV || st.kind == Step::CONVT) {
                 h->tap.info->in_bits = abits;
                 const size_t npix = (size_t)st.a.H * st.a.W;
@@ -697,7 +714,10 @@ int launch_plan(mi_unet *h, const uint8_t *d_imgs, int B, uint8_t *d_labels, flo
                         head_done = true;
                     }
                     const bool staged = conv3x3_wino4_runs_staged(a);      // conv_wino4s.hip: two workgroups per CU
-                    kname = staged ? (head_done ? "conv3x3_wino4s+head" : "conv3x3_wino4s")
+                    if (fused_first != nullptr && step_index == 1) {        // the first layer runs in this launch's loader
+                        a.first_img = d_imgs; a.first_lut = h->d_lut; a.first_w = fused_first->w; a.first_shift = fused_first->shift;
+                    }
+                    kname = staged ? (head_done ? "conv3x3_wino4s+head" : a.first_img ? "conv3x3_wino4s+first" : "conv3x3_wino4s")
                           : conv3x3_wino4_runs_asm(a) ? "conv3x3_wino4a" : (head_done ? "conv3x3_wino4+head" : "conv3x3_wino4");
                     e = launch_conv3x3_wino4(a, s);
                 }
@@ -780,6 +800,10 @@ int launch_plan(mi_unet *h, const uint8_t *d_imgs, int B, uint8_t *d_labels, flo
             ks.flops = st.flops_per_img * B;
             // algorithmic bytes: the 16-bit pipelines move half of them (activations and weights are 2 bytes)
             ks.bytes = (st.bytes_per_img * B + st.weight_bytes) * ((lp_kind && (st.kind == Step::CONV || st.kind == Step::CONVT)) ? 0.5 : 1.0);
+            if (fused_first != nullptr && step_index == 1) {           // + the first layer's arithmetic; the image in place of its output tensor
+                ks.flops += fused_first->flops_per_img * B;
+                ks.bytes += ((double)fused_first->H * fused_first->W * fused_first->C - 4.0 * st.a.H * st.a.W * st.a.Cin) * B;
+            }
             ks.ms = -1.f;                      // filled by mi_unet_get_kernel_stats
             h->stats.push_back(ks);
         }
@@ -840,6 +864,7 @@ Routing Routing::from_env()
     r.convt_lpr = num("MIUNET_CONVT_LPR", 1);
     r.wino4s = num("MIUNET_WINO4S", 1);
     r.wino4_asm = num("MIUNET_WINO4_ASM", 1);
+    r.fuse_first = num("MIUNET_FUSE_FIRST", 1);
     r.convt_small = num("MIUNET_CONVT_SMALL", 1) != 0;
     r.first_mfma = num("MIUNET_FIRST_MFMA", 1) != 0;
     int dev = 0;

@@ -23,6 +23,7 @@ struct Routing {
     int lprk = 1;             // MIUNET_LPRK: the 128 -> 64 K-split resident-weight kernel (conv_lprk.hip), as lpr
     int convt_lpr = 1;        // MIUNET_CONVT_LPR: as lpr
     int wino4s = 1;           // MIUNET_WINO4S: 0 never, 1 grids that fill the chip twice over, 2 every one-block case
+    int fuse_first = 1;       // MIUNET_FUSE_FIRST=0: the first layer stays a kernel of its own (A/B, parity checks)
     int wino4_asm = 1;        // MIUNET_WINO4_ASM: 0 never, 1 the hand-scheduled persistent two-block kernel for the shapes it takes
     bool convt_small = true;  // MIUNET_CONVT_SMALL=0: the per-tap transposed conv never shrinks its tile
     bool first_mfma = true;   // MIUNET_FIRST_MFMA=0: the 16-bit pipelines' first layer stays on the VALU kernel
@@ -67,6 +68,12 @@ struct ConvArgs {
     int head_classes;
     float *head_logits;
     uint8_t *head_labels;
+    // optional fused FIRST layer (conv_wino4s.hip, the fp32 plan's inc.c2): `in` is never read; the kernel builds each 16-channel
+    // chunk of its 18x18 input patch from the u8 image instead -- /255 table, conv3x3 (first_cin = 1 input channel, 64 output
+    // channels = this layer's Cin) + shift + ReLU, the arithmetic of conv3x3_first_kernel -- so the first layer's 1 GiB tensor is
+    // neither written nor read back.  first_w is [9][1][Cin] (BN scale folded), first_shift [Cin].
+    const uint8_t *first_img;
+    const float *first_lut, *first_w, *first_shift;
 };
 
 inline Routing routing_of(const ConvArgs &a) { return a.rt.resolved ? a.rt : Routing::from_env(); }
@@ -91,6 +98,7 @@ hipError_t launch_conv3x3_wino4(const ConvArgs &a, hipStream_t s);
 // routes its one-block cases here unless MIUNET_WINO4S=0.
 hipError_t launch_conv3x3_wino4s(const ConvArgs &a, hipStream_t s);
 bool conv3x3_wino4_runs_staged(const ConvArgs &a);   // the routing decision of launch_conv3x3_wino4 (for the launch log)
+bool conv3x3_wino4s_can_fuse_first(const ConvArgs &a, int first_cin);   // shape contract of the fused first layer (conv_wino4s.hip)
 // The two-block kernel hand-scheduled in gfx950 assembly and persistent (csrc/asm/gen_wino4_asm.py, csrc/wino4_asm.cpp): same
 // packing (a.wpk4), same tensors.  shape_ok = the contract of the assembly (whole 16x16 blocks, Cin % 32 == 0 and >= 64, Cout % 128
 // == 0, fp32, no fused head); runs_asm = what launch_conv3x3_wino4 decides (shape, MIUNET_WINO4_ASM, not a split-K grid).

@@ -40,7 +40,7 @@ class KernelStat(C.Structure):
 class LayerInfo(C.Structure):
     _fields_ = [("name", C.c_char * 48), ("kernel", C.c_char * 32), ("kind", C.c_int), ("in_h", C.c_int), ("in_w", C.c_int),
                 ("in_c", C.c_int), ("out_h", C.c_int), ("out_w", C.c_int), ("out_c", C.c_int), ("in_bits", C.c_int),
-                ("out_bits", C.c_int), ("pooled", C.c_int), ("fused_head", C.c_int), ("skipped", C.c_int)]
+                ("out_bits", C.c_int), ("pooled", C.c_int), ("fused_head", C.c_int), ("skipped", C.c_int), ("fused_first", C.c_int)]
 
     KINDS = ("first", "conv3x3", "convT2x2", "maxpool", "head")
 
@@ -367,6 +367,8 @@ class Engine:
         d = info.as_dict()
         if d["skipped"]:
             return d, None, None, None, None
+        if d["fused_first"]:             # the step read the u8 image (the first layer ran in its loader): `in` holds the image
+            x = x.reshape(-1)[: st.in_h * st.in_w * self.cfg.in_ch].reshape(st.in_h, st.in_w, self.cfg.in_ch).copy()
         if d["fused_head"] or d["kind"] == "head":
             y = y[: self.cfg.classes * st.out_h * st.out_w].reshape(self.cfg.classes, st.out_h, st.out_w)
         else:
