@@ -76,7 +76,7 @@ def family(kernel):
 def kernel_source_sha():
     """sha256 over the kernel and engine sources: a committed PMC summary is only quoted while it still describes them"""
     h = hashlib.sha256()
-    for p in sorted(glob.glob(os.path.join(PKG, "csrc", "*"))):
+    for p in sorted(glob.glob(os.path.join(PKG, "csrc", "*")) + glob.glob(os.path.join(PKG, "csrc", "asm", "*"))):
         if os.path.isfile(p):
             h.update(os.path.basename(p).encode())
             h.update(open(p, "rb").read())

@@ -36,7 +36,8 @@ SHADER_ENGINES = 32           # 8 XCDs x 4
 
 def kernel_source_sha():
     h = hashlib.sha256()
-    for p in sorted(glob.glob(os.path.join(ROOT, "unet-medical-image-contour-segmentation-cpp_amd", "csrc", "*"))):
+    pkg = os.path.join(ROOT, "unet-medical-image-contour-segmentation-cpp_amd", "csrc")
+    for p in sorted(glob.glob(os.path.join(pkg, "*")) + glob.glob(os.path.join(pkg, "asm", "*"))):      # the assembly generator is kernel source too
         if os.path.isfile(p):
             h.update(os.path.basename(p).encode())
             h.update(open(p, "rb").read())

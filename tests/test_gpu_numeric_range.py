@@ -142,7 +142,7 @@ def test_guard_probes_a_structured_tile_too(monkeypatch):
             err4 = float(np.max(np.abs(lg4 - ref)))
             print(f"\n[{family.__name__} act {act:g}] F(4x4) error on blobs {err4:.3e}; noise tile {noise:.3e}, structured tile {structured:.3e}; "
                   f"noise-only guard tripped {trip3}, two-tile guard tripped {trip1}")
-            assert abs(diff1 - max(noise, structured)) <= 1e-6 * max(1.0, diff1) and abs(diff3 - noise) <= 1e-6 * max(1.0, diff3)
+            assert abs(diff1 - max(noise, structured)) <= 6e-3 * diff1 and abs(diff3 - noise) <= 6e-3 * diff3      # (the text carries three digits)
             assert diff1 >= diff3 and (trip1 or not trip3)                      # never weaker than the round-3 guard
             assert trip1 == (diff1 > 5e-4)
             if err4 > 1e-3:
