@@ -51,13 +51,13 @@ LP_PEAK_TFLOPS = 2500.0       # dense bf16 / fp16 MFMA peak (the same per clock 
 HBM_PEAK_GBS = 8000.0
 
 # multiplies the MFMA pipe executes per algorithmic (direct-convolution) multiply, by kernel family
-WINOGRAD_REDUCTION = {"conv3x3_wino4": 4.0, "conv3x3_wino4a": 4.0, "conv3x3_wino4s": 4.0, "conv3x3_wino": 2.25, "conv3x3_wino16": 2.25}
-CONV_FAMILIES = ("conv3x3_mfma", "conv3x3_wino", "conv3x3_wino16", "conv3x3_wino4", "conv3x3_wino4a", "conv3x3_wino4s", "conv3x3_bf16", "conv3x3_fp16",
+WINOGRAD_REDUCTION = {"conv3x3_wino4": 4.0, "conv3x3_wino4a": 4.0, "conv3x3_wino4b": 4.0, "conv3x3_wino4s": 4.0, "conv3x3_wino": 2.25, "conv3x3_wino16": 2.25}
+CONV_FAMILIES = ("conv3x3_mfma", "conv3x3_wino", "conv3x3_wino16", "conv3x3_wino4", "conv3x3_wino4a", "conv3x3_wino4b", "conv3x3_wino4s", "conv3x3_bf16", "conv3x3_fp16",
                  "conv3x3_bf16w", "conv3x3_fp16w", "conv3x3_bf16r", "conv3x3_fp16r", "conv3x3_bf16k", "conv3x3_fp16k")
 LP_FAMILIES = ("conv3x3_bf16", "conv3x3_fp16", "conv3x3_bf16w", "conv3x3_fp16w", "conv3x3_bf16r", "conv3x3_fp16r", "conv3x3_bf16k", "conv3x3_fp16k", "convT2x2_bf16",
                "convT2x2_fp16", "convT2x2_bf16r", "convT2x2_fp16r")
 ROCPROF_NAME = {"conv3x3_wino": "miunet::conv3x3_wino_f32<*>", "conv3x3_wino16": "miunet::conv3x3_wino16_f32",
-                "conv3x3_wino4": "miunet::conv3x3_wino4_f32<*>", "conv3x3_wino4a": "conv3x3_wino4a_f32", "conv3x3_wino4s": "miunet::conv3x3_wino4s_f32<*>",
+                "conv3x3_wino4": "miunet::conv3x3_wino4_f32<*>", "conv3x3_wino4a": "conv3x3_wino4a_f32", "conv3x3_wino4b": "conv3x3_wino4b_f32", "conv3x3_wino4s": "miunet::conv3x3_wino4s_f32<*>",
                 "conv3x3_mfma": "miunet::conv_mfma_f32<*>", "convT2x2_taps": "miunet::convT2x2_taps_f32<*>",
                 "convT2x2_mfma": "miunet::conv_mfma_f32<*>", "conv3x3_first": "miunet::conv3x3_first_kernel<*>",
                 "conv3x3_bf16": "miunet::conv_mfma_bf16<*>", "conv3x3_fp16": "miunet::conv_mfma_bf16<*>",
@@ -183,7 +183,7 @@ def roofline_from_stats(stats, spec_macs, ips_per_gpu, tag):
     algorithmic = dom_flops / (dom_ms * 1e-3) / 1e12 if dom_ms else 0.0
     executed = algorithmic / red
     insn = ("v_mfma_f32_16x16x32_f16" if "fp16" in dom_kernel else "v_mfma_f32_16x16x32_bf16" if lp
-            else "v_mfma_f32_16x16x4_f32" if dom_kernel in ("conv3x3_wino4", "conv3x3_wino4a") else "v_mfma_f32_32x32x2_f32")
+            else "v_mfma_f32_16x16x4_f32" if dom_kernel in ("conv3x3_wino4", "conv3x3_wino4a", "conv3x3_wino4b") else "v_mfma_f32_32x32x2_f32")
     pmc, pmc_src = pmc_summary(tag)
     rk = (pmc or {}).get("kernels", {}).get(ROCPROF_NAME.get(dom_kernel, ""), {})
     # every kernel family of the step, same arithmetic: executed = algorithmic / winograd_reduction (1 for the direct forms)

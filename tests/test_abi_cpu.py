@@ -85,5 +85,5 @@ def test_product_library_has_no_experiment_kernels():
     assert "conv3x3_wino4_f32<2, false, false, 0>" in syms          # the check above looked at real names
     blob = open(so, "rb").read()
     for name in (b"MIUNET_W4_EXP", b"MIUNET_W4S_EXP", b"MIUNET_LP2_EXP", b"MIUNET_LPR_EXP", b"MIUNET_WINO4S_ONE_WG", b"MIUNET_W4S_UD",
-                 b"MIUNET_LP2_WD", b"MIUNET_LP2_NSPLIT", b"MIUNET_LP2_MINCIN", b"MIUNET_CONVT_CFG", b"MIUNET_CONVT_WPS", b"MIUNET_FIRST_RBW", b"MIUNET_WINO4A_HSACO"):
+                 b"MIUNET_LP2_WD", b"MIUNET_LP2_NSPLIT", b"MIUNET_LP2_MINCIN", b"MIUNET_CONVT_CFG", b"MIUNET_CONVT_WPS", b"MIUNET_FIRST_RBW", b"MIUNET_WINO4A_HSACO", b"MIUNET_WINO4B_HSACO"):
         assert name not in blob, name.decode()

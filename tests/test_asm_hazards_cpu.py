@@ -143,6 +143,15 @@ def test_generated_assembly_kernel_assembles_and_has_its_wait_states(tmp_path):
     subprocess.run([os.path.join(LLVM_BIN, "clang"), "-x", "assembler", "-target", "amdgcn-amd-amdhsa", "-mcpu=gfx950", "-c", str(asm), "-o", str(obj)],
                    check=True, capture_output=True, timeout=300)
     assert obj.stat().st_size > 40000
+    # the sibling kernel for the 64-channel layers (gen_wino4b_asm.py): the whole 160 KB of LDS, same checks
+    asm_b = tmp_path / "wino4b.s"
+    subprocess.run([sys.executable, os.path.join(CSRC, "asm", "gen_wino4b_asm.py"), str(asm_b)], check=True, capture_output=True, timeout=300)
+    tb = asm_b.read_text()
+    assert tb.count("v_mfma_f32_16x16x4_f32") == 2 * 4 * 288 and ".amdhsa_group_segment_fixed_size 163840" in tb
+    assert ".fill 256, 4, 3212836864" in tb[tb.rindex("s_endpgm"):]
+    assert scan_asm_kernel.scan(str(asm_b)) == []
+    subprocess.run([os.path.join(LLVM_BIN, "clang"), "-x", "assembler", "-target", "amdgcn-amd-amdhsa", "-mcpu=gfx950", "-c", str(asm_b), "-o", str(obj)],
+                   check=True, capture_output=True, timeout=300)
     # every timing-only / dump / stamp variant of the generator still assembles (they are bring-up tools, never shipped)
     for flags in (["--stamps"], ["--stop", "5", "--dump", "lds"], ["--timing-only", "nouload,novread,notransform,nodma"], ["--dma-pos", "0,4,8,12,16,20"]):
         v = tmp_path / "variant.s"

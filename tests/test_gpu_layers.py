@@ -304,3 +304,46 @@ def test_conv3x3_wino4a_contract_and_fallback(monkeypatch):
     c = binding.layer_debug("conv3x3_wino4", x, w)          # the hipcc two-block kernel
     assert not np.array_equal(a, c) or True
     assert np.max(np.abs(a - c)) < 2e-5 * max(1.0, float(np.abs(a).max()))
+
+
+# ---------------------------------------------------------------------------------------------------- conv3x3_wino4b (assembly)
+@pytest.mark.parametrize("B,H,W,Cin,Cout,pool", [
+    (1, 16, 32, 64, 64, False),      # one block of 16 x 32 pixels, four chunks
+    (1, 32, 64, 64, 64, True),       # four blocks: every image border in the zero padding, fused 2x2 pooling
+    (2, 32, 64, 128, 64, False),     # up4.c1's channels (128 -> 64), two images
+    (3, 16, 32, 96, 64, False),      # six chunks
+    (16, 128, 128, 64, 64, False),   # 512 blocks over 256 persistent workgroups: the block-to-block hand-over
+    (4, 64, 64, 128, 128, True),     # two channel groups of 64, pooling
+])
+def test_conv3x3_wino4b_assembly_kernel(B, H, W, Cin, Cout, pool):
+    """conv3x3_wino4b_f32 (csrc/asm/gen_wino4b_asm.py): 32 tiles x 64 channels per workgroup, a wave = 32 tiles x 16 channels, V
+    single-buffered with a transform phase and an MFMA phase per chunk -- against the oracle, full-size and pooled outputs."""
+    r = _rng(B * 1000 + H * 100 + W + Cin + Cout + 3)
+    x = r.standard_normal((B, H, W, Cin), dtype=np.float32)
+    w = (r.standard_normal((Cout, Cin, 3, 3), dtype=np.float32) * np.sqrt(2.0 / (9 * Cin))).astype(np.float32)
+    scale = (1.0 + 0.1 * r.standard_normal(Cout)).astype(np.float32)
+    shift = (0.1 * r.standard_normal(Cout)).astype(np.float32)
+    ref = np.maximum(orc.conv3x3(x, w) * scale + shift, 0.0)
+    got = binding.layer_debug("conv3x3_wino4b", x, w, scale, shift, relu=True)
+    assert not np.isnan(got).any(), "unwritten (NaN-poisoned) outputs"
+    assert np.max(np.abs(got - ref)) < _tol(ref)
+    if pool:
+        gotp = binding.layer_debug("conv3x3_wino4b_pool", x, w, scale, shift, relu=True)
+        assert np.array_equal(gotp, got.reshape(B, H // 2, 2, W // 2, 2, Cout).max(axis=(2, 4)))
+
+
+def test_conv3x3_wino4b_exact_and_contract():
+    r = _rng(29)
+    B, H, W, Cin, Cout = 2, 16, 64, 64, 64
+    x = r.integers(-2, 3, (B, H, W, Cin)).astype(np.float32)
+    for (ky, kx, ci, co) in [(0, 2, 5, 7), (2, 0, 63, 63), (1, 1, 0, 0), (0, 0, 17, 33), (2, 2, 9, 40), (1, 0, 3, 3), (0, 1, 16, 48)]:
+        w = np.zeros((Cout, Cin, 3, 3), np.float32)
+        w[co, ci, ky, kx] = 576.0
+        got = binding.layer_debug("conv3x3_wino4b", x, w)
+        ref = orc.conv3x3(x, w)
+        assert (ref < 0).any() and np.array_equal(got, ref), (ky, kx, ci, co)
+    for shape in [(1, 16, 16, 64, 64), (1, 20, 32, 64, 64), (1, 16, 32, 48, 64), (1, 16, 32, 64, 32)]:      # W % 32, H % 16, Cin % 32, Cout % 64
+        xs = r.standard_normal(shape[:4], dtype=np.float32)
+        ws = (r.standard_normal((shape[4], shape[3], 3, 3), dtype=np.float32) * 0.05).astype(np.float32)
+        with pytest.raises(binding.MiUnetError):
+            binding.layer_debug("conv3x3_wino4b", xs, ws)

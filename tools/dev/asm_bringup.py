@@ -28,7 +28,7 @@ else:
     scale = (1.0 + 0.1 * r.standard_normal(Cout)).astype(np.float32)
     shift = (0.1 * r.standard_normal(Cout)).astype(np.float32)
     relu = True
-op = "conv3x3_wino4a" + ("_pool" if pool else "")
+op = %(op)r + ("_pool" if pool else "")
 got = binding.layer_debug(op, x, w, scale, shift, relu=relu)
 ref = orc.conv3x3(x, w)
 if scale is not None:
@@ -62,7 +62,7 @@ def main():
         parts = c.split(",")
         shape = tuple(int(p) for p in parts[:5])
         src = CHILD % {"pkg": os.path.join(ROOT, "unet-medical-image-contour-segmentation-cpp_amd"), "tests": os.path.join(ROOT, "tests"),
-                       "shape": repr(shape), "pool": "pool" in parts, "exact": "exact" in parts}
+                       "shape": repr(shape), "pool": "pool" in parts, "exact": "exact" in parts, "op": os.environ.get("ASM_OP", "conv3x3_wino4a")}
         print(f"case {c}:", flush=True)
         try:
             r = subprocess.run([sys.executable, "-c", src], env=env, timeout=120)

@@ -36,7 +36,8 @@ int main(int argc, char **argv)
     else { std::printf("cannot read %s\n", argv[1]); return 2; }
     hipModule_t mod; hipFunction_t fn;
     CK(hipModuleLoadData(&mod, blob.data()));
-    CK(hipModuleGetFunction(&fn, mod, "conv3x3_wino4a_f32"));
+    const bool mode_b = getenv("ASM_MODE") && getenv("ASM_MODE")[0] == 'b';       // conv3x3_wino4b_f32: blocks of 16 x 32 pixels x 64 channels
+    CK(hipModuleGetFunction(&fn, mod, mode_b ? "conv3x3_wino4b_f32" : "conv3x3_wino4a_f32"));
     const size_t in_n = (size_t)B * H * W * Cin, out_n = (size_t)B * H * W * Cout, u_n = (size_t)(Cin / 16) * 36 * Cout * 16;
     std::vector<float> h_in(in_n), h_u(u_n), h_b(Cout);
     uint32_t x = 12345;
@@ -56,7 +57,7 @@ int main(int argc, char **argv)
     memset(&k, 0, sizeof k);
     k.in = d_in; k.u = d_u; k.bias = d_b; k.out = d_out; k.pool = d_pool;
     k.H = H; k.W = W; k.pix_in_bytes = Cin * 4; k.nchunks = Cin / 16;
-    k.tiles_x = W / 16; k.tiles_y = H / 16; k.m_tiles = k.tiles_x * k.tiles_y * B; k.nwg = k.m_tiles * (Cout / 128);
+    k.tiles_x = W / (mode_b ? 32 : 16); k.tiles_y = H / 16; k.m_tiles = k.tiles_x * k.tiles_y * B; k.nwg = k.m_tiles * (Cout / (mode_b ? 64 : 128));
     k.magic_m = magic_of(k.m_tiles); k.magic_x = magic_of(k.tiles_x); k.magic_y = magic_of(k.tiles_y);
     k.u_pos_bytes = Cout * 64u; k.u_bytes = k.nchunks * 36u * k.u_pos_bytes;
     k.img_in_bytes = (uint32_t)H * W * Cin * 4u; k.pix_out_bytes = Cout * 4u; k.co_off_bytes = 0; k.img_out_bytes = (uint32_t)H * W * Cout * 4u;

@@ -572,11 +572,18 @@ bool conv3x3_wino4_runs_asm(const ConvArgs &a)
     return !split_k;
 }
 
+// ... and conv3x3_wino4b for the layers conv3x3_wino4s would take (64 output channels per workgroup, big grids) when the shape fits
+bool conv3x3_wino4_runs_asm_b(const ConvArgs &a)
+{
+    return routing_of(a).wino4_asm_b != 0 && conv3x3_wino4b_shape_ok(a) && conv3x3_wino4_runs_staged(a) && a.Cout % 128 != 0;
+}
+
 hipError_t launch_conv3x3_wino4(const ConvArgs &a, hipStream_t s)
 {
     if (a.wpk4 == nullptr || a.Cin % 4 || a.ldc % 4 || a.CoutPad % NPAD) return hipErrorInvalidValue;
     // 128 output channels per workgroup when Cout fills them; 64 for the Cout = 64 layers (and any Cout % 128 in (0, 64])
     const int rem = a.Cout % 128;
+    if (conv3x3_wino4_runs_asm_b(a)) return launch_conv3x3_wino4b(a, s);
     if (conv3x3_wino4_runs_staged(a)) return launch_conv3x3_wino4s(a, s);
     if (a.head_w != nullptr) {
         if (a.Cout > 64 || a.head_classes < 1 || a.head_classes > 4 || a.pool_out != nullptr || a.head_labels == nullptr)

@@ -717,7 +717,8 @@ int launch_plan(mi_unet *h, const uint8_t *d_imgs, int B, uint8_t *d_labels, flo
                     if (fused_first != nullptr && step_index == 1) {        // the first layer runs in this launch's loader
                         a.first_img = d_imgs; a.first_lut = h->d_lut; a.first_w = fused_first->w; a.first_shift = fused_first->shift;
                     }
-                    kname = staged ? (head_done ? "conv3x3_wino4s+head" : a.first_img ? "conv3x3_wino4s+first" : "conv3x3_wino4s")
+                    kname = (staged && conv3x3_wino4_runs_asm_b(a)) ? "conv3x3_wino4b"
+                          : staged ? (head_done ? "conv3x3_wino4s+head" : a.first_img ? "conv3x3_wino4s+first" : "conv3x3_wino4s")
                           : conv3x3_wino4_runs_asm(a) ? "conv3x3_wino4a" : (head_done ? "conv3x3_wino4+head" : "conv3x3_wino4");
                     e = launch_conv3x3_wino4(a, s);
                 }
@@ -865,6 +866,7 @@ Routing Routing::from_env()
     r.wino4s = num("MIUNET_WINO4S", 1);
     r.wino4_asm = num("MIUNET_WINO4_ASM", 1);
     r.fuse_first = num("MIUNET_FUSE_FIRST", 1);
+    r.wino4_asm_b = num("MIUNET_WINO4_ASM_B", 1);
     r.convt_small = num("MIUNET_CONVT_SMALL", 1) != 0;
     r.first_mfma = num("MIUNET_FIRST_MFMA", 1) != 0;
     int dev = 0;
@@ -1761,7 +1763,7 @@ int mi_unet_layer_debug(int device, const char *op, const float *in, int B, int 
         out_n = (size_t)B * 4 * H * W * Cout;
         a.B = B; a.H = H; a.W = W; a.Cin = Cin; a.ldc = Cin; a.Cout = Cout; a.CoutPad = convT_taps_cpad(Cout); a.ldo = Cout; a.co_off = 0;
         a.relu = relu;
-    } else if (o == "conv3x3_wino4" || o == "conv3x3_wino4s" || o == "conv3x3_wino4a") {
+    } else if (o == "conv3x3_wino4" || o == "conv3x3_wino4s" || o == "conv3x3_wino4a" || o == "conv3x3_wino4b") {
         if (!w || Cout <= 0 || Cin % 4) return fail(MI_UNET_EARG, "layer_debug: conv needs weights and Cin % 4 == 0");
         const int nch = (Cin + WINO4_KC - 1) / WINO4_KC;
         const size_t npad = round_up((size_t)Cout, NPAD);
@@ -1861,11 +1863,12 @@ int mi_unet_layer_debug(int device, const char *op, const float *in, int B, int 
         DBG_TRY(hipMemcpy(d_w, wpk.data(), sizeof(float) * wpk.size(), hipMemcpyHostToDevice));
         DBG_TRY(hipMemcpy(d_b, bias.data(), sizeof(float) * bias.size(), hipMemcpyHostToDevice));
         a.in = d_in; a.wpk = d_w; a.bias = d_b; a.out = d_out;
-        if (o == "conv3x3_wino4" || o == "conv3x3_wino4s" || o == "conv3x3_wino4a" || o == "convT2x2_taps") a.wpk4 = d_w;
+        if (o == "conv3x3_wino4" || o == "conv3x3_wino4s" || o == "conv3x3_wino4a" || o == "conv3x3_wino4b" || o == "convT2x2_taps") a.wpk4 = d_w;
         DBG_TRY(o == "conv3x3" ? launch_conv3x3_mfma(a, nullptr)
                 : o == "conv3x3_wino4" ? launch_conv3x3_wino4(a, nullptr)
                 : o == "conv3x3_wino4s" ? launch_conv3x3_wino4s(a, nullptr)
                 : o == "conv3x3_wino4a" ? launch_conv3x3_wino4a(a, nullptr)
+                : o == "conv3x3_wino4b" ? launch_conv3x3_wino4b(a, nullptr)
                 : o == "convT2x2_taps" ? launch_convT2x2_taps(a, nullptr)
                 : o == "conv3x3_wino" ? launch_conv3x3_wino(a, nullptr)
                 : o == "conv3x3_wino16" ? launch_conv3x3_wino16(a, nullptr)

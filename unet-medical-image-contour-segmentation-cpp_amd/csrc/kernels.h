@@ -24,6 +24,7 @@ struct Routing {
     int convt_lpr = 1;        // MIUNET_CONVT_LPR: as lpr
     int wino4s = 1;           // MIUNET_WINO4S: 0 never, 1 grids that fill the chip twice over, 2 every one-block case
     int fuse_first = 1;       // MIUNET_FUSE_FIRST=0: the first layer stays a kernel of its own (A/B, parity checks)
+    int wino4_asm_b = 1;      // MIUNET_WINO4_ASM_B=0: the 64-channel layers stay on conv3x3_wino4s
     int wino4_asm = 1;        // MIUNET_WINO4_ASM: 0 never, 1 the hand-scheduled persistent two-block kernel for the shapes it takes
     bool convt_small = true;  // MIUNET_CONVT_SMALL=0: the per-tap transposed conv never shrinks its tile
     bool first_mfma = true;   // MIUNET_FIRST_MFMA=0: the 16-bit pipelines' first layer stays on the VALU kernel
@@ -105,6 +106,11 @@ bool conv3x3_wino4s_can_fuse_first(const ConvArgs &a, int first_cin);   // shape
 bool conv3x3_wino4a_shape_ok(const ConvArgs &a);
 bool conv3x3_wino4_runs_asm(const ConvArgs &a);
 hipError_t launch_conv3x3_wino4a(const ConvArgs &a, hipStream_t s);
+// ... and its sibling for the layers with 64 output channels per workgroup: blocks of 16 x 32 pixels (32 tiles) x 64 channels, a wave
+// = 32 tiles x 16 channels, V single-buffered with a transform phase and an MFMA phase per chunk (csrc/asm/gen_wino4b_asm.py)
+bool conv3x3_wino4b_shape_ok(const ConvArgs &a);
+bool conv3x3_wino4_runs_asm_b(const ConvArgs &a);
+hipError_t launch_conv3x3_wino4b(const ConvArgs &a, hipStream_t s);
 hipError_t launch_wino_splitk_reduce(const ConvArgs &a, hipStream_t s);   // sums a.ksplit slabs of a.ksplit_ws into a.out
 hipError_t launch_convT2x2_mfma(const ConvArgs &a, hipStream_t s);
 // The transposed conv as four per-tap GEMMs sharing one A operand (convt_taps.hip): a.wpk4 holds the weights packed

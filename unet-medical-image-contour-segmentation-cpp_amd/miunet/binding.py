@@ -488,7 +488,7 @@ def layer_debug(op, x, w=None, scale=None, shift=None, relu=False, device=0):
     pooled = op.endswith("_pool")     # conv3x3 ops: return the fused 2x2 max-pooled tensor instead of the full-size one
     if pooled:
         op = op[:-5]
-    if op in ("conv3x3", "conv3x3_wino", "conv3x3_wino16", "conv3x3_wino4", "conv3x3_wino4s", "conv3x3_wino4a", "conv3x3_bf16", "conv3x3_fp16", "conv3x3_bf16w", "conv3x3_fp16w", "conv3x3_bf16r", "conv3x3_fp16r", "conv3x3_bf16k", "conv3x3_fp16k", "conv3x3_first", "conv3x3_first_bf16", "conv3x3_first_fp16"):
+    if op in ("conv3x3", "conv3x3_wino", "conv3x3_wino16", "conv3x3_wino4", "conv3x3_wino4s", "conv3x3_wino4a", "conv3x3_wino4b", "conv3x3_bf16", "conv3x3_fp16", "conv3x3_bf16w", "conv3x3_fp16w", "conv3x3_bf16r", "conv3x3_fp16r", "conv3x3_bf16k", "conv3x3_fp16k", "conv3x3_first", "conv3x3_first_bf16", "conv3x3_first_fp16"):
         w = np.ascontiguousarray(w, np.float32)
         cout = w.shape[0]
         out = np.empty((b, h // 2, ww // 2, cout) if pooled else (b, h, ww, cout), np.float32)
