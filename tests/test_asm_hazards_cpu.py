@@ -147,7 +147,7 @@ def test_generated_assembly_kernel_assembles_and_has_its_wait_states(tmp_path):
     asm_b = tmp_path / "wino4b.s"
     subprocess.run([sys.executable, os.path.join(CSRC, "asm", "gen_wino4b_asm.py"), str(asm_b)], check=True, capture_output=True, timeout=300)
     tb = asm_b.read_text()
-    assert tb.count("v_mfma_f32_16x16x4_f32") == 2 * 4 * 288 and ".amdhsa_group_segment_fixed_size 163840" in tb
+    assert tb.count("v_mfma_f32_16x16x4_f32") == 4 * 288 and ".amdhsa_group_segment_fixed_size 163840" in tb          # one stream for the four waves
     assert ".fill 256, 4, 3212836864" in tb[tb.rindex("s_endpgm"):]
     assert scan_asm_kernel.scan(str(asm_b)) == []
     subprocess.run([os.path.join(LLVM_BIN, "clang"), "-x", "assembler", "-target", "amdgcn-amd-amdhsa", "-mcpu=gfx950", "-c", str(asm_b), "-o", str(obj)],

@@ -63,14 +63,15 @@ PX0 = AV0 + 16               # 52
 CR0 = PX0 + 32               # 84
 E0 = CR0 + 48                # 132
 TV0 = E0 + 16                # 148
-V_VRD0, V_VRD1, V_UVOFF, V_PRD, V_VWR = 160, 161, 162, 163, 164
+V_VRD0, V_VRD1, V_UVOFF, V_PRD, V_VWR = 160, 161, 162, 163, 164      # V_PRD / V_VWR: the two-row pass of the transform
+V_PRD2, V_VWR2 = 210, 211    # ... and its one-row pass (the other tile group)
 V_REL0 = 165                 # 11
 V_VOFF0 = 176                # 11
 V_PYPX0 = 187                # 11
 V_OUTOFF, V_POOLOFF, V_BIAS0, V_CHAN4 = 198, 199, 200, 201
-V_T0 = 202                   # eight temporaries
+V_T0 = 202                   # eight temporaries (set-up code only)
 ACCV = 224
-assert TV0 + 12 <= V_VRD0 and V_T0 + 8 <= ACCV
+assert TV0 + 12 <= V_VRD0 and V_T0 + 8 <= V_PRD2 and V_VWR2 < ACCV
 
 EP_M, EP_S, EP_Y, EP_C = PX0, PX0 + 12, PX0 + 20, PX0 + 28
 EP_T = CR0
@@ -170,13 +171,15 @@ def lq_reserve(E, lq, n):
 
 
 def tr_load(E, role, g, k, rbuf, lq):
+    """patch column k of this lane's rows (g only tags the pass: the tile group's columns are part of the base register)"""
     rows = 4 if role == "A" else 3
     rstep = 1 if role == "A" else 2
+    prd = V_PRD if role == "A" else V_PRD2
     lq_reserve(E, lq, rows)
     for i in range(rows):
-        off = (9 * (k & 3) + 4 * g + (k >> 2)) * 64 + i * rstep * ROWP * 64 + rbuf * RAWBUF_B
+        off = (9 * (k & 3) + (k >> 2)) * 64 + i * rstep * ROWP * 64 + rbuf * RAWBUF_B
         assert off < 65536
-        E.i(f"ds_read_b128 {v(px_bank(k) + 4 * i, 4)}, {v(V_PRD)} offset:{off}")
+        E.i(f"ds_read_b128 {v(px_bank(k) + 4 * i, 4)}, {v(prd)} offset:{off}")
         lq.issue(("L", g, k))
 
 
@@ -220,37 +223,38 @@ def tr_store_calc(E, row, nu, dst):
         pk_fma(E, dst, K_M5, c[3], dst)
 
 
-def tr_write(E, g, row, nu, src, lq):
-    off = nu * VPOS_B + row * 6 * VPOS_B + g * 1024
+def tr_write(E, role, g, row, nu, src, lq):
+    off = nu * VPOS_B + row * 6 * VPOS_B
     assert off < 65536
     lq_reserve(E, lq, 1)
-    E.i(f"ds_write_b128 {v(V_VWR)}, {v(src, 4)} offset:{off}")
+    E.i(f"ds_write_b128 {v(V_VWR if role == 'A' else V_VWR2)}, {v(src, 4)} offset:{off}")
     lq.issue(("W", g, row, nu))
 
 
-def emit_transform(E, role, rbuf):
-    """V = B^T d B of one chunk for both tile groups, Raw[rbuf] -> V"""
+def emit_transform(E, rbuf):
+    """V = B^T d B of one chunk, Raw[rbuf] -> V, for both tile groups.  The work is cut into eight (tile group, rows of B^T) pieces --
+    two rows (1,2) or (3,4): 96 packed operations, one row 0 or 5: 48 -- and every wave takes a two-row piece of one group and a
+    one-row piece of the OTHER group: 144 packed operations each, no wave waits for a heavier one at the barrier.  Which pieces is
+    in the wave's lane constants (V_PRD / V_VWR, V_PRD2 / V_VWR2, alpha / beta): one instruction stream for all four waves."""
     lq = LdsQueue()
-    E.c(f"transform, role {role}: Raw{rbuf} -> V")
-    seq = [(g, k) for g in range(2) for k in range(6)]
-    tr_load(E, role, *seq[0], rbuf, lq)
-    tr_load(E, role, *seq[1], rbuf, lq)
-    for n, (g, k) in enumerate(seq):
+    E.c(f"transform: Raw{rbuf} -> V")
+    seq = [("A", 0, k) for k in range(6)] + [("B", 1, k) for k in range(6)]
+    tr_load(E, seq[0][0], seq[0][1], seq[0][2], rbuf, lq)
+    tr_load(E, seq[1][0], seq[1][1], seq[1][2], rbuf, lq)
+    for n, (role, g, k) in enumerate(seq):
         waitcnt(E, lgkm=lq.wait_count(("L", g, k)))
         tr_col(E, role, k)
         if n + 2 < len(seq):
-            tr_load(E, role, *seq[n + 2], rbuf, lq)       # into the bank column k just left (the VALU above has read it)
-        if k == 5:                                         # the group's six columns are combined: its row pass
+            tr_load(E, seq[n + 2][0], seq[n + 2][1], seq[n + 2][2], rbuf, lq)      # into the bank column k just left
+        if k == 5:                                         # the pass's six columns are combined: its row pass
             for row in range(2 if role == "A" else 1):
                 tr_prep(E, row)
                 for grp in ((0, 1, 2), (3, 4, 5)):
                     for m, nu in enumerate(grp):
                         tr_store_calc(E, row, nu, TV0 + 4 * m)
                     for m, nu in enumerate(grp):
-                        tr_write(E, g, row, nu, TV0 + 4 * m, lq)
+                        tr_write(E, role, g, row, nu, TV0 + 4 * m, lq)
                     E.i("s_nop 1")
-    # (lgkmcnt of the 12 + 12 writes: the caller waits for 0 before its barrier; at most 15 LDS operations are ever outstanding
-    # between two waits above -- 8 reads + 6 writes)
 
 
 # ------------------------------------------------------------------------------------------------------------- chunk body
@@ -264,13 +268,13 @@ def vm_wait_for_position(p):
     return (UD - 1) + dmas
 
 
-def emit_body(E, role, par, kind):
+def emit_body(E, par, kind):
     assert kind in ("first", "mid", "last")
-    E.c(f"---- chunk body: role {role}, Raw{par}, {kind}")
+    E.c(f"---- chunk body: Raw{par}, {kind}")
     # raw(c) is in LDS (requested two bodies ago: every U wait of the previous body implies it; the first tile waited for everything),
     # and every wave has finished the MFMA phase that read V: then the transform may overwrite V
     E.i("s_barrier")
-    emit_transform(E, role, par)
+    emit_transform(E, par)
     waitcnt(E, lgkm=0)
     E.i("s_barrier")
     lq = LdsQueue()
@@ -511,37 +515,48 @@ def emit_kernel(E, name):
     E.i(f"s_lshl_b32 {s(S_T0)}, {s(L_WAVE)}, 6")                             # wave * 16 channels * 4 bytes
     E.i(f"v_lshlrev_b32 {v(TMPA)}, 2, {v(J16)}")
     E.i(f"v_add_u32 {v(V_CHAN4)}, {s(S_T0)}, {v(TMPA)}")
-    # ---- transform-role lane constants
-    E.i(f"s_sub_u32 {s(S_T0)}, {s(L_WAVE)}, 2")
-    E.i(f"s_cmp_lt_u32 {s(L_WAVE)}, 2")
-    E.i(f"s_cselect_b32 {s(S_T0)}, 1, {s(S_T0)}")                            # row0
-    E.i(f"s_mul_i32 {s(S_T0)}, {s(S_T0)}, {ROWP * 64}")
-    E.i(f"s_add_u32 {s(S_T0)}, {s(S_T0)}, {LDS_R0}")
+    # ---- transform lane constants.  Wave w: two-row piece (rows 1,2 for even w: alpha -4, beta 1; rows 3,4 for odd w: alpha -1, beta 2)
+    # of tile group w >> 1, one-row piece (row 0 for even w, row 5 for odd w) of the OTHER group.  Patch rows: two-row pieces read
+    # rows 1..4 (row0 = 1, step 1), row 0 reads rows 0,2,4 (row0 = 0, step 2), row 5 reads rows 1,3,5 (row0 = 1, step 2).
     E.i(f"v_lshrrev_b32 {v(TMPA)}, 2, {v(TT)}")                              # ty
     E.i(f"v_and_b32 {v(TMPB)}, 3, {v(TT)}")                                  # tx (inside the group)
     E.i(f"v_mul_u32_u24 {v(V_PRD)}, {4 * ROWP * 64}, {v(TMPA)}")
     E.i(f"v_lshl_add_u32 {v(V_PRD)}, {v(TMPB)}, 6, {v(V_PRD)}")
-    E.i(f"v_lshl_add_u32 {v(V_PRD)}, {v(TQ)}, 4, {v(V_PRD)}")
+    E.i(f"v_lshl_add_u32 {v(V_PRD)}, {v(TQ)}, 4, {v(V_PRD)}")                # (4 ty rows, tx, quad) of the lane
+    E.i(f"s_lshr_b32 {s(S_T1)}, {s(L_WAVE)}, 1")                             # g1 = w >> 1
+    E.i(f"s_and_b32 {s(S_T2)}, {s(L_WAVE)}, 1")                              # odd
+    E.i(f"s_lshl_b32 {s(S_T0)}, {s(S_T1)}, 8")                               # g1 * 4 slots * 64 bytes
+    E.i(f"s_add_u32 {s(S_T0)}, {s(S_T0)}, {LDS_R0 + ROWP * 64}")            # + row 1
+    E.i(f"s_xor_b32 {s(S_T3)}, {s(S_T1)}, 1")                                # g2 = 1 - g1
+    E.i(f"s_lshl_b32 {s(S_T4)}, {s(S_T3)}, 8")
+    E.i(f"s_mul_i32 {s(S_T3)}, {s(S_T2)}, {ROWP * 64}")                      # row0 of the one-row piece = odd
+    E.i(f"s_add_u32 {s(S_T4)}, {s(S_T4)}, {s(S_T3)}")
+    E.i(f"s_add_u32 {s(S_T4)}, {s(S_T4)}, {LDS_R0}")
+    E.i(f"v_add_u32 {v(V_PRD2)}, {s(S_T4)}, {v(V_PRD)}")
     E.i(f"v_add_u32 {v(V_PRD)}, {s(S_T0)}, {v(V_PRD)}")
-    E.i(f"s_cmp_eq_u32 {s(L_WAVE)}, 0")
-    E.i(f"s_cselect_b32 {s(S_T0)}, 1, 3")
-    E.i(f"s_cmp_eq_u32 {s(L_WAVE)}, 2")
-    E.i(f"s_cselect_b32 {s(S_T0)}, 0, {s(S_T0)}")
-    E.i(f"s_cmp_eq_u32 {s(L_WAVE)}, 3")
-    E.i(f"s_cselect_b32 {s(S_T0)}, 5, {s(S_T0)}")                            # xi_a
-    E.i(f"s_mul_i32 {s(S_T0)}, {s(S_T0)}, {6 * VPOS_B}")
+    # V write bases: position row xi_a of the piece, tile 16 g + t, quad ^ swz(t)
     E.i(f"v_and_b32 {v(TMPA)}, 1, {v(TMPA)}")
     E.i(f"v_lshlrev_b32 {v(TMPA)}, 1, {v(TMPA)}")                            # swz(tile)
     E.i(f"v_xor_b32 {v(TMPA)}, {v(TMPA)}, {v(TQ)}")
     E.i(f"v_lshlrev_b32 {v(TMPA)}, 4, {v(TMPA)}")
     E.i(f"v_lshl_or_b32 {v(TMPA)}, {v(TT)}, 6, {v(TMPA)}")
+    E.i(f"s_lshl_b32 {s(S_T0)}, {s(S_T2)}, 1")
+    E.i(f"s_add_u32 {s(S_T0)}, {s(S_T0)}, 1")                                # xi_a = 1 (even) or 3 (odd)
+    E.i(f"s_mul_i32 {s(S_T0)}, {s(S_T0)}, {6 * VPOS_B}")
+    E.i(f"s_lshl_b32 {s(S_T3)}, {s(S_T1)}, 10")                              # g1 * 16 tiles * 64 bytes
+    E.i(f"s_add_u32 {s(S_T0)}, {s(S_T0)}, {s(S_T3)}")
     E.i(f"v_add_u32 {v(V_VWR)}, {s(S_T0)}, {v(TMPA)}")
+    E.i(f"s_mul_i32 {s(S_T0)}, {s(S_T2)}, {5 * 6 * VPOS_B}")                 # xi = 0 (even) or 5 (odd)
+    E.i(f"s_xor_b32 {s(S_T3)}, {s(S_T1)}, 1")
+    E.i(f"s_lshl_b32 {s(S_T3)}, {s(S_T3)}, 10")
+    E.i(f"s_add_u32 {s(S_T0)}, {s(S_T0)}, {s(S_T3)}")
+    E.i(f"v_add_u32 {v(V_VWR2)}, {s(S_T0)}, {v(TMPA)}")
 
     def kpair(reg, value):
         E.i(f"s_mov_b32 {s(reg)}, {value}")
         E.i(f"s_mov_b32 {s(reg + 1)}, {value}")
     kpair(K_4, "4.0"); kpair(K_M5, "0xc0a00000"); kpair(K_2, "2.0"); kpair(K_M2, "-2.0"); kpair(K_M4, "-4.0"); kpair(K_8, "0x41000000")
-    E.i(f"s_cmp_eq_u32 {s(L_WAVE)}, 0")
+    E.i(f"s_bitcmp0_b32 {s(L_WAVE)}, 0")                                       # even wave: rows 1, 2
     for reg, v0_, v1_ in ((K_ALPHA, "-4.0", "-1.0"), (K_BETA, "1.0", "2.0"), (K_MBETA, "-1.0", "-2.0")):
         E.i(f"s_cselect_b32 {s(reg)}, {v0_}, {v1_}")
         E.i(f"s_mov_b32 {s(reg + 1)}, {s(reg)}")
@@ -625,17 +640,14 @@ def emit_kernel(E, name):
     emit_u_ring_fill(E)
     E.checkpoint(5, "first two raw chunks and the U ring requested")
     E.i("s_waitcnt vmcnt(0)")
-    E.i(f"s_cmp_lt_u32 {s(L_WAVE)}, 2")
-    E.i("s_cbranch_scc0 .Ljoin_B")
-    for role in ("A", "B"):
-        R = role
+    for R in ("A",):                                                          # one instruction stream for the four waves
         E.i(f"s_branch .Ljoin_{R}")
         # ================================================================================================ tile loop
         E.label(f".Ltile_{R}")
-        emit_body(E, role, 0, "first")
+        emit_body(E, 0, "first")
         E.checkpoint(8, "first chunk done")
         E.label(f".Lloop_{R}")
-        emit_body(E, role, 1, "mid")
+        emit_body(E, 1, "mid")
         E.i(f"s_cmp_eq_u32 {s(L_PAIRS)}, 1")
         E.i(f"s_cbranch_scc0 .Lnosetup_{R}")
         # ---- the next block: from here on the LDS-DMA loads fetch ITS first two chunks
@@ -648,11 +660,11 @@ def emit_kernel(E, name):
         E.i(f"s_add_u32 {s(S_T0)}, {s(S_T0)}, {s(L_TSTART)}")
         emit_setup_tile(E)
         E.label(f".Lnosetup_{R}")
-        emit_body(E, role, 0, "mid")
+        emit_body(E, 0, "mid")
         E.i(f"s_sub_u32 {s(L_PAIRS)}, {s(L_PAIRS)}, 1")
         E.i(f"s_cmp_lg_u32 {s(L_PAIRS)}, 0")
         E.i(f"s_cbranch_scc1 .Lloop_{R}")
-        emit_body(E, role, 1, "last")
+        emit_body(E, 1, "last")
         E.checkpoint(9, "every chunk of the block done; epilogue next")
         # every load that opens the next block (its U ring, raw chunks 0 and 1, bias) is home BEFORE the epilogue's stores join the queue
         E.i("s_waitcnt vmcnt(0)")
@@ -685,9 +697,7 @@ def emit_kernel(E, name):
     E.label(".Lepi_nopool")
     emit_epilogue(E, False)
     E.label(".Lepi_return")
-    E.i(f"s_cmp_lt_u32 {s(L_WAVE)}, 2")
-    E.i("s_cbranch_scc1 .Lepi_done_A")
-    E.i("s_branch .Lepi_done_B")
+    E.i("s_branch .Lepi_done_A")
     E.label(".Lend_program")
     E.i("s_waitcnt vmcnt(0) lgkmcnt(0)")
     E.i("s_endpgm")
