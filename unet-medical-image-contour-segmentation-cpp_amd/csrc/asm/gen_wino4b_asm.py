@@ -23,7 +23,8 @@ import sys
 
 from gen_wino4_asm import Emitter, LdsQueue, a, s, v, waitcnt
 
-UD = 9                       # U ring depth in positions (one 16-channel fragment = 4 registers per position)
+UD = 12                      # U ring depth in positions (one 16-channel fragment = 4 registers per position; same-card A/B of 6 / 9 / 12:
+                             # up4.c1 1.543 / 1.518 / 1.506 ms, profiles/r04_ab_wino4b_variants.txt)
 VPOS_B = 2048                # bytes per position of V: 32 tiles x 64 B
 VBUF_B = 36 * VPOS_B         # 73728
 ROWP = 36                    # pixel slots per patch row (34 live): pixel x = 4 a + c sits in slot 9 c + a
@@ -58,25 +59,34 @@ S_G1, S_PG1 = 100, 101       # byte offset of the right tile group in an output 
 S_PROW = 0                   # s[0:1]: pooled rows (the argument pointer is dead by then)
 
 U0 = 0
-AV0 = 4 * UD                 # 36: [2 position parities][2 groups][4]
-PX0 = AV0 + 16               # 52
-CR0 = PX0 + 32               # 84
-E0 = CR0 + 48                # 132
-TV0 = E0 + 16                # 148
-V_VRD0, V_VRD1, V_UVOFF, V_PRD, V_VWR = 160, 161, 162, 163, 164      # V_PRD / V_VWR: the two-row pass of the transform
-V_PRD2, V_VWR2 = 210, 211    # ... and its one-row pass (the other tile group)
-V_REL0 = 165                 # 11
-V_VOFF0 = 176                # 11
-V_PYPX0 = 187                # 11
-V_OUTOFF, V_POOLOFF, V_BIAS0, V_CHAN4 = 198, 199, 200, 201
-V_T0 = 202                   # eight temporaries (set-up code only)
 ACCV = 224
-assert TV0 + 12 <= V_VRD0 and V_T0 + 8 <= V_PRD2 and V_VWR2 < ACCV
 
-EP_M, EP_S, EP_Y, EP_C = PX0, PX0 + 12, PX0 + 20, PX0 + 28
-EP_T = CR0
-EP_VX = E0                   # 16 per-x voffsets
-EP_VXP = TV0                 # 8 per-x pooled voffsets
+
+def layout(ud):
+    """vector register map for a U ring of `ud` positions (4 registers each)"""
+    global UD, AV0, PX0, CR0, E0, TV0, V_VRD0, V_VRD1, V_UVOFF, V_PRD, V_VWR, V_PRD2, V_VWR2, V_REL0, V_VOFF0, V_PYPX0
+    global V_OUTOFF, V_POOLOFF, V_BIAS0, V_CHAN4, V_T0, EP_M, EP_S, EP_Y, EP_C, EP_T, EP_VX, EP_VXP
+    UD = ud
+    AV0 = 4 * UD                 # [2 position parities][2 groups][4]
+    PX0 = AV0 + 16
+    CR0 = PX0 + 32
+    E0 = CR0 + 48
+    TV0 = E0 + 16
+    base = TV0 + 12
+    V_VRD0, V_VRD1, V_UVOFF, V_PRD, V_VWR, V_PRD2, V_VWR2 = (base + i for i in range(7))   # V_PRD / V_VWR: two-row pass; ..2: one-row pass
+    V_REL0 = base + 7            # 11
+    V_VOFF0 = V_REL0 + 11        # 11
+    V_PYPX0 = V_VOFF0 + 11       # 11
+    V_OUTOFF, V_POOLOFF, V_BIAS0, V_CHAN4 = (V_PYPX0 + 11 + i for i in range(4))
+    V_T0 = V_CHAN4 + 1           # eight temporaries (set-up code only)
+    assert V_T0 + 8 <= ACCV, (ud, V_T0)
+    EP_M, EP_S, EP_Y, EP_C = PX0, PX0 + 12, PX0 + 20, PX0 + 28
+    EP_T = CR0
+    EP_VX = E0                   # 16 per-x voffsets
+    EP_VXP = TV0                 # 8 per-x pooled voffsets
+
+
+layout(UD)
 
 
 class E2(Emitter):
@@ -258,7 +268,8 @@ def emit_transform(E, rbuf):
 
 
 # ------------------------------------------------------------------------------------------------------------- chunk body
-DMA_POS = tuple(range(DMA_PER_WAVE))      # one LDS-DMA load in each of the first eleven positions of the MFMA phase
+DMA_POS = tuple(range(1, 34, 3))          # one LDS-DMA load every third position of the MFMA phase (tuning: --dma-pos; same card: the first
+                                          # eleven positions 1.518 ms, every second 1.504, every third 1.47, positions 12..22 1.53)
 
 
 def vm_wait_for_position(p):
@@ -778,8 +789,13 @@ def emit_kernel(E, name):
 
 
 def main():
-    global STOP_AT, DUMP
+    global STOP_AT, DUMP, DMA_POS
     out = sys.argv[1] if len(sys.argv) > 1 else "wino4b_gfx950.s"
+    if "--ud" in sys.argv:
+        layout(int(sys.argv[sys.argv.index("--ud") + 1]))
+    if "--dma-pos" in sys.argv:
+        DMA_POS = tuple(int(x) for x in sys.argv[sys.argv.index("--dma-pos") + 1].split(","))
+        assert len(DMA_POS) == DMA_PER_WAVE and len(set(DMA_POS)) == DMA_PER_WAVE and max(DMA_POS) < 36
     if "--dump" in sys.argv:
         DUMP = sys.argv[sys.argv.index("--dump") + 1]
     if "--stop" in sys.argv:
