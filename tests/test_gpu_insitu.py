@@ -124,11 +124,11 @@ def _show(tag, report):
 
 
 def test_fp32_plan_every_layer_at_512_batch_16():
-    """BASELINE configs[1]: the bench's fp32 workload (F(4x4) two-block + staged kernels, per-tap convT, fused head)"""
+    """BASELINE configs[1]: the bench's fp32 workload (both assembly F(4x4) kernels, the staged kernel with the fused first layer and with the fused head, per-tap convT)"""
     rep = _check_layers("winograd", UNetSpec(), 512, 16, 1234, img=5)
     _show("fp32 512^2 x16", rep)
     kernels = {k for _, k, _, _ in rep}
-    assert {"conv3x3_wino4s+first", "conv3x3_wino4a", "conv3x3_wino4s", "convT2x2_taps"} <= kernels and any(k.endswith("+head") for k in kernels)
+    assert {"conv3x3_wino4s+first", "conv3x3_wino4a", "conv3x3_wino4b", "convT2x2_taps"} <= kernels and any(k.endswith("+head") for k in kernels)
     assert "conv3x3_first" not in kernels and len(rep) == 21          # inc.c1 runs inside inc.c2's loader: one launch and 1 GiB of traffic less
 
 
