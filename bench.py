@@ -449,7 +449,9 @@ def run_pipeline_config5(binding, synth, dev_index, nimg=8):
 
 def summary_of(out):
     """the headline figures once more, compact, as the LAST key of the line (the driver keeps the tail of stdout)"""
-    s = {"configs[1]_fp32_images_per_s": round(out["value"], 1), "ms_per_step": round(out["ms_per_step"], 3),
+    wl = out["config"]["workload"]
+    head = (wl.split(":")[0].replace("BASELINE.json ", "") if wl.startswith("BASELINE.json") else "custom") + "_" + str(out["dtype"])
+    s = {head + "_images_per_s": round(out["value"], 1), "ms_per_step": round(out["ms_per_step"], 3),
          "roofline_frac": round(out["roofline"]["frac"], 4), "parity_ok": (out.get("parity") or {}).get("ok")}
     for c in out.get("configs") or []:
         if "value" in c:
