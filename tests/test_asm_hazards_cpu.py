@@ -19,14 +19,18 @@ HIPCC = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
 NEEDS_HIPCC = pytest.mark.skipif(not os.path.exists(HIPCC) and os.environ.get("MIUNET_NO_HIPCC_OK") == "1", reason="hipcc not installed")
 
 
+# the Makefile's extra flag for the files whose fully unrolled loops hold many inline-asm MFMAs (the size estimate of an asm trips the
+# pragma-unroll limit, and a loop left rolled indexes its register arrays through scratch)
+EXTRA_FLAGS = {"conv_wino4.hip": ["-mllvm", "-pragma-unroll-threshold=1000000"], "conv_lpr.hip": ["-mllvm", "-pragma-unroll-threshold=1000000"]}
+
+
 @NEEDS_HIPCC
 @pytest.mark.parametrize("src", sorted(os.path.basename(p) for p in glob.glob(os.path.join(CSRC, "*.hip"))))
 def test_no_wide_store_data_hazard(src, tmp_path):
     import scan_store_hazard
     asm = tmp_path / (src + ".s")
     flags = ["-O3", "-std=c++17", "--offload-arch=gfx950", "-S", "--cuda-device-only"]
-    if src == "conv_wino4.hip":                # the Makefile's extra flag for this file
-        flags += ["-mllvm", "-pragma-unroll-threshold=1000000"]
+    flags += EXTRA_FLAGS.get(src, [])
     subprocess.run([HIPCC, *flags, "-o", str(asm), os.path.join(CSRC, src)], check=True, capture_output=True, timeout=600)
     hits = scan_store_hazard.scan(str(asm))
     assert hits == [], "\n".join(hits)
@@ -49,7 +53,7 @@ def test_resident_weight_kernels_do_not_spill(tmp_path):
     accesses per tile).  Every instantiation must fit its register budget."""
     for src, kernels in (("conv_lpr.hip", 12), ("convt_lpr.hip", 6), ("conv_lprk.hip", 2)):       # shapes x two operand types
         asm = tmp_path / (src + ".s")
-        subprocess.run([HIPCC, "-O3", "-std=c++17", "--offload-arch=gfx950", "-S", "--cuda-device-only", "-o", str(asm),
+        subprocess.run([HIPCC, "-O3", "-std=c++17", "--offload-arch=gfx950", "-S", "--cuda-device-only", *EXTRA_FLAGS.get(src, []), "-o", str(asm),
                         os.path.join(CSRC, src)], check=True, capture_output=True, timeout=600)
         text = asm.read_text()
         assert text.count(".amdhsa_kernel ") >= kernels
@@ -69,7 +73,7 @@ def test_inline_asm_mfmas_have_their_wait_states(src, tmp_path):
     instantiation; the accumulate chain (the next MFMA taking the destination whole as its C) is exempt."""
     import scan_mfma_hazard
     asm = tmp_path / (src + ".s")
-    subprocess.run([HIPCC, "-O3", "-std=c++17", "--offload-arch=gfx950", "-S", "--cuda-device-only", "-o", str(asm),
+    subprocess.run([HIPCC, "-O3", "-std=c++17", "--offload-arch=gfx950", "-S", "--cuda-device-only", *EXTRA_FLAGS.get(src, []), "-o", str(asm),
                     os.path.join(CSRC, src)], check=True, capture_output=True, timeout=600)
     text = asm.read_text()
     assert text.count("v_mfma_f32_16x16x32") > 100 and "v_mfma_f32_32x32x16" not in text       # one MFMA shape in the 16-bit kernels

@@ -13,7 +13,10 @@ targets and loop back-edges included: an MFMA at a loop tail is checked against 
 import re
 import sys
 
-WAIT_D = 12        # MFMA destination -> any other access
+WAIT_D = 12        # MFMA destination -> any other access (the 8-pass 16x16x32 forms: 11 + 1)
+# the MFMAs the kernels issue through asm, and the states each needs behind it: conv_lpr.hip's fused first layer threads the 16-pass
+# v_mfma_f32_32x32x2_f32 between the 16-bit ones (19 + 1)
+SHAPES = {"v_mfma_f32_16x16x32": WAIT_D, "v_mfma_f32_32x32x2": 20}
 WAIT_S = 2         # VALU write -> MFMA source
 _REG = re.compile(r"\b([va])\[(\d+):(\d+)\]|\b([va])(\d+)\b")
 
@@ -64,7 +67,8 @@ def _states(line):
     return int(m.group(1)) + 1 if m else 1
 
 
-def scan(path, shapes=("v_mfma_f32_16x16x32",)):
+def scan(path, shapes=None):
+    shapes = SHAPES if shapes is None else {k: SHAPES.get(k, WAIT_D) for k in shapes}
     ins, labels = _instructions(path)
     preds = {}
     for j in range(len(ins)):
@@ -72,8 +76,9 @@ def scan(path, shapes=("v_mfma_f32_16x16x32",)):
             preds.setdefault(k, []).append(j)
     hits = []
     for i, line in enumerate(ins):
-        if not line.startswith(shapes):
+        if not line.startswith(tuple(shapes)):
             continue
+        wait_d = next(v for k, v in shapes.items() if line.startswith(k))
         ops = [o.strip() for o in line.split(None, 1)[1].split(",")]
         dst, srcs = _regs(ops[0]), _regs(ops[1]) | _regs(ops[2])
         # --- destination hazard: every path out of the MFMA (a loop's back-edge continues at the loop head), until WAIT_D states
@@ -82,7 +87,7 @@ def scan(path, shapes=("v_mfma_f32_16x16x32",)):
         found = None
         while work and found is None:
             j, states = work.pop()
-            if states >= WAIT_D or best.get(j, WAIT_D) <= states:
+            if states >= wait_d or best.get(j, wait_d) <= states:
                 continue
             best[j] = states
             nxt = ins[j]

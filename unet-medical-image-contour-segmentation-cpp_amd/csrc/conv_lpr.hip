@@ -47,14 +47,32 @@ struct LprGeom {
     static constexpr int PLANE_BYTES = PLANE_LOADS * 1024;
     static constexpr int RB_BYTES = 8 * PW * 64;                  // the next row block of the same wave: 8 patch rows further
 };
+// FIRST (the network's first layer computed in this kernel's loader, ConvArgs::first_img; C0 = channels of the u8 image): a window of
+// (PH + 2) x 36 normalised image pixels per tile in LDS as [pixel][C0] floats (conv3x3_first_mfma's layout, layers_mem.hip), and the
+// layer itself on v_mfma_f32_32x32x2_f32 exactly as that kernel runs it -- same K order, same accumulation: the same bits.  A unit
+// of work is 32 patch pixels x 32 channels: the first 32 columns of one patch row, or (the last units) 32 pixels of columns 32, 33.
+template <int RB, int CIN, int C0>
+struct LprFirst {
+    using GEO = LprGeom<RB>;
+    static constexpr int K = 9 * C0, KS = (K + 1) / 2;            // K steps of two
+    static constexpr int WP = GEO::PW + 2;                        // window pitch
+    static constexpr int WIN_PIX = (GEO::PH + 2) * WP;
+    static constexpr int WIN_FLOATS = WIN_PIX * C0 + 4;           // + zeros for the padded K step
+    static constexpr int WIN_BYTES = (WIN_FLOATS * 4 + 15) & ~15;
+    static constexpr int FILL_ITERS = (GEO::PH + 2 + 3) / 4;      // window rows in fours: thread = (row tid >> 7 of the four, byte tid & 127 of its 36 C0)
+    static constexpr int EDGE_BLOCKS = (2 * GEO::PH + 31) / 32;   // units of the columns 32, 33
+    static constexpr int UNITS = GEO::PH + EDGE_BLOCKS;           // (CIN = 32: one 32-channel block); wave w takes units w, w + 8, w + 16
+    static_assert(UNITS <= 24, "three units per wave");
+    static constexpr int BYTES = 2 * WIN_BYTES + 1024 + KS * 256 + FILL_ITERS * 2048;      // two windows, the /255 table, the B fragments [KS][64 lanes], the byte staging
+};
 struct LPR {
     static constexpr int TROW = 40;                               // 16-bit elements per pixel of the output tile (32 + 8 pad)
     static constexpr int SCR_BYTES = (32 + 8) * TROW * 2;         // per wave: [32 pixels][TROW] + pooled [8][TROW]
     static constexpr int HEAD_ROW = 32 + 4;                       // floats per pixel of the fused head's tile (conflict-free b128 rows)
     static constexpr int HEAD_SCR_BYTES = 32 * HEAD_ROW * 4;      // per wave: [32 pixels][HEAD_ROW] fp32
-    static constexpr size_t lds_bytes(int plane_bytes, int cin, int nbuf, bool head)
+    static constexpr size_t lds_bytes(int plane_bytes, int cin, int nbuf, bool head, int first_bytes = 0)
     {
-        return (size_t)nbuf * (cin / 32) * plane_bytes + 8 * (head ? HEAD_SCR_BYTES : SCR_BYTES) + (head ? 3 * 32 * 4 : 0);
+        return (size_t)nbuf * (cin / 32) * plane_bytes + 8 * (head ? HEAD_SCR_BYTES : SCR_BYTES) + (head ? 3 * 32 * 4 : 0) + first_bytes;
     }
 };
 
@@ -63,7 +81,16 @@ struct LPR {
 // post-ReLU fp32 row block crosses the wave's LDS scratch, lane = pixel, the head's weights stay in registers (96), the sums
 // run in the order of conv_mfma_bf16's fused head (four interleaved partial sums per class, folded at the end): the same
 // logits bit for bit.  `out` is never written.
-template <typename T, int CIN, int NBT, int NBUF, int RB, bool HEAD = false>
+// FIRST = C0 (1 or 3): the input tensor is the network's first layer, computed here from the u8 image (LprFirst above): instead of
+// the LDS-DMA of tile n + LEAD, the workgroup computes the patch of tile n + 1 BETWEEN the MFMA steps of tile n -- conv3x3_first_mfma's
+// arithmetic (fp32 MFMA over k = tap C0 + c, + shift, ReLU, one rounding to 16 bits), zero outside the image: the same bits as the
+// stand-alone first layer -- and stores it where the DMA would have.  The layer is bound by the matrix pipe either way (the first
+// layer's fp32 MFMAs are twice the conv's 16-bit ones in pipe time); interleaved, the dependent fp32 chain of a unit runs in the
+// shadow of the conv's independent MFMAs.  Built as a separate phase behind the epilogue it cost more than the launch it replaced
+// (same card, config 5: 0.51 ms against 0.21 + 0.27; timing-only builds: the phase 0.25 ms, of which stores 0.05).  Cin = 32 only:
+// the 64 -> 64 layer's 144 weight registers leave no room for a second accumulator set (256 registers per wave at 8 waves per CU).
+// The first layer's activation tensor (0.5 GB at 1024^2 x 32 x 8 images) is neither written nor read back.
+template <typename T, int CIN, int NBT, int NBUF, int RB, bool HEAD = false, int FIRST = 0>
 __global__ __launch_bounds__(512, 1) void conv3x3_lpr(const ConvArgs a, const int tiles_x, const int tiles_y, const int ntiles, const int exp_arg)
 {
 #ifdef MIUNET_EXPERIMENTS
@@ -75,10 +102,12 @@ __global__ __launch_bounds__(512, 1) void conv3x3_lpr(const ConvArgs a, const in
     typedef typename LprVec<T>::x8 x8;
     typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
     typedef __attribute__((address_space(3))) void *lds_ptr;
-    static_assert((CIN == 32 || CIN == 64) && (NBT == 1 || NBT == 2) && NBUF >= 3, "narrow layers only");
+    static_assert((CIN == 32 || CIN == 64) && (NBT == 1 || NBT == 2) && (NBUF >= 3 || FIRST != 0), "narrow layers only");
     static_assert(!HEAD || NBT == 1, "the fused head needs every channel of a pixel in one wave");
     static_assert(RB == 1 || CIN == 32, "two row blocks per wave: one 32-channel plane only (immediate LDS offsets, LDS size)");
+    static_assert(FIRST == 0 || ((FIRST == 1 || FIRST == 3) && !HEAD && NBUF == 2 && CIN == 32), "fused first layer: one or three image channels, two patch slots, 32 channels");
     using GEO = LprGeom<RB>;
+    using FG = LprFirst<RB, CIN, FIRST ? FIRST : 1>;
     constexpr int PLANES = CIN / 32;
     constexpr bool SPLITN = CIN * NBT > 64;                   // 64 -> 64: a wave keeps ONE 32-channel block (144 weight registers) ...
     constexpr int MB = SPLITN ? 2 : 1;                        // ... for both column halves of its row pair; otherwise one row block,
@@ -119,7 +148,13 @@ __global__ __launch_bounds__(512, 1) void conv3x3_lpr(const ConvArgs a, const in
     // ---- per-lane LDS byte offsets of the A fragments inside a plane: pixel (row 2 rp + mr, column 16 ch0 + i16) of the
     // tile displaced by the tap, 16-byte piece kq in slot kq ^ lds_swz_row16(column) (lpr_common.h; the second row block of a
     // wave is 8 rows down and the second column half 16 columns right: the same slots)
-    unsigned aoff[9][2];
+    // (FIRST: the register file is full -- three column offsets, the row displacement goes into the reads' immediate offsets)
+    unsigned aoff[9][2], acol[3];
+#pragma unroll
+    for (int dx = 0; dx < 3; ++dx) {
+        const int pcol = 16 * ch0 + i16 + dx;
+        acol[dx] = (unsigned)((2 * rp * GEO::PW + pcol) * 64 + ((kq ^ lds_swz_row16(pcol)) << 4));
+    }
 #pragma unroll
     for (int tap = 0; tap < 9; ++tap) {
         const int dy = tap / 3, dx = tap - 3 * dy;
@@ -134,7 +169,7 @@ __global__ __launch_bounds__(512, 1) void conv3x3_lpr(const ConvArgs a, const in
     // wave + 8 k covers pixels 16 (i % 22) .. + 16 of plane i / 22, lane l = (pixel l >> 2, slot l & 3)
     unsigned dvoff[DMA_ITERS];
 #pragma unroll
-    for (int k = 0; k < DMA_ITERS; ++k) {
+    for (int k = 0; k < (FIRST != 0 ? 0 : DMA_ITERS); ++k) {
         const int i = wave + 8 * k, c = i / GEO::PLANE_LOADS, j = i - c * GEO::PLANE_LOADS;
         const int p = 16 * j + (lane >> 2);
         const int py = p / GEO::PW, px = p - py * GEO::PW;
@@ -224,11 +259,149 @@ __global__ __launch_bounds__(512, 1) void conv3x3_lpr(const ConvArgs a, const in
     };
 
     if (nt == 0) return;
+
+    // ---- FIRST: the fused first layer (see LprFirst and the kernel's header)
+    constexpr int C0 = FIRST ? FIRST : 1;
+    char *const WinL = smem + LPR::lds_bytes(GEO::PLANE_BYTES, CIN, NBUF, HEAD);
+    float *const LutL = reinterpret_cast<float *>(WinL + 2 * FG::WIN_BYTES);
+    const int li = lane & 31, lh = lane >> 5;
+    float *const FbwL = LutL + 256;                                            // B fragments: [s][lane] = w[2 s + lh][li] (LDS: the register file is full)
+    float fsh = 0.f;                                                           // shift of channel li
+    // window offset of k = tap C0 + c: the 3 C0 values of a kernel row are consecutive floats of the window.  A lane's k is 2 s + lh:
+    // its offset is that of k = 2 s plus lh -- folded into the lane's unit base -- except where 2 s + 1 starts the next kernel row
+    // (+ lhx more); the padded step past K reads a finite neighbour (its weight is 0).  So a read is base + an immediate.
+    auto fkoff = [](const int k) constexpr { return (k / (3 * C0)) * FG::WP * C0 + k % (3 * C0); };
+    const int lhx = lh * (FG::WP * C0 - 3 * C0);
+    auto tile_of = [&](const int n, int &b, int &y0, int &x0) {
+        int L = t_start + slot + n * slots;
+        const int tx = L % tiles_x; L /= tiles_x;
+        const int ty = L % tiles_y;
+        b = L / tiles_y; y0 = ty * GEO::TH; x0 = tx * 32;
+    };
+    // the window's rows are runs of 36 C0 bytes of the image: four rows per pass, thread = (row, byte).  The bytes come by LDS-DMA
+    // (one byte per lane into a dword slot of the staging area: no registers, and a whole MFMA loop between request and use); outside
+    // the image the range check returns the byte 0, which the /255 table maps to 0.0f: the first layer's zero padding.  Every thread
+    // converts the slots its own wave requested, so the wave's own vmcnt wait is all the ordering the staging area needs.
+    char *const StageL = reinterpret_cast<char *>(FbwL + FG::KS * 64);
+    const int wr0 = tid >> 7, wbx = tid & 127, wgx = wbx / C0;
+    auto win_request = [&](const int n) {
+        int b, y0, x0;
+        tile_of(n, b, y0, x0);
+        const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t *>(a.first_img) + (size_t)b * a.H * a.W * C0, 0, a.H * a.W * C0, 0x00020000);
+        const int gx = x0 - 2 + wgx;
+        const bool xok = wbx < FG::WP * C0 && (unsigned)gx < (unsigned)a.W;
 #pragma unroll
-    for (int n = 0; n < LEAD; ++n)
-        if (n < nt) issue_dma(n);
-    // tile 0 has landed when at most the loads of tiles 1 .. LEAD - 1 are outstanding
-    {
+        for (int it = 0; it < FG::FILL_ITERS; ++it) {
+            const int gy = y0 - 2 + 4 * it + wr0;
+            const bool ok = xok && (unsigned)gy < (unsigned)a.H && 4 * it + wr0 < GEO::PH + 2;
+            const unsigned voff = ok ? (unsigned)((gy * a.W + x0 - 2) * C0 + wbx) : 0xFFFFFFFFu;
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lds_ptr)(StageL + it * 2048 + wave * 256), 1, voff, 0, 0, 0);
+        }
+    };
+    auto win_commit = [&](const int buf) {    // (after this wave's vmcnt wait) ... through the /255 table into window `buf`
+        float *const w = reinterpret_cast<float *>(WinL + buf * FG::WIN_BYTES) + wr0 * FG::WP * C0 + wbx;
+#pragma unroll
+        for (int it = 0; it < FG::FILL_ITERS; ++it)
+            if (wbx < FG::WP * C0 && 4 * it + wr0 < GEO::PH + 2) w[4 * it * FG::WP * C0] = LutL[*reinterpret_cast<const unsigned *>(StageL + it * 2048 + tid * 4) & 255u];
+        if (tid < 4) reinterpret_cast<float *>(WinL + buf * FG::WIN_BYTES)[FG::WIN_PIX * C0 + tid] = 0.f;
+    };
+    // ---- the units of this wave: un = 0, 1 are the patch rows `wave` and `wave + 8`; un = 2 is row wave + 16, or (past the
+    // rows) the block eb = wave + 16 - PH of the columns 32, 33, or nothing.  Accumulator register r of a unit is its pixel
+    // c_r + 4 lh, c_r = (r & 3) + 8 (r >> 2): a row unit's column (slot swizzle = the lane constant 2 lh), an edge block's pixel
+    // (row 16 eb + 2 lh + (c_r >> 1), column 32 + (c_r & 1): swizzle 0) -- a store address is a lane constant plus an immediate.
+    const bool has3 = wave + 16 < FG::UNITS, edge3 = wave + 16 >= GEO::PH;      // (uniform)
+    const int eb3 = wave + 16 - GEO::PH;
+    const int ee = 32 * eb3 + li;
+    const int upb_c[3] = { (wave * FG::WP + li) * C0 + lh, ((wave + 8) * FG::WP + li) * C0 + lh,
+                           (edge3 ? (((ee >> 1) < GEO::PH ? (ee >> 1) : GEO::PH - 1) * FG::WP + 32 + (ee & 1)) * C0 : ((wave + 16) * FG::WP + li) * C0) + lh };
+    const unsigned frow0 = (unsigned)((li & 7) * 2 + 4 * lh * 64 + (((li >> 3) ^ (2 * lh)) << 4));
+    const unsigned ust_c[3] = { (unsigned)(wave * GEO::PW * 64) + frow0, (unsigned)((wave + 8) * GEO::PW * 64) + frow0,
+                                edge3 ? (unsigned)((li & 7) * 2 + ((li >> 3) << 4) + ((16 * eb3 + 2 * lh) * GEO::PW + 32) * 64)
+                                      : (unsigned)((wave + 16) * GEO::PW * 64) + frow0 };
+    int fy0 = 0, fx0 = 0;                     // the tile whose patch is being computed: origin,
+    bool finterior = true;                    // no patch pixel outside the image,
+    const float *fwin = nullptr;              // window,
+    char *fdst = nullptr;                     // patch slot
+    f32x16 facc;
+    // border tiles: bit r of fcolm = column c_r + 4 lh of a row unit is inside the image (the row itself is a uniform test), bit r
+    // of fedgm = pixel r of this wave's edge block is
+    unsigned fcolm = 0xFFFFu, fedgm = 0xFFFFu;
+    auto first_setup = [&](const int n, const int into) {
+        int b;
+        tile_of(n, b, fy0, fx0);
+        finterior = fy0 >= 1 && fy0 + GEO::PH - 1 <= a.H && fx0 >= 1 && fx0 + 33 <= a.W;
+        fwin = reinterpret_cast<const float *>(WinL + (n & 1) * FG::WIN_BYTES);
+        fdst = smem + (into % NBUF) * TILE_BYTES;
+        fcolm = 0xFFFFu; fedgm = 0xFFFFu;
+        if (!finterior) {
+            unsigned cm = 0, em = 0;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int cr = (r & 3) + 8 * (r >> 2);
+                cm |= (unsigned)(fx0 - 1 + cr + 4 * lh) < (unsigned)a.W ? (1u << r) : 0u;
+                em |= ((unsigned)(fy0 - 1 + 16 * eb3 + 2 * lh + (cr >> 1)) < (unsigned)a.H && (unsigned)(fx0 + 31 + (cr & 1)) < (unsigned)a.W) ? (1u << r) : 0u;
+            }
+            fcolm = cm; fedgm = em;
+        }
+    };
+    auto unit_store = [&](const int un) {     // + shift, ReLU, one rounding; zero outside the image
+        char *const d = fdst + ust_c[un];
+        const unsigned mk = (un == 2 && edge3) ? fedgm : ((unsigned)(fy0 - 1 + wave + 8 * un) < (unsigned)a.H ? fcolm : 0u);
+        if (!(un == 2 && edge3)) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const float v = facc[r] + fsh;
+                *reinterpret_cast<T *>(d + ((r & 3) + 8 * (r >> 2)) * 64) = (mk >> r & 1u) ? (T)(v > 0.f ? v : 0.f) : (T)0.f;
+            }
+        } else {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int cr = (r & 3) + 8 * (r >> 2);
+                const float v = facc[r] + fsh;
+                if (16 * eb3 + 2 * lh + (cr >> 1) < GEO::PH)
+                    *reinterpret_cast<T *>(d + ((cr >> 1) * GEO::PW + (cr & 1)) * 64) = (mk >> r & 1u) ? (T)(v > 0.f ? v : 0.f) : (T)0.f;
+            }
+        }
+    };
+    // K step q % KS of unit q / KS (q is a constant after unrolling): the operands are READ one conv step ahead of the MFMA that
+    // takes them (LDS reads do not move across volatile asms, so a read next to its MFMA would expose the LDS latency 42 times per tile)
+    constexpr int MS = (3 * FG::KS + 9 * PLANES - 1) / (9 * PLANES);        // first-layer K steps per conv step
+    float fav[MS] = {}, fbv[MS] = {};
+    auto first_read = [&](const int q, const int i) {
+        const int un = q / FG::KS, s_ = q - un * FG::KS;
+        if (un == 2 && !has3) return;
+        const bool cross = (2 * s_ + 1) % (3 * C0) == 0 && 2 * s_ + 1 < FG::K;
+        fav[i] = fwin[upb_c[un] + fkoff(2 * s_) + (cross ? lhx : 0)];
+        fbv[i] = FbwL[s_ * 64 + lane];
+    };
+    auto first_micro = [&](const int q, const int i) {
+        const int un = q / FG::KS, s_ = q - un * FG::KS;
+        if (un == 2 && !has3) return;
+        if (s_ == 0) mfma32_f32_first(facc, fav[i], fbv[i]);
+        else mfma32_f32(facc, fav[i], fbv[i]);
+        if (s_ == FG::KS - 1 && !(exp & 8)) { mfma32_settle(facc); unit_store(un); }      // (exp & 8, lab build: no stores -- timing only)
+    };
+    if constexpr (FIRST != 0) {
+        for (int e = tid; e < FG::KS * 64; e += 512) {
+            const int k = 2 * (e >> 6) + ((e >> 5) & 1);
+            FbwL[e] = k < FG::K ? a.first_w[(size_t)k * CIN + (e & 31)] : 0.f;
+        }
+        fsh = a.first_shift[li];
+        if (tid < 256) LutL[tid] = a.first_lut[tid];
+        win_request(0);
+        __syncthreads();                      // the table
+        lpr_wait_vm<0>(); asm volatile("" ::: "memory");
+        win_commit(0);
+        if (nt > 1) { win_request(1); lpr_wait_vm<0>(); asm volatile("" ::: "memory"); win_commit(1); }
+        __syncthreads();                      // both windows
+        first_setup(0, 0);                    // the patch of tile 0; every later one is computed under the MFMAs of the tile before
+#pragma unroll
+        for (int q = 0; q < 3 * FG::KS; ++q) { first_read(q, 0); first_micro(q, 0); }
+    } else {
+#pragma unroll
+        for (int n = 0; n < LEAD; ++n)
+            if (n < nt) issue_dma(n);
+        // tile 0 has landed when at most the loads of tiles 1 .. LEAD - 1 are outstanding
         int later = 0;
 #pragma unroll
         for (int n = 1; n < LEAD; ++n) later += (n < nt) ? my_loads : 0;
@@ -238,7 +411,15 @@ __global__ __launch_bounds__(512, 1) void conv3x3_lpr(const ConvArgs a, const in
     for (int n = 0; n < nt; ++n) {
         __syncthreads();                      // tile n is complete in LDS (every wave waited for its share); tile n - 1 is consumed
         // (exp: timing-only switches, MIUNET_LPR_EXP, results WRONG -- 1 = no patch DMA after the ring's first fill, 2 = no output stores)
-        if (n + LEAD < nt && !(exp & 1)) issue_dma(n + LEAD);      // ... into the slot tile n - 1 just left
+        if constexpr (FIRST != 0) {
+            // window n + 1 is complete, patch slot (n + 1) % 2 is free: the patch of tile n + 1 is computed between the MFMA steps below;
+            // the bytes of window n + 2 are requested now (LDS-DMA) and converted behind the MFMAs, into the window tile n's patch
+            // was computed from
+            if (n + 2 < nt && !(exp & 16)) win_request(n + 2);
+            first_setup(n + 1 < nt ? n + 1 : n, n + 1);       // (past the last tile: that tile once more, into the free slot -- no branch in the steps)
+        } else {
+            if (n + LEAD < nt && !(exp & 1)) issue_dma(n + LEAD);      // ... into the slot tile n - 1 just left
+        }
 
         // ---- tile n: 9 taps x Cin / 16 MFMAs per row block and channel block
         const unsigned base = (unsigned)((n % NBUF) * TILE_BYTES);
@@ -254,12 +435,21 @@ __global__ __launch_bounds__(512, 1) void conv3x3_lpr(const ConvArgs a, const in
                 for (int mb = 0; mb < MB; ++mb)
 #pragma unroll
                     for (int mr = 0; mr < 2; ++mr)
-                        dst[rb][mb][mr] = *reinterpret_cast<const x8 *>(smem + (base + aoff[tap][mr]) + c * GEO::PLANE_BYTES + rb * GEO::RB_BYTES + mb * 1024);
+                        dst[rb][mb][mr] = FIRST != 0
+                            ? *reinterpret_cast<const x8 *>(smem + (base + acol[tap % 3]) + (mr + tap / 3) * GEO::PW * 64 + c * GEO::PLANE_BYTES + rb * GEO::RB_BYTES + mb * 1024)
+                            : *reinterpret_cast<const x8 *>(smem + (base + aoff[tap][mr]) + c * GEO::PLANE_BYTES + rb * GEO::RB_BYTES + mb * 1024);
         };
         read_step(0, af[0]);
 #pragma unroll
         for (int t = 0; t < 9 * PLANES; ++t) {
             const int c = t / 9, tap = t - 9 * c;
+            if constexpr (FIRST != 0) {           // the operands of this step's share of the next tile's patch
+                if (!(exp & 4)) {
+#pragma unroll
+                    for (int i = 0; i < MS; ++i)
+                        if (t * MS + i < 3 * FG::KS && !(exp & 32)) first_read(t * MS + i, i);      // (exp & 32, lab build: stale operands -- timing only)
+                }
+            }
             if (t + 1 < 9 * PLANES) read_step(t + 1, af[(t + 1) & 1]);
 #pragma unroll
             for (int rb = 0; rb < RB; ++rb)
@@ -272,6 +462,13 @@ __global__ __launch_bounds__(512, 1) void conv3x3_lpr(const ConvArgs a, const in
                             if (t == 0) mfma16_lpr_first(acc[rb][mb][mr][jb], af[t & 1][rb][mb][mr], wreg[tap][c][jb]);
                             else mfma16_lpr(acc[rb][mb][mr][jb], af[t & 1][rb][mb][mr], wreg[tap][c][jb]);
                         }
+            if constexpr (FIRST != 0) {           // this step's share of the next tile's patch (exp & 4, lab build: none -- timing only)
+                if (!(exp & 4)) {
+#pragma unroll
+                    for (int i = 0; i < MS; ++i)
+                        if (t * MS + i < 3 * FG::KS) first_micro(t * MS + i, i);
+                }
+            }
         }
         mfma16_drain();                           // (lpr_common.h: the epilogue below reads the accumulators with no barrier in between)
 #pragma unroll
@@ -283,8 +480,10 @@ __global__ __launch_bounds__(512, 1) void conv3x3_lpr(const ConvArgs a, const in
 #pragma unroll
                     for (int jb = 0; jb < NB16; ++jb) mfma16_settled(acc[rb][mb][mr][jb]);
 
-        // ---- this wave's loads of tile n + 1 (older than everything it issued for tiles n + 2 .. n + LEAD)
-        {
+        if constexpr (FIRST != 0) {
+            if (n + 2 < nt && !(exp & 16)) { lpr_wait_vm<0>(); asm volatile("" ::: "memory"); win_commit(n & 1); }      // (the DMA wrote LDS behind the compiler's back)
+        } else {
+            // ---- this wave's loads of tile n + 1 (older than everything it issued for tiles n + 2 .. n + LEAD)
             int later = 0;
 #pragma unroll
             for (int d = 2; d <= LEAD; ++d) later += (n + d < nt) ? my_loads : 0;
@@ -388,7 +587,7 @@ __global__ __launch_bounds__(512, 1) void conv3x3_lpr(const ConvArgs a, const in
     }
 }
 
-template <typename T, int CIN, int NBT, int NBUF, int RB, bool HEAD = false>
+template <typename T, int CIN, int NBT, int NBUF, int RB, bool HEAD = false, int FIRST = 0>
 static hipError_t launch_lpr_cfg(const ConvArgs &a, hipStream_t s)
 {
     using GEO = LprGeom<RB>;
@@ -396,9 +595,9 @@ static hipError_t launch_lpr_cfg(const ConvArgs &a, hipStream_t s)
     const int ntiles = tiles_x * tiles_y * a.B;
     const int cus = routing_of(a).cus;
     const int grid = ntiles < cus ? ntiles : cus;
-    constexpr size_t lds = LPR::lds_bytes(GEO::PLANE_BYTES, CIN, NBUF, HEAD);
+    constexpr size_t lds = LPR::lds_bytes(GEO::PLANE_BYTES, CIN, NBUF, HEAD, FIRST ? LprFirst<RB, CIN, FIRST ? FIRST : 1>::BYTES : 0);
     static_assert(lds <= 160 * 1024, "LDS of one CU");
-    auto kern = conv3x3_lpr<T, CIN, NBT, NBUF, RB, HEAD>;
+    auto kern = conv3x3_lpr<T, CIN, NBT, NBUF, RB, HEAD, FIRST>;
     if (hipError_t e = ensure_dynamic_lds(kern, lds); e != hipSuccess) return e;
 #ifdef MIUNET_EXPERIMENTS                              // lab build only (libmiunet_exp.so, tools/dev/ab*.sh): never in libmiunet.so
     static const int exp = [] { const char *e = getenv("MIUNET_LPR_EXP"); return e ? atoi(e) : 0; }();          // timing-only switches (see the kernel)
@@ -407,6 +606,14 @@ static hipError_t launch_lpr_cfg(const ConvArgs &a, hipStream_t s)
 #endif
     hipLaunchKernelGGL(kern, dim3(grid), dim3(512), lds, s, a, tiles_x, tiles_y, ntiles, exp);
     return hipGetLastError();
+}
+
+// The fused first layer (ConvArgs::first_img): 32 -> 32 channels behind a three-channel image (BASELINE config 5's inc.c2);
+// `first_cin` = channels of the image.  Not 64 -> 64: see the kernel's header.
+bool conv3x3_lpr_can_fuse_first(const ConvArgs &a, int first_cin)
+{
+    if (a.head_w != nullptr || !a.out_lp) return false;
+    return first_cin == 3 && a.Cin == 32 && a.Cout == 32;
 }
 
 static bool lpr_shape_ok(const ConvArgs &a)
@@ -443,6 +650,8 @@ static hipError_t launch_lpr(const ConvArgs &a, hipStream_t s)
     const int rb_env = routing_of(a).lpr_rb;                // MIUNET_LPR_RB = 1: 8-row tiles for every shape (A/B, parity tests)
     // the fused head keeps 8-row tiles: with two row blocks its 96 head-weight registers spill, and scratch traffic shares
     // vmcnt with the patch DMA (the compiler's waits for it drain the ring: measured 0.27 -> 0.53 ms)
+    if (a.first_img != nullptr)               // (the caller asked conv3x3_lpr_can_fuse_first)
+        return (a.Cin == 32 && a.Cout == 32 && a.first_cin == 3) ? launch_lpr_cfg<T, 32, 1, 2, 2, false, 3>(a, s) : hipErrorInvalidValue;
     if (a.head_w != nullptr) return launch_lpr_cfg<T, 32, 1, 4, 1, true>(a, s);
     if (rb_env == 2) {
         if (a.Cin == 32 && a.Cout == 32) return launch_lpr_cfg<T, 32, 1, 3, 2>(a, s);

@@ -609,8 +609,16 @@ int launch_plan(mi_unet *h, const uint8_t *d_imgs, int B, uint8_t *d_labels, flo
     bool head_done = false;
     int step_index = -1;
     // The first layer can run inside its consumer (conv_wino4s.hip, FIRST): when the default fp32 plan sends inc.c2 to the staged
-    // F(4x4) kernel at this batch size, one input channel.  Decided per launch, like every routing choice that depends on the grid.
+    // F(4x4) kernel at this batch size, one input channel ...  Decided per launch, like every routing choice that depends on the grid.
     const Step *fused_first = nullptr;
+    if (h->plan.size() >= 2 && h->plan[0].kind == Step::FIRST && h->plan[1].kind == Step::CONV && lp_kind != 0 && h->routing.fuse_first &&
+        h->plan[1].head_step < 0) {
+        // ... and in the 16-bit plans when inc.c2 goes to the resident-weight kernel (conv_lpr.hip, FIRST) with one of its two fused shapes
+        ConvArgs a = h->plan[1].a; a.B = B; a.rt = h->routing;
+        a.out_lp = h->plan[1].feeds_head ? 0 : 1;
+        if (!conv3x3_lp2_takes(a) && !conv3x3_lprk_takes(a) && conv3x3_lpr_takes(a) && conv3x3_lpr_can_fuse_first(a, h->plan[0].C))
+            fused_first = &h->plan[0];
+    }
     if (h->plan.size() >= 2 && h->plan[0].kind == Step::FIRST && h->plan[1].kind == Step::CONV && lp_kind == 0 && h->routing.fuse_first &&
         h->algo == MI_UNET_CONV_WINOGRAD && !h->wino4_guard_tripped && h->plan[1].a.wpk4 != nullptr && h->plan[1].head_step < 0) {
         ConvArgs a = h->plan[1].a; a.B = B; a.rt = h->routing;
@@ -692,7 +700,11 @@ int launch_plan(mi_unet *h, const uint8_t *d_imgs, int B, uint8_t *d_labels, flo
                 e = launch_conv3x3_lprk(a, lp_kind == 2, s);
             }
             else if (lp_kind != 0 && conv3x3_lpr_takes(a)) {     // narrow layer: weights in registers, persistent (conv_lpr.hip)
-                kname = lp_kind == 1 ? (head_done ? "conv3x3_bf16r+head" : "conv3x3_bf16r") : (head_done ? "conv3x3_fp16r+head" : "conv3x3_fp16r");
+                if (fused_first != nullptr && step_index == 1) {           // the first layer runs in this launch's loader
+                    a.first_img = d_imgs; a.first_cin = fused_first->C; a.first_lut = h->d_lut; a.first_w = fused_first->w; a.first_shift = fused_first->shift;
+                }
+                kname = lp_kind == 1 ? (head_done ? "conv3x3_bf16r+head" : a.first_img ? "conv3x3_bf16r+first" : "conv3x3_bf16r")
+                                     : (head_done ? "conv3x3_fp16r+head" : a.first_img ? "conv3x3_fp16r+first" : "conv3x3_fp16r");
                 e = launch_conv3x3_lpr(a, lp_kind == 2, s);
             }
             else if (h->algo == MI_UNET_CONV_BF16) { kname = head_done ? "conv3x3_bf16+head" : "conv3x3_bf16"; e = launch_conv3x3_bf16(a, s); }
@@ -803,7 +815,7 @@ int launch_plan(mi_unet *h, const uint8_t *d_imgs, int B, uint8_t *d_labels, flo
             ks.bytes = (st.bytes_per_img * B + st.weight_bytes) * ((lp_kind && (st.kind == Step::CONV || st.kind == Step::CONVT)) ? 0.5 : 1.0);
             if (fused_first != nullptr && step_index == 1) {           // + the first layer's arithmetic; the image in place of its output tensor
                 ks.flops += fused_first->flops_per_img * B;
-                ks.bytes += ((double)fused_first->H * fused_first->W * fused_first->C - 4.0 * st.a.H * st.a.W * st.a.Cin) * B;
+                ks.bytes += ((double)fused_first->H * fused_first->W * fused_first->C - (lp_kind ? 2.0 : 4.0) * st.a.H * st.a.W * st.a.Cin) * B;
             }
             ks.ms = -1.f;                      // filled by mi_unet_get_kernel_stats
             h->stats.push_back(ks);

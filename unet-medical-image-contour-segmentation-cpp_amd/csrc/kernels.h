@@ -74,6 +74,7 @@ struct ConvArgs {
     // channels = this layer's Cin) + shift + ReLU, the arithmetic of conv3x3_first_kernel -- so the first layer's 1 GiB tensor is
     // neither written nor read back.  first_w is [9][1][Cin] (BN scale folded), first_shift [Cin].
     const uint8_t *first_img;
+    int first_cin;                  // channels of first_img (conv_lpr.hip; conv_wino4s.hip takes one channel only)
     const float *first_lut, *first_w, *first_shift;
 };
 
@@ -100,6 +101,7 @@ hipError_t launch_conv3x3_wino4(const ConvArgs &a, hipStream_t s);
 hipError_t launch_conv3x3_wino4s(const ConvArgs &a, hipStream_t s);
 bool conv3x3_wino4_runs_staged(const ConvArgs &a);   // the routing decision of launch_conv3x3_wino4 (for the launch log)
 bool conv3x3_wino4s_can_fuse_first(const ConvArgs &a, int first_cin);   // shape contract of the fused first layer (conv_wino4s.hip)
+bool conv3x3_lpr_can_fuse_first(const ConvArgs &a, int first_cin);      // ... of the 16-bit resident-weight kernel (conv_lpr.hip)
 // The two-block kernel hand-scheduled in gfx950 assembly and persistent (csrc/asm/gen_wino4_asm.py, csrc/wino4_asm.cpp): same
 // packing (a.wpk4), same tensors.  shape_ok = the contract of the assembly (whole 16x16 blocks, Cin % 32 == 0 and >= 64, Cout % 128
 // == 0, fp32, no fused head); runs_asm = what launch_conv3x3_wino4 decides (shape, MIUNET_WINO4_ASM, not a split-K grid).

@@ -36,6 +36,13 @@ __device__ __forceinline__ void mfma16_lpr_first(f32x4 &c, LprVec<_Float16>::x8 
 {
     asm volatile("v_mfma_f32_16x16x32_f16 %0, %1, %2, 0" : "=&v"(c) : "v"(a), "v"(b));
 }
+// ---- v_mfma_f32_32x32x2_f32 in place, for a kernel that threads a second, fp32 GEMM between its 16-bit MFMAs (conv_lpr.hip, FIRST):
+// volatile asms keep their program order, a builtin would be clustered away from them.  Lane (i = lane & 31, h = lane >> 5)
+// supplies A[i][h] and B[h][i] and holds D[(r & 3) + 8 (r >> 2) + 4 h][i] in register r.  A chain starts from the literal 0;
+// before the first VALU read of the result: mfma32_settle (a 16-pass MFMA needs 18 wait states there; the asm hides it from hipcc).
+__device__ __forceinline__ void mfma32_f32(f32x16 &c, float a, float b) { asm volatile("v_mfma_f32_32x32x2_f32 %0, %1, %2, %0" : "+v"(c) : "v"(a), "v"(b)); }
+__device__ __forceinline__ void mfma32_f32_first(f32x16 &c, float a, float b) { asm volatile("v_mfma_f32_32x32x2_f32 %0, %1, %2, 0" : "=&v"(c) : "v"(a), "v"(b)); }
+__device__ __forceinline__ void mfma32_settle(f32x16 &c) { asm volatile("s_nop 7\n\ts_nop 7\n\ts_nop 7" : "+v"(c)); }
 // The compiler does not see an MFMA behind the asm, so it pads nothing between the last of them and the first VALU read of
 // an accumulator (a 4-pass MFMA needs 7 wait states there): a kernel whose epilogue follows its MFMAs without a barrier calls
 // mfma16_drain() once and mfma16_settled(acc) on every accumulator -- volatile asms keep their order, and every later read
