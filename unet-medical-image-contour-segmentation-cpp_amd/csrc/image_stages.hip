@@ -182,39 +182,53 @@ __global__ __launch_bounds__(256) void cc_merge(const uint8_t *__restrict__ fg, 
     }
 }
 
-// flatten + per-component area and bounding box.  Lanes of a wave mostly share one root, and same-address atomics
-// serialise, so the wave first reduces per distinct root and one lane issues the five atomics.
+// flatten + per-component area and bounding box.  Lanes of a wave mostly share one root, and same-address atomics serialise
+// (a mask is a handful of components: every wave of the image would queue on the same five words -- 0.25 ms per call at
+// 4 x 1024^2, profiles/r04_image_stage_kernels.txt), so a wave reduces per distinct root inside a 64-pixel segment AND carries
+// that root's sums over CC_RUN consecutive segments, issuing the five atomics only when the root changes.
+constexpr int CC_RUN = 16;
 __global__ __launch_bounds__(256) void cc_stats(int *parent, int *area, int *minx, int *miny, int *maxx, int *maxy, int H, int W,
                                                 long long n)
 {
-    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
-    int r = -1, x = 0, y = 0;
-    if (i < n && parent[i] >= 0) {
-        r = find_root_ro(parent, (int)i);
-        parent[i] = r;
-        const int p = (int)(i % ((long long)H * W));
-        y = p / W; x = p - y * W;
-    }
     const int lane = threadIdx.x & 63;
-    unsigned long long todo = __ballot(r >= 0);
-    while (todo) {
-        const int leader = __builtin_ctzll(todo);
-        const int r0 = __shfl(r, leader, 64);
-        const bool mine = r == r0;
-        const unsigned long long m = __ballot(mine);
-        int lx = mine ? x : 0x7FFFFFFF, hx = mine ? x : -1, ly = mine ? y : 0x7FFFFFFF, hy = mine ? y : -1;
+    const long long first = (((long long)blockIdx.x * 256 + threadIdx.x) >> 6) * (64LL * CC_RUN);
+    int ar = -1, an = 0, alx = 0x7FFFFFFF, ahx = -1, aly = 0x7FFFFFFF, ahy = -1;      // the carried root and its sums (wave-uniform)
+    auto flush = [&]() {
+        if (ar >= 0 && lane == 0) {
+            atomicAdd(area + ar, an);
+            atomicMin(minx + ar, alx); atomicMax(maxx + ar, ahx);
+            atomicMin(miny + ar, aly); atomicMax(maxy + ar, ahy);
+        }
+    };
+    for (int sg = 0; sg < CC_RUN; ++sg) {
+        const long long i = first + 64LL * sg + lane;
+        if (first + 64LL * sg >= n) break;                          // (wave-uniform)
+        int r = -1, x = 0, y = 0;
+        if (i < n && parent[i] >= 0) {
+            r = find_root_ro(parent, (int)i);
+            parent[i] = r;
+            const int p = (int)(i % ((long long)H * W));
+            y = p / W; x = p - y * W;
+        }
+        unsigned long long todo = __ballot(r >= 0);
+        while (todo) {
+            const int leader = __builtin_ctzll(todo);
+            const int r0 = __shfl(r, leader, 64);
+            const bool mine = r == r0;
+            const unsigned long long m = __ballot(mine);
+            int lx = mine ? x : 0x7FFFFFFF, hx = mine ? x : -1, ly = mine ? y : 0x7FFFFFFF, hy = mine ? y : -1;
 #pragma unroll
-        for (int o = 32; o > 0; o >>= 1) {
-            lx = min(lx, __shfl_xor(lx, o, 64)); hx = max(hx, __shfl_xor(hx, o, 64));
-            ly = min(ly, __shfl_xor(ly, o, 64)); hy = max(hy, __shfl_xor(hy, o, 64));
+            for (int o = 32; o > 0; o >>= 1) {
+                lx = min(lx, __shfl_xor(lx, o, 64)); hx = max(hx, __shfl_xor(hx, o, 64));
+                ly = min(ly, __shfl_xor(ly, o, 64)); hy = max(hy, __shfl_xor(hy, o, 64));
+            }
+            if (r0 != ar) { flush(); ar = r0; an = 0; alx = 0x7FFFFFFF; ahx = -1; aly = 0x7FFFFFFF; ahy = -1; }
+            an += __builtin_popcountll(m);
+            alx = min(alx, lx); ahx = max(ahx, hx); aly = min(aly, ly); ahy = max(ahy, hy);
+            todo &= ~m;
         }
-        if (lane == leader) {
-            atomicAdd(area + r0, __builtin_popcountll(m));
-            atomicMin(minx + r0, lx); atomicMax(maxx + r0, hx);
-            atomicMin(miny + r0, ly); atomicMax(maxy + r0, hy);
-        }
-        todo &= ~m;
     }
+    flush();
 }
 
 __global__ __launch_bounds__(256) void k_inv(const uint8_t *__restrict__ labels, uint8_t *inv, long long n)
@@ -286,7 +300,7 @@ hipError_t launch_postprocess_masks(const uint8_t *labels_in, uint8_t *labels_ou
     auto label = [&](const uint8_t *fg) {
         hipLaunchKernelGGL(pp::cc_init, g, b, 0, s, fg, parent, area, minx, miny, maxx, maxy, W, n);
         hipLaunchKernelGGL(pp::cc_merge, g, b, 0, s, fg, parent, H, W, n);
-        hipLaunchKernelGGL(pp::cc_stats, g, b, 0, s, parent, area, minx, miny, maxx, maxy, H, W, n);
+        hipLaunchKernelGGL(pp::cc_stats, dim3((unsigned)((n + 256LL * pp::CC_RUN - 1) / (256LL * pp::CC_RUN))), b, 0, s, parent, area, minx, miny, maxx, maxy, H, W, n);
     };
     hipLaunchKernelGGL(pp::k_inv, g, b, 0, s, labels_in, u0, n);
     label(u0);
@@ -343,21 +357,31 @@ __global__ __launch_bounds__(256) void k_zero_counts(int *counts, int B)
     if (i < B) counts[i] = 0;
 }
 
-// one entry per external component: its root (= start pixel).  fparent: flattened fg labelling; bparent + bbox: background.
+// a background component reaches the image frame iff one of the frame's pixels belongs to it: every background pixel of the frame
+// flags its root (`flag`: zeroed by cc_init).  2 (H + W) pixels per image instead of a statistics pass over all of them.
+__global__ __launch_bounds__(256) void k_frame_flags(const int *__restrict__ bparent, int *flag, int H, int W, int B)
+{
+    const int per = 2 * (H + W), t = blockIdx.x * 256 + threadIdx.x;
+    if (t >= B * per) return;
+    const int img = t / per, k = t - img * per;
+    const int y = k < W ? 0 : k < 2 * W ? H - 1 : k < 2 * W + H ? k - 2 * W : k - 2 * W - H;
+    const int x = k < W ? k : k < 2 * W ? k - W : k < 2 * W + H ? 0 : W - 1;
+    const int p = img * H * W + y * W + x;
+    if (bparent[p] >= 0) flag[pp::find_root_ro(bparent, p)] = 1;
+}
+
+// one entry per external component: its root (= start pixel).  fparent: fg labelling (not flattened: only `is a root` is asked);
+// bparent + flag: background labelling (not flattened either) and which of its roots reach the frame.
 __global__ __launch_bounds__(256) void k_collect(const int *__restrict__ fparent, const int *__restrict__ bparent,
-                                                 const int *__restrict__ bminx, const int *__restrict__ bminy,
-                                                 const int *__restrict__ bmaxx, const int *__restrict__ bmaxy, int *roots,
-                                                 int *counts, int cap, int H, int W, long long n)
+                                                 const int *__restrict__ flag, int *roots, int *counts, int cap, int H, int W, long long n)
 {
     const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
     if (i >= n || fparent[i] != (int)i) return;                // roots only
     const int hw = H * W, img = (int)(i / hw);
     const int p = (int)(i % hw), y = p / W;
     bool external = (y == 0);
-    if (!external) {
-        const int r = bparent[i - W];                           // the pixel above a component's first pixel is background
-        external = r >= 0 && (bminx[r] == 0 || bminy[r] == 0 || bmaxx[r] == W - 1 || bmaxy[r] == H - 1);
-    }
+    if (!external)                                              // the pixel above a component's first pixel is background
+        external = bparent[i - W] >= 0 && flag[pp::find_root_ro(bparent, (int)(i - W))] != 0;
     if (external) {
         const int slot = atomicAdd(counts + img, 1);
         if (slot < cap) roots[(size_t)img * cap + slot] = p;
@@ -552,16 +576,15 @@ hipError_t launch_extract_contours(const uint8_t *masks, int B, int H, int W, in
     int *npts = roots + (size_t)B * cap_contours, *counts = npts + (size_t)B * cap_contours;
     const dim3 g((unsigned)((n + 255) / 256)), b(256);
     hipLaunchKernelGGL(ct::k_threshold, g, b, 0, s, masks, fg, bg, n);
-    // foreground labelling (8-connected); its stats are not needed, the arrays are reused by the background pass
+    // foreground labelling (8-connected): only its roots are asked for (no statistics pass, no flattening)
     hipLaunchKernelGGL(pp::cc_init, g, b, 0, s, fg, fparent, area, minx, miny, maxx, maxy, W, n);
     hipLaunchKernelGGL(pp::cc_merge, g, b, 0, s, fg, fparent, H, W, n);
-    hipLaunchKernelGGL(pp::cc_stats, g, b, 0, s, fparent, area, minx, miny, maxx, maxy, H, W, n);
-    // background labelling (4-connected) with bounding boxes
+    // background labelling (4-connected); `area` (zeroed by cc_init) becomes the reaches-the-frame flag of its roots
     hipLaunchKernelGGL(pp::cc_init, g, b, 0, s, bg, bparent, area, minx, miny, maxx, maxy, W, n);
     hipLaunchKernelGGL(ct::cc_merge4, g, b, 0, s, bg, bparent, H, W, n);
-    hipLaunchKernelGGL(pp::cc_stats, g, b, 0, s, bparent, area, minx, miny, maxx, maxy, H, W, n);
+    hipLaunchKernelGGL(ct::k_frame_flags, dim3((unsigned)((B * 2 * (H + W) + 255) / 256)), b, 0, s, bparent, area, H, W, B);
     hipLaunchKernelGGL(ct::k_zero_counts, dim3((B + 255) / 256), b, 0, s, counts, B);
-    hipLaunchKernelGGL(ct::k_collect, g, b, 0, s, fparent, bparent, minx, miny, maxx, maxy, roots, counts, cap_contours, H, W, n);
+    hipLaunchKernelGGL(ct::k_collect, g, b, 0, s, fparent, bparent, area, roots, counts, cap_contours, H, W, n);
     hipLaunchKernelGGL(ct::k_sort_roots, dim3((B + 63) / 64), dim3(64), 0, s, roots, counts, cap_contours, B);
     // one workgroup per image; the mask as an LDS bit plane when it fits
     const size_t plane = (((size_t)H * W + 31) / 32) * 4 + 4;    // + one word of slack behind the plane (k_trace's windows)
