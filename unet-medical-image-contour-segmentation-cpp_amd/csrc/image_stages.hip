@@ -474,20 +474,25 @@ __global__ __launch_bounds__(256) void k_trace(const uint8_t *__restrict__ fg, c
     // on the resulting 8-bit mask instead of up to eight chained probes.
     // three pixels (x-1, x, x+1) of row y as bits 0..2: the rows of the plane are packed back to back, so they are three
     // CONSECUTIVE bits of one 64-bit window (two LDS words), whatever W is; columns outside the image are masked off
-    auto row3 = [&](int x, int y) -> unsigned {
-        if (y < 0 || y >= H) return 0u;
-        const int p = y * W + x;
-        const int q = p > 0 ? p - 1 : 0;                        // first bit of the window (p = 0 only at the image origin)
-        const unsigned lo = bits[q >> 5], hi = bits[(q >> 5) + 1];
-        unsigned v = (unsigned)((((unsigned long long)hi << 32) | lo) >> (q & 31));
-        if (p == 0) v <<= 1;
-        return v & (x > 0 ? 7u : 6u) & (x + 1 < W ? 7u : 3u);
-    };
+    // Branch-free: a row outside the image reads the plane's first words and is masked to zero afterwards, so the six LDS reads of a
+    // step are issued together and waited for ONCE (with an early return per row hipcc waited three times per border pixel).
     auto nb8 = [&](int x, int y) -> unsigned {                  // bit d = neighbour in direction d is foreground
         if constexpr (IN_LDS) {
-            const unsigned r0 = row3(x, y - 1), r1 = row3(x, y), r2 = row3(x, y + 1);
-            return ((r1 >> 2) & 1u) | (((r0 >> 2) & 1u) << 1) | (((r0 >> 1) & 1u) << 2) | ((r0 & 1u) << 3) | ((r1 & 1u) << 4) |
-                   ((r2 & 1u) << 5) | (((r2 >> 1) & 1u) << 6) | (((r2 >> 2) & 1u) << 7);
+            const unsigned cols = (x > 0 ? 7u : 6u) & (x + 1 < W ? 7u : 3u);
+            unsigned r[3];
+#pragma unroll
+            for (int k = 0; k < 3; ++k) {
+                const int yy = y - 1 + k;
+                const bool ok = (unsigned)yy < (unsigned)H;
+                const int q = yy * W + x - 1;                   // first bit of the window; -1 only at the image origin
+                const int qc = ok ? (q > 0 ? q : 0) : 0;
+                const unsigned lo = bits[qc >> 5], hi = bits[(qc >> 5) + 1];
+                unsigned v = (unsigned)((((unsigned long long)hi << 32) | lo) >> (qc & 31));
+                if (q < 0) v <<= 1;
+                r[k] = ok ? (v & cols) : 0u;
+            }
+            return ((r[1] >> 2) & 1u) | (((r[0] >> 2) & 1u) << 1) | (((r[0] >> 1) & 1u) << 2) | ((r[0] & 1u) << 3) | ((r[1] & 1u) << 4) |
+                   ((r[2] & 1u) << 5) | (((r[2] >> 1) & 1u) << 6) | (((r[2] >> 2) & 1u) << 7);
         } else {
             unsigned m = 0;
 #pragma unroll
