@@ -120,9 +120,12 @@ def test_three_tracers_agree_on_adversarial_masks():
             got = eng.extract_contours(m[None], cap_points=4 * h * w, cap_contours=h * w)[0]
         assert got == orc.find_contours(m) == hostlib.extract_contours(m)
     rng = np.random.default_rng(11)
-    for density in (0.25, 0.5, 0.75):
-        noise = np.stack([(rng.random((32, 48)) < density).astype(np.uint8) * 255 for _ in range(8)])
-        with binding.Engine(32, 48, 1, 16, 1, 3, max_batch=4) as eng:
-            got = eng.extract_contours(noise, cap_points=4 * 32 * 48, cap_contours=32 * 48)
-        for i in range(8):
-            assert got[i] == orc.find_contours(noise[i]) == hostlib.extract_contours(noise[i]), (density, i)
+    # (two width classes of the device tracer: 48 = rows packed back to back in the bit plane; 64 = rows are whole words, the plane
+    # carries a zero row above and below and the walk has no row tests -- noise touches every edge of the frame)
+    for hh, ww in ((32, 48), (24, 64)):
+        for density in (0.25, 0.5, 0.75):
+            noise = np.stack([(rng.random((hh, ww)) < density).astype(np.uint8) * 255 for _ in range(8)])
+            with binding.Engine(hh, ww, 1, 16, 1, 3, max_batch=4) as eng:
+                got = eng.extract_contours(noise, cap_points=4 * hh * ww, cap_contours=hh * ww)
+            for i in range(8):
+                assert got[i] == orc.find_contours(noise[i]) == hostlib.extract_contours(noise[i]), (hh, ww, density, i)

@@ -410,7 +410,10 @@ __global__ __launch_bounds__(64) void k_sort_roots(int *roots, const int *counts
 // The walk is a chain of dependent pixel probes (2-8 per border step), so the probe latency IS the kernel time: a workgroup
 // = one image first packs the thresholded mask into an LDS bit plane (H*W/8 bytes: 32 KB at 512x512; images past the LDS
 // budget keep probing global memory), then the lanes that own a contour walk it at LDS latency.
-template <bool IN_LDS>
+// PAD (IN_LDS and W % 32 == 0, so that rows are whole words): the plane carries one zero row above the image and one below it.
+// Every row of a 3 x 3 probe then exists, the window's first bit is never negative, and the three rows of a probe share their
+// shift -- the probe of a border step loses its row tests and selects.
+template <bool IN_LDS, bool PAD = false>
 __global__ __launch_bounds__(256) void k_trace(const uint8_t *__restrict__ fg, const int *__restrict__ roots,
                                                const int *__restrict__ counts, int cap, int H, int W, int B, int *npts,
                                                const int *__restrict__ offs, int *out_xy, int cap_points, int write)
@@ -421,9 +424,13 @@ __global__ __launch_bounds__(256) void k_trace(const uint8_t *__restrict__ fg, c
     const int nc = counts[img];
     if (nc <= 0 || nc > cap) return;                             // workgroup-uniform
     if (write && nc == 1) return;                                // contour 0 was written by the count pass
+    static_assert(!PAD || IN_LDS, "the padded plane lives in LDS");
+    const int padw = PAD ? (W >> 5) : 0;                         // words of the zero row in front of the image
     if constexpr (IN_LDS) {
         const int nwords = (H * W + 31) >> 5;
-        if (threadIdx.x == 0) bits[nwords] = 0;                  // one word past the plane: the 64-bit windows below may touch it
+        if (threadIdx.x == 0) bits[nwords + 2 * padw] = 0;       // one word past the plane: the 64-bit windows below may touch it
+        if constexpr (PAD)
+            for (int w = threadIdx.x; w < padw; w += 256) { bits[w] = 0; bits[padw + nwords + w] = 0; }
         for (int w = threadIdx.x; w < nwords; w += 256) {
             unsigned m = 0;
             const int base = w << 5;
@@ -437,14 +444,14 @@ __global__ __launch_bounds__(256) void k_trace(const uint8_t *__restrict__ fg, c
             } else {
                 for (int k = 0; k < 32 && base + k < H * W; ++k) m |= (im[base + k] != 0 ? 1u : 0u) << k;
             }
-            bits[w] = m;
+            bits[padw + w] = m;
         }
         __syncthreads();
     }
     auto at = [&](int x, int y) -> bool {
         if (x < 0 || x >= W || y < 0 || y >= H) return false;
         const int p = y * W + x;
-        if constexpr (IN_LDS) return (bits[p >> 5] >> (p & 31)) & 1u;
+        if constexpr (IN_LDS) return (bits[padw + (p >> 5)] >> (p & 31)) & 1u;
         else return im[p] != 0;
     };
     // direction d: 0 = E, then counter-clockwise on screen (y grows down): DX = {1,1,0,-1,-1,-1,0,1}, DY = {0,-1,-1,-1,0,1,1,1}.
@@ -477,7 +484,20 @@ __global__ __launch_bounds__(256) void k_trace(const uint8_t *__restrict__ fg, c
     // Branch-free: a row outside the image reads the plane's first words and is masked to zero afterwards, so the six LDS reads of a
     // step are issued together and waited for ONCE (with an early return per row hipcc waited three times per border pixel).
     auto nb8 = [&](int x, int y) -> unsigned {                  // bit d = neighbour in direction d is foreground
-        if constexpr (IN_LDS) {
+        if constexpr (PAD) {
+            const unsigned cols = (x > 0 ? 7u : 6u) & (x + 1 < W ? 7u : 3u);
+            const int q = (y + 1) * W + x - 1;                  // row y of the image is row y + 1 of the plane: q >= W - 1
+            const unsigned *const b = bits + (q >> 5);
+            const int sh = q & 31;
+            unsigned r[3];
+#pragma unroll
+            for (int k = 0; k < 3; ++k) {
+                const unsigned *const bk = b + (k - 1) * padw;
+                r[k] = (unsigned)((((unsigned long long)bk[1] << 32) | bk[0]) >> sh) & cols;
+            }
+            return ((r[1] >> 2) & 1u) | (((r[0] >> 2) & 1u) << 1) | (((r[0] >> 1) & 1u) << 2) | ((r[0] & 1u) << 3) | ((r[1] & 1u) << 4) |
+                   ((r[2] & 1u) << 5) | (((r[2] >> 1) & 1u) << 6) | (((r[2] >> 2) & 1u) << 7);
+        } else if constexpr (IN_LDS) {
             const unsigned cols = (x > 0 ? 7u : 6u) & (x + 1 < W ? 7u : 3u);
             unsigned r[3];
 #pragma unroll
@@ -594,9 +614,14 @@ hipError_t launch_extract_contours(const uint8_t *masks, int B, int H, int W, in
     // one workgroup per image; the mask as an LDS bit plane when it fits
     const size_t plane = (((size_t)H * W + 31) / 32) * 4 + 4;    // + one word of slack behind the plane (k_trace's windows)
     const bool in_lds = plane <= 160 * 1024;                     // the whole LDS of a CU: 1024x1024 is 128 KB + 4
+    const size_t padded = plane + 2 * (size_t)(W / 32) * 4;      // + a zero row above and below (k_trace<true, true>)
+    const bool pad = W % 32 == 0 && padded <= 160 * 1024;
     const dim3 gt((unsigned)B), bt(256);
     for (int pass = 0; pass < 2; ++pass) {
-        if (in_lds) {
+        if (pad) {
+            if (hipError_t e = ensure_dynamic_lds(ct::k_trace<true, true>, padded); e != hipSuccess) return e;
+            hipLaunchKernelGGL((ct::k_trace<true, true>), gt, bt, padded, s, fg, roots, counts, cap_contours, H, W, B, npts, out_start, out_xy, cap_points, pass);
+        } else if (in_lds) {
             if (hipError_t e = ensure_dynamic_lds(ct::k_trace<true>, plane); e != hipSuccess) return e;
             hipLaunchKernelGGL(ct::k_trace<true>, gt, bt, plane, s, fg, roots, counts, cap_contours, H, W, B, npts, out_start, out_xy, cap_points, pass);
         } else {
