@@ -359,6 +359,25 @@ def test_tail_micro_batch_takes_other_kernels_and_gives_the_same_bits(algo, monk
     assert np.array_equal(lg3[2], lg2[0]) and np.array_equal(lab3[2], lab2[0])
 
 
+def test_fused_first_layer_gives_the_unfused_bits_at_config5_size(monkeypatch):
+    """BASELINE config 5's shape (1024 x 1024 x 3, base 32, five levels, batch 8): inc.c1 inside inc.c2's launch (conv3x3_lpr FIRST:
+    fp32 MFMAs threaded between the conv's MFMA steps, window bytes by LDS-DMA) against inc.c1 as a launch of its own
+    (MIUNET_FUSE_FIRST=0) -- same instruction, same K order: the logits are the same bits, on interior and border tiles alike."""
+    spec = UNetSpec(in_ch=3, base=32, levels=5)
+    blob = pack_weights(spec, synth.make_weights(spec, 77))
+    imgs = synth.make_images(8, 1024, 1024, 3, 5, "blobs")
+    out, fused = {}, {}
+    for mode in ("0", "1"):
+        monkeypatch.setenv("MIUNET_FUSE_FIRST", mode)
+        with binding.Engine(1024, 1024, in_ch=3, base=32, levels=5, classes=3, max_batch=8, conv_algo="fp16") as eng:
+            eng.load_weights(blob)
+            eng.set_profiling(True)
+            out[mode] = eng.infer(imgs, want_logits=True)
+            fused[mode] = [s["kernel"] for s in eng.kernel_stats() if s["kernel"].endswith("+first")]
+    assert fused["0"] == [] and fused["1"] == ["conv3x3_fp16r+first"]
+    assert np.array_equal(out["0"][1].view(np.uint32), out["1"][1].view(np.uint32)) and np.array_equal(out["0"][0], out["1"][0])
+
+
 # ---------------------------------------------------------------- the large transposed convolutions with resident weights (convt_lpr.hip)
 @pytest.mark.parametrize("op,B,H,W,Cin,Cout", [
     ("convT2x2_bf16", 1, 8, 32, 64, 32),        # exactly one 8 x 32 tile: wave = tap x half of the row blocks
