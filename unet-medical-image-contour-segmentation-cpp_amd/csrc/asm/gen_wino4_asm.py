@@ -107,6 +107,9 @@ def prev_kind(kind):
     """the body that ran before a body of this kind in steady state (for the LDS-DMA loads still counted by its early U waits)"""
     return {"first": "last", "mid": "mid", "last": "mid"}[kind]
 U_POLICY = ""                # cache-policy modifier of the U loads (tuning: --u-policy "nt" | "sc0" | "sc1" | "sc0 sc1")
+ST_POLICY = "nt"             # ... of the epilogue's output stores: non-temporal -- the next layer reads them a launch later, from HBM / the Infinity
+                             # Cache either way, and keeping them out of L2 leaves it to U and the halos (same card: the 14 layers 10.08 -> 9.89 ms;
+                             # sc1 / sc0 sc1: 10.02; profiles/r04_ab_store_policy.txt; tuning: --store-policy "")
 TIMING_ONLY = ""             # tuning builds with WRONG results: "notransform" | "nodma" | "nouload" | "novread" (comma-separated)
 STAMPS = False               # bring-up / tuning: s_memtime stamps at the phase boundaries of a tile, summed per wave, written to the POOL pointer
 DUMP = ""                    # bring-up: at the checkpoint, workgroup 0 writes "lds" | "vgpr" | "agpr" to the OUTPUT buffer instead of going on
@@ -624,7 +627,7 @@ def emit_epilogue(E, pool):
                     for rr in range(2):
                         x = 4 * (r0 + rr) + k
                         E.i(f"buffer_store_dword {v(EP_Y + 2 * k + rr)}, {v(EP_VX + x)}, {s(R_OUT, 4)}, {s(S_ROW + i)} offen" +
-                            (" offset:64" if blk else ""))
+                            (" offset:64" if blk else "") + (" " + ST_POLICY if ST_POLICY else ""))
                 if pool:
                     if i % 2 == 0:
                         for rr in range(2):
@@ -638,7 +641,7 @@ def emit_epilogue(E, pool):
                             for j in range(2):
                                 xp = 2 * (r0 + rr) + j
                                 E.i(f"buffer_store_dword {v(EP_C + 2 * j + rr)}, {v(EP_VXP + xp)}, {s(R_POOL, 4)}, {s(S_PROW + (i >> 1))} offen" +
-                                    (" offset:64" if blk else ""))
+                                    (" offset:64" if blk else "") + (" " + ST_POLICY if ST_POLICY else ""))
 
 
 # ----------------------------------------------------------------------------------------------------------------- kernel
@@ -986,9 +989,11 @@ def emit_kernel(E, name):
 
 def main():
     global UD, AV0
-    global STOP_AT, DUMP, STAMPS, DMA_POS, TIMING_ONLY, U_POLICY, DMA_POS_FIRST
+    global STOP_AT, DUMP, STAMPS, DMA_POS, TIMING_ONLY, U_POLICY, DMA_POS_FIRST, ST_POLICY
     if "--u-policy" in sys.argv:
         U_POLICY = sys.argv[sys.argv.index("--u-policy") + 1]
+    if "--store-policy" in sys.argv:
+        ST_POLICY = sys.argv[sys.argv.index("--store-policy") + 1]
     if "--dma-pos-first" in sys.argv:
         DMA_POS_FIRST = tuple(int(x) for x in sys.argv[sys.argv.index("--dma-pos-first") + 1].split(","))
     if "--dma-pos" in sys.argv:

@@ -268,6 +268,8 @@ def emit_transform(E, rbuf):
 
 
 # ------------------------------------------------------------------------------------------------------------- chunk body
+ST_POLICY = ""               # cache policy of the output stores: the default one -- "nt", which pays in gen_wino4_asm.py, costs here (same card: up4.c1
+                             # 1.45 -> 1.51 ms, profiles/r04_ab_store_policy.txt); tuning: --store-policy
 DMA_POS = tuple(range(1, 34, 3))          # one LDS-DMA load every third position of the MFMA phase (tuning: --dma-pos; same card: the first
                                           # eleven positions 1.518 ms, every second 1.504, every third 1.47, positions 12..22 1.53)
 
@@ -467,7 +469,7 @@ def emit_epilogue(E, pool):
                 for k in range(4):
                     for rr in range(2):
                         x = 4 * (r0 + rr) + k
-                        E.i(f"buffer_store_dword {v(EP_Y + 2 * k + rr)}, {v(EP_VX + x)}, {s(R_OUT, 4)}, {s(row_s)} offen")
+                        E.i(f"buffer_store_dword {v(EP_Y + 2 * k + rr)}, {v(EP_VX + x)}, {s(R_OUT, 4)}, {s(row_s)} offen" + (" " + ST_POLICY if ST_POLICY else ""))
                 if pool:
                     if i % 2 == 0:
                         for rr in range(2):
@@ -484,7 +486,7 @@ def emit_epilogue(E, pool):
                         for rr in range(2):
                             for j in range(2):
                                 xp = 2 * (r0 + rr) + j
-                                E.i(f"buffer_store_dword {v(EP_C + 2 * j + rr)}, {v(EP_VXP + xp)}, {s(R_POOL, 4)}, {s(prow_s)} offen")
+                                E.i(f"buffer_store_dword {v(EP_C + 2 * j + rr)}, {v(EP_VXP + xp)}, {s(R_POOL, 4)}, {s(prow_s)} offen" + (" " + ST_POLICY if ST_POLICY else ""))
 
 
 # ----------------------------------------------------------------------------------------------------------------- kernel
@@ -789,13 +791,15 @@ def emit_kernel(E, name):
 
 
 def main():
-    global STOP_AT, DUMP, DMA_POS
+    global STOP_AT, DUMP, DMA_POS, ST_POLICY
     out = sys.argv[1] if len(sys.argv) > 1 else "wino4b_gfx950.s"
     if "--ud" in sys.argv:
         layout(int(sys.argv[sys.argv.index("--ud") + 1]))
     if "--dma-pos" in sys.argv:
         DMA_POS = tuple(int(x) for x in sys.argv[sys.argv.index("--dma-pos") + 1].split(","))
         assert len(DMA_POS) == DMA_PER_WAVE and len(set(DMA_POS)) == DMA_PER_WAVE and max(DMA_POS) < 36
+    if "--store-policy" in sys.argv:
+        ST_POLICY = sys.argv[sys.argv.index("--store-policy") + 1]
     if "--dump" in sys.argv:
         DUMP = sys.argv[sys.argv.index("--dump") + 1]
     if "--stop" in sys.argv:

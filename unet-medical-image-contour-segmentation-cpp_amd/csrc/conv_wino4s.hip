@@ -326,7 +326,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wino4s_f32(const ConvArgs a, c
                         unsigned voff = vbase;
                         if constexpr (!INTERIOR) voff = row_ok ? vcol[r][k] : 0xFFFFFFFFu;
                         __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), out_rsrc, voff,
-                                                              i * row_bytes + (4 * r + k) * pix_bytes, 0);
+                                                              i * row_bytes + (4 * r + k) * pix_bytes, ST_AUX);
                     }
                 if (!HEAD && do_pool) {
                     f32x2 hm0, hm1;               // horizontal maxima of this row: pooled columns 2r and 2r + 1
@@ -341,9 +341,9 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wino4s_f32(const ConvArgs a, c
                             unsigned v0 = pbase, v1 = pbase;
                             if constexpr (!INTERIOR) { v0 = row_ok ? pcol[r][0] : 0xFFFFFFFFu; v1 = row_ok ? pcol[r][1] : 0xFFFFFFFFu; }
                             __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, p0), pool_rsrc, v0,
-                                                                  (i >> 1) * prow_bytes + (2 * r) * ppix_bytes, 0);
+                                                                  (i >> 1) * prow_bytes + (2 * r) * ppix_bytes, ST_AUX);
                             __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, p1), pool_rsrc, v1,
-                                                                  (i >> 1) * prow_bytes + (2 * r + 1) * ppix_bytes, 0);
+                                                                  (i >> 1) * prow_bytes + (2 * r + 1) * ppix_bytes, ST_AUX);
                         }
                     }
                 }

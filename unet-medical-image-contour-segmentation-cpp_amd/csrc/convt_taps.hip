@@ -190,7 +190,7 @@ __global__ __launch_bounds__(256, WPS) void convT2x2_taps_f32(const ConvArgs a, 
                     unsigned voff = vbase;
                     if constexpr (!INTERIOR) voff = (row_ok && x0 + xr + 4 * lh < a.W) ? vbase : 0xFFFFFFFFu;
                     __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, acc[mb][nb][r] + bias), out_rsrc, voff,
-                                                          (2 * mb * W2 + 2 * xr) * pix_bytes, 0);
+                                                          (2 * mb * W2 + 2 * xr) * pix_bytes, ST_AUX);
                 }
             }
         }

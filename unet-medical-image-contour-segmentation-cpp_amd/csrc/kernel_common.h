@@ -9,6 +9,15 @@
 
 namespace miunet {
 
+// cache policy of the hipcc fp32 kernels' OUTPUT stores (the aux operand of the raw buffer store builtins; gfx940+: bit 0 = sc0,
+// bit 1 = nt, bit 4 = sc1).  Non-temporal stores pay in the assembly two-block kernel (gen_wino4_asm.py) and not here: same card,
+// -DMIUNET_ST_AUX=2 against 0: inc.c2 1.105 -> 1.13 ms, the transposed convs +- 0.008 (profiles/r04_ab_store_policy.txt).
+#ifndef MIUNET_ST_AUX
+#define MIUNET_ST_AUX 0
+#endif
+constexpr int ST_AUX = MIUNET_ST_AUX;
+
+
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
