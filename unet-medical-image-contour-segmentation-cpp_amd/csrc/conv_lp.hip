@@ -271,7 +271,7 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_bf16(const ConvArgs a, const
                 const bool ok = y0 + py < a.H && x0 + pxx < a.W && n0 + 8 * q < a.Cout;
                 const u32x4 v = *reinterpret_cast<const u32x4 *>(Ts + px * TROW + 8 * q);
                 __builtin_amdgcn_raw_buffer_store_b128(v, out_rsrc,
-                    ok ? (unsigned)((((y0 + py) * a.W + x0 + pxx) * a.ldo + a.co_off + n0 + 8 * q) * ES) : 0xFFFFFFFFu, 0, 0);
+                    ok ? (unsigned)((((y0 + py) * a.W + x0 + pxx) * a.ldo + a.co_off + n0 + 8 * q) * ES) : 0xFFFFFFFFu, 0, LP_ST_AUX);
                 wide_store_guard();
             }
             if (do_pool) {
@@ -281,7 +281,7 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_bf16(const ConvArgs a, const
                     const bool ok = y0 + 2 * py + 1 < a.H && x0 + 2 * pxx + 1 < a.W && n0 + 8 * q < a.Cout;
                     const u32x4 v = *reinterpret_cast<const u32x4 *>(Ps + px * TROW + 8 * q);
                     __builtin_amdgcn_raw_buffer_store_b128(v, pool_rsrc,
-                        ok ? (unsigned)(((((y0 >> 1) + py) * Wp + (x0 >> 1) + pxx) * a.pool_ld + n0 + 8 * q) * ES) : 0xFFFFFFFFu, 0, 0);
+                        ok ? (unsigned)(((((y0 >> 1) + py) * Wp + (x0 >> 1) + pxx) * a.pool_ld + n0 + 8 * q) * ES) : 0xFFFFFFFFu, 0, LP_ST_AUX);
                     wide_store_guard();
                 }
             }

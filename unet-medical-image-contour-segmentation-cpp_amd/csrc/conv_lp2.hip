@@ -47,6 +47,13 @@
 #include <cstdlib>
 #include <type_traits>
 
+// this file's 16-byte output stores are non-temporal (kernel_common.h: LP_ST_AUX).  Same-card A/B of every 16-bit kernel
+// (profiles/r04_ab_store_policy.txt): the wide layers of config 3 3.05 -> 2.99 ms with it -- their consumers of the two smallest
+// tensors, which had found them in L2, + 0.016 --; neutral or worse in the resident-weight kernels, the transposed convs and the
+// first layer, which keep the default policy.
+#ifndef MIUNET_LP_ST_AUX
+#define MIUNET_LP_ST_AUX 2
+#endif
 #include "kernel_common.h"
 #include "lpr_common.h"
 
@@ -255,7 +262,7 @@ __global__ __launch_bounds__(256, 1) void conv3x3_lp2(const ConvArgs a, const in
                         const u32x4 v = *reinterpret_cast<const u32x4 *>(Ts + m * TROW + 8 * q);
                         const bool ok = INTERIOR || (yw + i < a.H && x0 + m < a.W);
                         __builtin_amdgcn_raw_buffer_store_b128(v, out_rsrc,
-                            ok ? (unsigned)((((yw + i) * a.W + x0 + m) * a.ldo + a.co_off + n0 + 32 * jp + 8 * q) * 2) : 0xFFFFFFFFu, 0, 0);
+                            ok ? (unsigned)((((yw + i) * a.W + x0 + m) * a.ldo + a.co_off + n0 + 32 * jp + 8 * q) * 2) : 0xFFFFFFFFu, 0, LP_ST_AUX);
                         wide_store_guard();
                     }
                     if (do_pool && (i & 1)) {
@@ -263,7 +270,7 @@ __global__ __launch_bounds__(256, 1) void conv3x3_lp2(const ConvArgs a, const in
                         const u32x4 v = *reinterpret_cast<const u32x4 *>(Ps + m * TROW + 8 * q);
                         const bool ok = INTERIOR || (yw + i < a.H && x0 + 2 * m + 1 < a.W);
                         __builtin_amdgcn_raw_buffer_store_b128(v, pool_rsrc,
-                            ok ? (unsigned)(((((yw + i) >> 1) * Wp + (x0 >> 1) + m) * a.pool_ld + n0 + 32 * jp + 8 * q) * 2) : 0xFFFFFFFFu, 0, 0);
+                            ok ? (unsigned)(((((yw + i) >> 1) * Wp + (x0 >> 1) + m) * a.pool_ld + n0 + 32 * jp + 8 * q) * 2) : 0xFFFFFFFFu, 0, LP_ST_AUX);
                         wide_store_guard();
                     }
                 }
@@ -482,7 +489,7 @@ __global__ __launch_bounds__(256, 1) void conv3x3_lp2n(const ConvArgs a, const i
                 const u32x4 v = *reinterpret_cast<const u32x4 *>(Ts + mm * TROW + 8 * q);
                 const bool ok = (INTERIOR || (y0 + i < a.H && x0 + mm < a.W)) && c0 + 8 * q < a.Cout;
                 __builtin_amdgcn_raw_buffer_store_b128(v, out_rsrc,
-                    ok ? (unsigned)((((y0 + i) * a.W + x0 + mm) * a.ldo + a.co_off + c0 + 8 * q) * 2) : 0xFFFFFFFFu, 0, 0);
+                    ok ? (unsigned)((((y0 + i) * a.W + x0 + mm) * a.ldo + a.co_off + c0 + 8 * q) * 2) : 0xFFFFFFFFu, 0, LP_ST_AUX);
                 wide_store_guard();
             }
             if (do_pool && (i & 1)) {
@@ -490,7 +497,7 @@ __global__ __launch_bounds__(256, 1) void conv3x3_lp2n(const ConvArgs a, const i
                 const u32x4 v = *reinterpret_cast<const u32x4 *>(Ps + mm * TROW + 8 * q);
                 const bool ok = (INTERIOR || (y0 + i < a.H && x0 + 2 * mm + 1 < a.W)) && c0 + 8 * q < a.Cout;
                 __builtin_amdgcn_raw_buffer_store_b128(v, pool_rsrc,
-                    ok ? (unsigned)(((((y0 + i) >> 1) * Wp + (x0 >> 1) + mm) * a.pool_ld + c0 + 8 * q) * 2) : 0xFFFFFFFFu, 0, 0);
+                    ok ? (unsigned)(((((y0 + i) >> 1) * Wp + (x0 >> 1) + mm) * a.pool_ld + c0 + 8 * q) * 2) : 0xFFFFFFFFu, 0, LP_ST_AUX);
                 wide_store_guard();
             }
         }

@@ -572,7 +572,7 @@ __global__ __launch_bounds__(512, 1) void conv3x3_lpr(const ConvArgs a, const in
                     const u32x4 v = *reinterpret_cast<const u32x4 *>(Ts + m * TROW + 8 * q);
                     unsigned voff = ovoff[mb][j][it];
                     if ((edge && !(yb + 2 * rp + (m >> 4) < a.H && x0 + 16 * (ch0 + mb) + (m & 15) < a.W)) || (exp & 2)) voff = 0xFFFFFFFFu;
-                    __builtin_amdgcn_raw_buffer_store_b128(v, out_rsrc, voff, osoff + (unsigned)(8 * rb * a.W * a.ldo * 2), 0);
+                    __builtin_amdgcn_raw_buffer_store_b128(v, out_rsrc, voff, osoff + (unsigned)(8 * rb * a.W * a.ldo * 2), LP_ST_AUX);
                     wide_store_guard();
                 }
                 if (do_pool) {
@@ -580,7 +580,7 @@ __global__ __launch_bounds__(512, 1) void conv3x3_lpr(const ConvArgs a, const in
                     const u32x4 v = *reinterpret_cast<const u32x4 *>(Ps + m * TROW + 8 * q);
                     unsigned voff = pvoff[mb][j];
                     if (edge && !(yb + 2 * rp + 1 < a.H && x0 + 16 * (ch0 + mb) + 2 * m + 1 < a.W)) voff = 0xFFFFFFFFu;
-                    __builtin_amdgcn_raw_buffer_store_b128(v, pool_rsrc, voff, psoff + (unsigned)(4 * rb * Wp * a.pool_ld * 2), 0);
+                    __builtin_amdgcn_raw_buffer_store_b128(v, pool_rsrc, voff, psoff + (unsigned)(4 * rb * Wp * a.pool_ld * 2), LP_ST_AUX);
                     wide_store_guard();
                 }
             }

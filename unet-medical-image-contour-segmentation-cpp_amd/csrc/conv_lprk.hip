@@ -236,7 +236,7 @@ __global__ __launch_bounds__(512, 1) void conv3x3_lprk(const ConvArgs a, const i
             const u32x4 v = *reinterpret_cast<const u32x4 *>(Ts + m * TROW + 8 * q);
             unsigned voff = ovoff[it];
             if (edge && !(y0 + 2 * rp + (m >> 4) < a.H && x0 + 16 * kh + (m & 15) < a.W)) voff = 0xFFFFFFFFu;
-            __builtin_amdgcn_raw_buffer_store_b128(v, out_rsrc, voff, osoff, 0);
+            __builtin_amdgcn_raw_buffer_store_b128(v, out_rsrc, voff, osoff, LP_ST_AUX);
             wide_store_guard();
         }
     }

@@ -16,6 +16,11 @@ namespace miunet {
 #define MIUNET_ST_AUX 0
 #endif
 constexpr int ST_AUX = MIUNET_ST_AUX;
+// ... and of the 16-bit kernels' 16-byte output stores (-DMIUNET_LP_ST_AUX=2 for an A/B)
+#ifndef MIUNET_LP_ST_AUX
+#define MIUNET_LP_ST_AUX 0
+#endif
+constexpr int LP_ST_AUX = MIUNET_LP_ST_AUX;
 
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));

@@ -225,7 +225,7 @@ __global__ __launch_bounds__(256) void conv3x3_first_mfma(const uint8_t *__restr
                 const int e = lane + 64 * it, m = e >> 2, q = e & 3;
                 const u32x4 v = *reinterpret_cast<const u32x4 *>(Ts + m * TROW + 8 * q);
                 const bool ok = y < H && x0 + m < W && 32 * j + 8 * q < Cout;
-                __builtin_amdgcn_raw_buffer_store_b128(v, out_rsrc, ok ? (unsigned)((((y * W) + x0 + m) * ldo + 32 * j + 8 * q) * 2) : 0xFFFFFFFFu, 0, 0);
+                __builtin_amdgcn_raw_buffer_store_b128(v, out_rsrc, ok ? (unsigned)((((y * W) + x0 + m) * ldo + 32 * j + 8 * q) * 2) : 0xFFFFFFFFu, 0, LP_ST_AUX);
                 wide_store_guard();
             }
         }
