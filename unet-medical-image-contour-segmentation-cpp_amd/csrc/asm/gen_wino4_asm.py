@@ -107,7 +107,6 @@ def prev_kind(kind):
     """the body that ran before a body of this kind in steady state (for the LDS-DMA loads still counted by its early U waits)"""
     return {"first": "last", "mid": "mid", "last": "mid"}[kind]
 U_POLICY = ""                # cache-policy modifier of the U loads (tuning: --u-policy "nt" | "sc0" | "sc1" | "sc0 sc1")
-DMA_POLICY = ""              # ... of the raw-patch LDS-DMA loads (tuning: --dma-policy)
 ST_POLICY = "nt"             # ... of the epilogue's output stores: non-temporal -- the next layer reads them a launch later, from HBM / the Infinity
                              # Cache either way, and keeping them out of L2 leaves it to U and the halos (same card: the 14 layers 10.08 -> 9.89 ms;
                              # sc1 / sc0 sc1: 10.02; profiles/r04_ab_store_policy.txt; tuning: --store-policy "")
@@ -421,7 +420,7 @@ def emit_body(E, role, par, kind):
                 lq.issue(("AV", p + 1))
             for n, j in enumerate(dma_idx):
                 if m == 1 + 2 * n:
-                    E.i(f"buffer_load_dwordx4 {v(V_VOFF0 + j)}, {s(R_IN, 4)}, {s(L_DMAOFF)} offen" + (" " + DMA_POLICY if DMA_POLICY else "") + " lds")
+                    E.i(f"buffer_load_dwordx4 {v(V_VOFF0 + j)}, {s(R_IN, 4)}, {s(L_DMAOFF)} offen lds")
             if m == 3:
                 for act in valu:
                     if act[0] == "waitL":
@@ -550,7 +549,7 @@ def emit_dma_chunk(E, buf, sidx_range=range(6)):
     for j in sidx_range:
         E.i(f"s_add_u32 m0, {s(L_M0BASE)}, {buf * RAWBUF_B + 4096 * j}")
         E.i("s_nop 0")
-        E.i(f"buffer_load_dwordx4 {v(V_VOFF0 + j)}, {s(R_IN, 4)}, {s(L_DMAOFF)} offen" + (" " + DMA_POLICY if DMA_POLICY else "") + " lds")
+        E.i(f"buffer_load_dwordx4 {v(V_VOFF0 + j)}, {s(R_IN, 4)}, {s(L_DMAOFF)} offen lds")
 
 
 def emit_u_ring_fill(E):
@@ -990,13 +989,11 @@ def emit_kernel(E, name):
 
 def main():
     global UD, AV0
-    global STOP_AT, DUMP, STAMPS, DMA_POS, TIMING_ONLY, U_POLICY, DMA_POS_FIRST, ST_POLICY, DMA_POLICY
+    global STOP_AT, DUMP, STAMPS, DMA_POS, TIMING_ONLY, U_POLICY, DMA_POS_FIRST, ST_POLICY
     if "--u-policy" in sys.argv:
         U_POLICY = sys.argv[sys.argv.index("--u-policy") + 1]
     if "--store-policy" in sys.argv:
         ST_POLICY = sys.argv[sys.argv.index("--store-policy") + 1]
-    if "--dma-policy" in sys.argv:
-        DMA_POLICY = sys.argv[sys.argv.index("--dma-policy") + 1]
     if "--dma-pos-first" in sys.argv:
         DMA_POS_FIRST = tuple(int(x) for x in sys.argv[sys.argv.index("--dma-pos-first") + 1].split(","))
     if "--dma-pos" in sys.argv:
